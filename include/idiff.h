@@ -1,0 +1,187 @@
+/*
+ * idiff.h -- C ABI of the MI355X-native InstanceDiff hot path (gfx950 HIP kernels).
+ *
+ * The reference (zyc-123/InstanceDiff) is pure Python: its "FFI" for this path is the YAML-keyed
+ * plugin registry (models/__init__.py:4-12 -> create_net / create_sde) and every device kernel is an
+ * implicit ATen/cuDNN dispatch.  Each entry point below names the reference call site(s) whose
+ * implicit kernels it replaces.  The Python host side (instancediff_amd/) binds these with ctypes;
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - all tensor pointers are DEVICE pointers to fp32 unless stated; NCHW, contiguous inside a sample;
+ *     "bstride" = elements between consecutive samples (lets a tensor be a channel slice of a bigger one)
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work (no sync, no alloc, no free)
+ *   - caller owns every buffer, including workspaces; no pointer is retained after return
+ *   - return 0 on success, <0 on error (IDIFF_E_*); idiff_last_error() gives a message
+ */
+#ifndef IDIFF_H
+#define IDIFF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IDIFF_OK 0
+#define IDIFF_E_BADARG (-1)
+#define IDIFF_E_UNSUPPORTED (-2)
+#define IDIFF_E_HIP (-3)
+
+typedef void* idiff_stream_t;
+
+const char* idiff_last_error(void);
+int idiff_version(void);
+/* number of compute units etc. of the current device (plumbing for grid sizing / tests) */
+int idiff_device_info(int* num_cu, int* wave_size, char* arch_name, int arch_name_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on the f32 matrix cores (v_mfma_f32_32x32x2_f32), NCHW fp32.
+ * Replaces: every nn.Conv2d inside the (missing) UNet body -- ResBlock convs, init 7x7, final 3x3,
+ * res 1x1, Down/Up-sample (call sites models/drift_noise_model.py:250-268).
+ * ---------------------------------------------------------------------------------------------- */
+#define IDIFF_CONV_NORMAL 0     /* out HxW = in HxW, pad = ks/2                                         */
+#define IDIFF_CONV_UPSAMPLE2 1  /* nearest x2 upsample fused into the gather: out = 2Hin x 2Win         */
+#define IDIFF_CONV_UNSHUFFLE2 2 /* pixel_unshuffle(2) fused: virtual Cin = 4*C0, out = Hin/2 x Win/2, ks=1 */
+
+typedef struct {
+    const float* src0;      /* [B, C0, Hin, Win]                                                      */
+    const float* src1;      /* optional second source, channels appended after src0 (virtual concat)  */
+    int64_t src0_bstride, src1_bstride;
+    int32_t C0, C1;
+    int32_t B, Hin, Win;
+    int32_t mode;           /* IDIFF_CONV_*                                                            */
+    int32_t ks;             /* 1, 3 or 7                                                               */
+    int32_t Cout;
+    const float* wpk;       /* packed weights [ks*ks][Cin][Cout] (idiff_pack_conv_weight)             */
+    const float* bias;      /* [Cout] or NULL                                                          */
+    /* prologue on src0 (requires C1 == 0): v = silu(pro_a[b,c]*v + pro_b[b,c]); zero padding applies
+       AFTER the activation (it pads the activated tensor). NULL = raw input.                          */
+    const float* pro_a;
+    const float* pro_b;
+    /* epilogue */
+    float* out;             /* [B, Cout, Hout, Wout]                                                   */
+    int64_t out_bstride;
+    const float* res;       /* optional residual, same shape as out (res_bstride)                      */
+    int64_t res_bstride;
+    const float* vec;       /* optional per-(b,co) additive vector [B, Cout]                           */
+    /* optional epilogue term: out += silu(aux_a[b,co]*aux[b,co,y,x] + aux_b[b,co])  (GN+SiLU of another tensor) */
+    const float* aux;
+    int64_t aux_bstride;
+    const float* aux_a;
+    const float* aux_b;
+    float* stats;           /* optional GroupNorm partials [B][ntiles][Cout][2] (sum, sumsq) of the value
+                               acc+bias, ntiles = idiff_conv2d_num_tiles(Hout,Wout)                     */
+} idiff_conv_desc;
+
+int idiff_conv2d_num_tiles(int Hout, int Wout);
+int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream);
+/* w [Cout][Cin][ks][ks] (torch layout) -> wpk [ks*ks][Cin][Cout] */
+int idiff_pack_conv_weight(const float* w, float* wpk, int Cout, int Cin, int ks, idiff_stream_t stream);
+/* same, but spatially flipped and in/out swapped: wpk_T [ks*ks][Cout][Cin] for the data-gradient conv */
+int idiff_pack_conv_weight_T(const float* w, float* wpk, int Cout, int Cin, int ks, idiff_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GroupNorm (+FiLM) folded to a per-(sample,channel) affine, applied by the consumer kernel.
+ * Replaces: nn.GroupNorm + x*(scale+1)+shift inside every ResBlock.
+ *   mean/var per (b,group) from the conv partials (fp64 finalize), then
+ *   a[b,c] = rstd*gamma[c]*(1+scale[b,c]);  b[b,c] = (beta[c]-mean*rstd*gamma[c])*(1+scale[b,c]) + shift[b,c]
+ *   film: [B, 2C] (scale = film[b, c], shift = film[b, C+c], row stride film_ld) or NULL.
+ *   mean_rstd (optional out): [B, groups, 2] for the backward pass.
+ * ---------------------------------------------------------------------------------------------- */
+int idiff_gn_finalize(const float* stats, int ntiles, int B, int C, int groups, int HW, const float* gamma,
+                      const float* beta, const float* film, int64_t film_ld, float eps, float* out_a, float* out_b,
+                      float* mean_rstd, idiff_stream_t stream);
+
+/* out[b,c,p] = silu(a[b,c]*h[b,c,p] + b[b,c]) + res[b,c,p] + vec[b,c]   (res, vec, a/b optional)
+ * Replaces: GroupNorm->SiLU->(+residual) tail of each ResBlock and the M=1 cross-attention add. */
+int idiff_affine_silu_add(const float* h, int64_t h_bstride, const float* a, const float* b, const float* res,
+                          int64_t res_bstride, const float* vec, float* out, int64_t out_bstride, int B, int C, int HW,
+                          idiff_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Token-side ops (small row counts): Linear, LayerNorm, sinusoidal time embedding.
+ * Replaces: timestep-embedding MLP, per-ResBlock time projections, image-context K/V projections and
+ * the ScoreMapModule text branch (_modified_BiomedCLIP.py:531-541,1205-1223).
+ * ---------------------------------------------------------------------------------------------- */
+#define IDIFF_ACT_NONE 0
+#define IDIFF_ACT_SILU 1
+#define IDIFF_ACT_GELU 2
+/* out[r, n] = res[r,n] + gscale[n] * ( sum_k act_in(x[r,k]) * w[n,k] + bias[n] ), then act_out.
+ * x: [R, K] row stride ldx; w: [N, K] row stride ldw (torch nn.Linear layout); out row stride ldo;
+ * res (row stride ldr), bias, gscale optional (NULL). */
+int idiff_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* res,
+                     int64_t ldr, const float* gscale, float* out, int64_t ldo, int R, int K, int N, int act_in,
+                     int act_out, idiff_stream_t stream);
+int idiff_layernorm_rows_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out,
+                             int64_t ldo, int R, int C, float eps, float* mean_rstd, idiff_stream_t stream);
+/* sinusoidal embedding, [sin | cos] halves; freqs [dim/2] = host-built table exp(-ln(1e4) * i/(half-1))
+ * (NULL = computed on device) */
+int idiff_time_embed_fwd(const float* t, const float* freqs, int B, int dim, float* out, idiff_stream_t stream);
+
+/* LayerNorm over the channel dim of an NCHW map (per pixel). Replaces the pre-norm of attention blocks. */
+int idiff_chan_layernorm_fwd(const float* x, int64_t x_bstride, const float* gamma, const float* beta, float* out,
+                             int64_t out_bstride, int B, int C, int HW, float eps, float* mean_rstd,
+                             idiff_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Attention.  All follow _modified_BiomedCLIP.py:464-478:  softmax(q k^T * scale) v  per head.
+ * ---------------------------------------------------------------------------------------------- */
+/* self-attention over a feature map: qkv [B, 3C, N] channel-major (q rows 0..C-1, k C..2C-1, v 2C..3C-1),
+ * out [B, C, N]; head h owns channels h*dh..(h+1)*dh-1; dh must be 64 or 32; flash-style on f32 MFMA.
+ * lse (optional) [B, heads, N] = log-sum-exp per query for the backward pass. */
+int idiff_attn_self_fwd(const float* qkv, float* out, float* lse, int B, int C, int N, int heads, float scale,
+                        idiff_stream_t stream);
+/* pixels attend to M context tokens: q [B,C,N] channel-major, k,v [B,M,C] token-major, out [B,C,N]; M <= 32 */
+int idiff_attn_ctx_fwd(const float* q, const float* k, const float* v, float* out, int B, int C, int N, int M,
+                       int heads, float scale, idiff_stream_t stream);
+/* tiny token-major attention (ScoreMapModule decoder self-attention): q [B,Nq,C], k,v [B,M,C]; Nq,M <= 64 */
+int idiff_attn_tokens_fwd(const float* q, const float* k, const float* v, float* out, int B, int Nq, int M, int C,
+                          int heads, float scale, idiff_stream_t stream);
+/* ScoreMapModule cross-attention, K/V projections folded onto the query side:
+ *   S[b,h,q,n] = scale * sum_c qf[b,q,h,c] * mem[b,c,n];  P = softmax_n(S);  o[b,q,h,c] = sum_n P * mem[b,c,n]
+ * qf, o: [B, Nq, heads, Cm];  mem: [B, Cm, N] channel-major;  Nq*heads <= 32, Cm % 32 == 0.
+ * ws: workspace of idiff_smm_xattn_ws_floats(B,Nq,heads,Cm,N) floats. */
+int64_t idiff_smm_xattn_ws_floats(int B, int Nq, int heads, int Cm, int N);
+int idiff_smm_xattn_fwd(const float* qf, const float* mem, float* o, float* ws, int B, int Nq, int heads, int Cm,
+                        int N, float scale, idiff_stream_t stream);
+/* score map: out[b,k,p] = <feat[b,:,p]/max(|feat[b,:,p]|,eps), tv[b,k,:]/max(|tv[b,k,:]|,eps)>; K <= 8
+ * sel (optional) [B, HW] = out[b, idx[b], :]  (idx int32 [B]) */
+int idiff_scoremap_fwd(const float* feat, int64_t feat_bstride, const float* tv, float* out, const int32_t* idx,
+                       float* sel, int B, int C, int HW, int K, idiff_stream_t stream);
+/* out[b,0,p] = x[b, idx[b], p] */
+int idiff_gather_channel(const float* x, const int32_t* idx, float* out, int B, int C, int HW, idiff_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * SDE updates.  Replaces the 4-6 ATen elementwise launches + randn_like per step of
+ * utils/sde_utils.py:45-46,178-188,196-199 (IRSDE) and the driftSDE reverse update.
+ * Noise: z != NULL -> injected draws (parity mode); z == NULL -> on-device Philox4x32-10 + Box-Muller
+ * keyed by (seed, offset) (throughput mode).
+ * ---------------------------------------------------------------------------------------------- */
+#define IDIFF_SDE_STEP 0  /* reverse_sde_step       (sde_utils.py:45-46)  */
+#define IDIFF_SDE_MEAN 1  /* reverse_sde_step_mean  (:41-42)              */
+#define IDIFF_SDE_ODE 2   /* reverse_ode_step       (:48-49,181-182)      */
+/* x_out = x - (theta*(mu-x) - coef*sigma^2*score)*dt [- sigma*(z*sqrt_dt)],  score = -noise_pred/sigma_bar;
+ * same fp32 operation order as the reference (bit-exact given identical z). */
+int idiff_irsde_reverse_step(const float* x, const float* mu, const float* noise_pred, const float* z, float* x_out,
+                             int64_t n, float theta, float sigma, float sigma_bar, float dt, float sqrt_dt, int mode,
+                             uint64_t seed, uint64_t offset, idiff_stream_t stream);
+/* x_out = ((x - a*r_hat) - b*e_hat) + c*z ;  xa_out (optional) = x_out - cond  (next step's network input) */
+int idiff_drift_reverse_step(const float* x, const float* r_hat, const float* e_hat, const float* z, const float* cond,
+                             float* x_out, float* xa_out, int64_t n, float a, float b, float c, uint64_t seed,
+                             uint64_t offset, idiff_stream_t stream);
+/* standard normals (Philox4x32-10, Box-Muller), element i uses counter (offset + i/4) lane i%4 */
+int idiff_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, idiff_stream_t stream);
+/* raw Philox4x32-10 words for tests: out[4*i..4*i+3] = philox(counter = offset+i, key = seed) */
+int idiff_philox_raw(uint32_t* out, int64_t ncounters, uint64_t seed, uint64_t offset, idiff_stream_t stream);
+/* out = alpha*x + beta*y */
+int idiff_axpby(const float* x, const float* y, float* out, int64_t n, float alpha, float beta, idiff_stream_t stream);
+/* forward marginals with per-sample coefficients (training-state samplers):
+ *   out[b,:] = c0[b]*x0[b,:] + c1[b]*cond[b,:] + c2[b]*eps[b,:]      (driftSDE.forward_diffusion, IRSDE.generate_random_states) */
+int idiff_mix3_per_sample(const float* x0, const float* cond, const float* eps, const float* c0, const float* c1,
+                          const float* c2, float* out, int B, int64_t per_sample, idiff_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IDIFF_H */

@@ -1,0 +1,107 @@
+"""ctypes binding of the C ABI in include/idiff.h (instancediff_amd/libidiff_hip.so).
+
+The library is the product: there is no CPU / ATen fallback.  If it is missing or a symbol declared in
+include/idiff.h is not exported, importing the compute path fails loudly.
+"""
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libidiff_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "idiff.h")
+
+c_f32p = C.c_void_p  # device pointers travel as integers
+c_stream = C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("src0", C.c_void_p), ("src1", C.c_void_p),
+        ("src0_bstride", C.c_int64), ("src1_bstride", C.c_int64),
+        ("C0", C.c_int32), ("C1", C.c_int32),
+        ("B", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32),
+        ("mode", C.c_int32), ("ks", C.c_int32), ("Cout", C.c_int32),
+        ("wpk", C.c_void_p), ("bias", C.c_void_p),
+        ("pro_a", C.c_void_p), ("pro_b", C.c_void_p),
+        ("out", C.c_void_p), ("out_bstride", C.c_int64),
+        ("res", C.c_void_p), ("res_bstride", C.c_int64),
+        ("vec", C.c_void_p),
+        ("aux", C.c_void_p), ("aux_bstride", C.c_int64), ("aux_a", C.c_void_p), ("aux_b", C.c_void_p),
+        ("stats", C.c_void_p),
+    ]
+
+
+P, I, I64, F, U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
+
+# name -> (restype, argtypes); must list every function declared in include/idiff.h
+SIGNATURES = {
+    "idiff_last_error": (C.c_char_p, []),
+    "idiff_version": (I, []),
+    "idiff_device_info": (I, [C.POINTER(I), C.POINTER(I), C.c_char_p, I]),
+    "idiff_conv2d_num_tiles": (I, [I, I]),
+    "idiff_conv2d_fwd": (I, [C.POINTER(ConvDesc), c_stream]),
+    "idiff_pack_conv_weight": (I, [P, P, I, I, I, c_stream]),
+    "idiff_pack_conv_weight_T": (I, [P, P, I, I, I, c_stream]),
+    "idiff_gn_finalize": (I, [P, I, I, I, I, I, P, P, P, I64, F, P, P, P, c_stream]),
+    "idiff_affine_silu_add": (I, [P, I64, P, P, P, I64, P, P, I64, I, I, I, c_stream]),
+    "idiff_linear_fwd": (I, [P, I64, P, I64, P, P, I64, P, P, I64, I, I, I, I, I, c_stream]),
+    "idiff_layernorm_rows_fwd": (I, [P, I64, P, P, P, I64, I, I, F, P, c_stream]),
+    "idiff_time_embed_fwd": (I, [P, P, I, I, P, c_stream]),
+    "idiff_chan_layernorm_fwd": (I, [P, I64, P, P, P, I64, I, I, I, F, P, c_stream]),
+    "idiff_attn_self_fwd": (I, [P, P, P, I, I, I, I, F, c_stream]),
+    "idiff_attn_ctx_fwd": (I, [P, P, P, P, I, I, I, I, I, F, c_stream]),
+    "idiff_attn_tokens_fwd": (I, [P, P, P, P, I, I, I, I, I, F, c_stream]),
+    "idiff_smm_xattn_ws_floats": (I64, [I, I, I, I, I]),
+    "idiff_smm_xattn_fwd": (I, [P, P, P, P, I, I, I, I, I, F, c_stream]),
+    "idiff_scoremap_fwd": (I, [P, I64, P, P, P, P, I, I, I, I, c_stream]),
+    "idiff_gather_channel": (I, [P, P, P, I, I, I, c_stream]),
+    "idiff_irsde_reverse_step": (I, [P, P, P, P, P, I64, F, F, F, F, F, I, U64, U64, c_stream]),
+    "idiff_drift_reverse_step": (I, [P, P, P, P, P, P, P, I64, F, F, F, U64, U64, c_stream]),
+    "idiff_randn": (I, [P, I64, U64, U64, c_stream]),
+    "idiff_philox_raw": (I, [P, I64, U64, U64, c_stream]),
+    "idiff_axpby": (I, [P, P, P, I64, F, F, c_stream]),
+    "idiff_mix3_per_sample": (I, [P, P, P, P, P, P, P, I, I64, c_stream]),
+}
+
+
+def header_symbols(path=HEADER_PATH):
+    """Every function name declared in include/idiff.h (used by the CPU test that the library exports them all)."""
+    with open(path) as f:
+        txt = f.read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(idiff_[a-z0-9_]+)\s*\(", txt)))
+
+
+class IdiffError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP kernel library (idempotent).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IdiffError(
+            f"{LIB_PATH} not found: the HIP kernel library has not been built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or `make -C instancediff_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise IdiffError(f"libidiff_hip.so does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().idiff_last_error()
+        raise IdiffError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,433 @@
+// Attention kernels (gfx950, fp32).  All compute softmax(q k^T * scale) v per head, i.e. the formula of
+// models/_modified_BiomedCLIP.py:464-478, on channel-major ([B, C, N]) feature maps so that the pixel/key
+// index is the unit-stride one and maps onto the MFMA N (lane) dimension without any transposes.
+//
+//  * attn_self   : flash-style self-attention over N = H*W tokens on v_mfma_f32_32x32x2_f32.
+//                  S^T = K Q^T (keys on the accumulator rows, queries on the lanes), online softmax over the
+//                  16 registers x 2 half-waves, and O^T += V^T P with P taken straight from the S accumulator
+//                  (accumulator-as-B-operand, k order permuted to the accumulator's row order).
+//  * attn_ctx    : every pixel attends to M <= 32 context tokens (image embedding); VALU, HBM-bound.
+//  * attn_tokens : tiny token-major attention for the ScoreMapModule decoder self-attention.
+//  * smm_xattn   : ScoreMapModule cross-attention (few text queries vs. N pixel keys) with the K/V
+//                  projections folded to the query side; 4 waves split the channel (K) dimension of S and the
+//                  channel (M) dimension of P.V, partial S tiles are exchanged through LDS; flash-decoding
+//                  style split over keys + combine kernel.
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+#define KAPPA(r) (((r) & 3) + 8 * ((r) >> 2))
+
+// ---------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ lse, int C,
+                                                        int N, int heads, float scale) {
+    constexpr int MB = DH / 32;
+    constexpr int KT = DH * 32;       // K tile floats  [DH][32]
+    constexpr int VT = DH * 33;       // V tile floats  [DH][33]
+    constexpr int BUF = KT + VT + 3;  // keep 16-B multiples irrelevant: scalar LDS access only
+    constexpr int NV4 = DH * 32 / 4 / 256;  // float4 per thread per tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y / heads, h = blockIdx.y % heads;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const float* qb = qkv + (long long)b * 3 * C * N + (long long)(h * DH) * N;
+    const float* kb = qb + (long long)C * N;
+    const float* vb = qb + (long long)2 * C * N;
+
+    float qreg[DH / 2];
+    const int qi = q0 + l31;
+#pragma unroll
+    for (int s = 0; s < DH / 2; ++s) qreg[s] = qi < N ? qb[(long long)(2 * s + half) * N + qi] : 0.f;
+
+    floatx16 O[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[m][r] = 0.f;
+    float mrun = -INFINITY, lrun = 0.f;
+
+    const int nkb = (N + 31) / 32;
+    floatx4 rk[NV4], rv[NV4];
+    auto load_tile = [&](int kbi) {
+        const int key0 = kbi * 32;
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+            const int f = tid + i * 256;
+            const int d = f >> 3, j4 = (f & 7) * 4;
+            floatx4 kz = {0.f, 0.f, 0.f, 0.f}, vz = {0.f, 0.f, 0.f, 0.f};
+            if (key0 + j4 + 3 < N) {
+                kz = *reinterpret_cast<const floatx4*>(kb + (long long)d * N + key0 + j4);
+                vz = *reinterpret_cast<const floatx4*>(vb + (long long)d * N + key0 + j4);
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (key0 + j4 + e < N) {
+                        kz[e] = kb[(long long)d * N + key0 + j4 + e];
+                        vz[e] = vb[(long long)d * N + key0 + j4 + e];
+                    }
+            }
+            rk[i] = kz;
+            rv[i] = vz;
+        }
+    };
+    auto write_tile = [&](int buf) {
+        float* kt = smem + buf * BUF;
+        float* vt = kt + KT;
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+            const int f = tid + i * 256;
+            const int d = f >> 3, j4 = (f & 7) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                kt[d * 32 + j4 + e] = rk[i][e];
+                vt[d * 33 + j4 + e] = rv[i][e];
+            }
+        }
+    };
+
+    load_tile(0);
+    write_tile(0);
+    __syncthreads();
+    for (int kbi = 0; kbi < nkb; ++kbi) {
+        const int buf = kbi & 1;
+        if (kbi + 1 < nkb) load_tile(kbi + 1);
+        const float* kt = smem + buf * BUF;
+        const float* vt = kt + KT;
+        floatx16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < DH / 2; ++s) S = __builtin_amdgcn_mfma_f32_32x32x2f32(kt[(2 * s + half) * 32 + l31], qreg[s], S, 0, 0, 0);
+        const int key0 = kbi * 32 + 4 * half;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float sv = (key0 + KAPPA(r) < N) ? S[r] * scale : -INFINITY;
+            S[r] = sv;
+            mx = fmaxf(mx, sv);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrun, mx);
+        const float alpha = __expf(mrun - mnew);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __expf(S[r] - mnew);
+            S[r] = p;
+            ps += p;
+        }
+        lrun = lrun * alpha + ps;
+        mrun = mnew;
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[m][r] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+                O[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(vt[(m * 32 + l31) * 33 + KAPPA(r) + 4 * half], S[r], O[m], 0, 0, 0);
+        if (kbi + 1 < nkb) write_tile(buf ^ 1);
+        __syncthreads();
+    }
+    const float l = lrun + __shfl_xor(lrun, 32, 64);
+    const float inv = 1.0f / l;
+    if (qi < N) {
+        float* ob = out + (long long)b * C * N + (long long)(h * DH) * N + qi;
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ob[(long long)(m * 32 + KAPPA(r) + 4 * half) * N] = O[m][r] * inv;
+        if (lse && half == 0) lse[((long long)b * heads + h) * N + qi] = mrun + logf(l);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void attn_ctx_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                       float* __restrict__ out, int C, int N, int M, float scale) {
+    extern __shared__ float kv[];  // k [M][DH], v [M][DH]
+    const int b = blockIdx.z, h = blockIdx.y;
+    for (int i = threadIdx.x; i < M * DH; i += blockDim.x) {
+        const int m = i / DH, d = i % DH;
+        kv[i] = k[((long long)b * M + m) * C + h * DH + d];
+        kv[M * DH + i] = v[((long long)b * M + m) * C + h * DH + d];
+    }
+    __syncthreads();
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    const float* qp = q + ((long long)b * C + h * DH) * N + p;
+    float qr[DH], o[DH];
+#pragma unroll
+    for (int d = 0; d < DH; ++d) {
+        qr[d] = qp[(long long)d * N];
+        o[d] = 0.f;
+    }
+    float mrun = -INFINITY, l = 0.f;
+    for (int m = 0; m < M; ++m) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) s += qr[d] * kv[m * DH + d];
+        s *= scale;
+        const float mnew = fmaxf(mrun, s);
+        const float alpha = __expf(mrun - mnew), pw = __expf(s - mnew);
+        l = l * alpha + pw;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) o[d] = o[d] * alpha + pw * kv[M * DH + m * DH + d];
+        mrun = mnew;
+    }
+    const float inv = 1.0f / l;
+    float* op = out + ((long long)b * C + h * DH) * N + p;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) op[(long long)d * N] = o[d] * inv;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// one wave per (b, head, query); lanes = keys
+__global__ __launch_bounds__(64) void attn_tokens_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                         float* __restrict__ out, int Nq, int M, int C, int heads, float scale) {
+    const int dh = C / heads;
+    const int n = blockIdx.x % Nq, h = (blockIdx.x / Nq) % heads, b = blockIdx.x / (Nq * heads);
+    const int lane = threadIdx.x;
+    const float* qp = q + ((long long)b * Nq + n) * C + h * dh;
+    float s = -INFINITY;
+    if (lane < M) {
+        const float* kp = k + ((long long)b * M + lane) * C + h * dh;
+        float acc = 0.f;
+        for (int d = 0; d < dh; ++d) acc += qp[d] * kp[d];
+        s = acc * scale;
+    }
+    const float mx = wave_max(s);
+    const float p = lane < M ? __expf(s - mx) : 0.f;
+    const float l = wave_sum(p);
+    const float pn = p / l;
+    float* op = out + ((long long)b * Nq + n) * C + h * dh;
+    for (int d = 0; d < dh; ++d) {
+        const float t = wave_sum(lane < M ? pn * v[((long long)b * M + lane) * C + h * dh + d] : 0.f);
+        if (lane == 0) op[d] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ScoreMapModule cross attention, Cm == 256, rows = Nq*heads <= 32
+constexpr int XCM = 256;
+constexpr int XCW = 64;           // channels per wave
+constexpr int XTILE = XCW * 33;   // per-wave mem slice [64 c][33]
+__global__ __launch_bounds__(256) void smm_xattn_kernel(const float* __restrict__ qf, const float* __restrict__ mem, float* __restrict__ ws,
+                                                        int rows, int N, int nsplit, int kps, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tile = smem + (threadIdx.x >> 6) * XTILE;  // private per wave
+    float* xch = smem + 4 * XTILE;                    // [4][16][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y, sp = blockIdx.x;
+    const int c0 = wave * XCW;
+    const float* memb = mem + (long long)b * XCM * N + (long long)c0 * N;
+
+    float qreg[XCW / 2];
+#pragma unroll
+    for (int t = 0; t < XCW / 2; ++t) qreg[t] = l31 < rows ? qf[((long long)b * rows + l31) * XCM + c0 + 2 * t + half] : 0.f;
+
+    floatx16 O[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[m][r] = 0.f;
+    float mrun = -INFINITY, lrun = 0.f;
+
+    const int nkb = (N + 31) / 32;
+    const int kb_begin = sp * kps;
+    const int kb_end = min(nkb, kb_begin + kps);
+
+    floatx4 rt[8];  // 64 c x 32 keys / 64 lanes = 32 floats per lane
+    auto load_tile = [&](int kbi) {
+        const int key0 = kbi * 32;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = lane + i * 64;  // float4 index in [64][8]
+            const int c = f >> 3, j4 = (f & 7) * 4;
+            floatx4 z = {0.f, 0.f, 0.f, 0.f};
+            if (key0 + j4 + 3 < N)
+                z = *reinterpret_cast<const floatx4*>(memb + (long long)c * N + key0 + j4);
+            else
+                for (int e = 0; e < 4; ++e)
+                    if (key0 + j4 + e < N) z[e] = memb[(long long)c * N + key0 + j4 + e];
+            rt[i] = z;
+        }
+    };
+    auto write_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = lane + i * 64;
+            const int c = f >> 3, j4 = (f & 7) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[c * 33 + j4 + e] = rt[i][e];
+        }
+    };
+
+    if (kb_begin < kb_end) {
+        load_tile(kb_begin);
+        write_tile();
+    }
+    for (int kbi = kb_begin; kbi < kb_end; ++kbi) {
+        if (kbi + 1 < kb_end) load_tile(kbi + 1);
+        floatx16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < XCW / 2; ++t) S = __builtin_amdgcn_mfma_f32_32x32x2f32(tile[(2 * t + half) * 33 + l31], qreg[t], S, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[(wave * 16 + r) * 64 + lane] = S[r];
+        __syncthreads();
+        const int key0 = kbi * 32 + 4 * half;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float sv = xch[(0 * 16 + r) * 64 + lane] + xch[(1 * 16 + r) * 64 + lane] + xch[(2 * 16 + r) * 64 + lane] + xch[(3 * 16 + r) * 64 + lane];
+            sv = (key0 + KAPPA(r) < N) ? sv * scale : -INFINITY;
+            S[r] = sv;
+            mx = fmaxf(mx, sv);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrun, mx);
+        const float alpha = __expf(mrun - mnew);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __expf(S[r] - mnew);
+            S[r] = p;
+            ps += p;
+        }
+        lrun = lrun * alpha + ps;
+        mrun = mnew;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[m][r] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                O[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(tile[(m * 32 + l31) * 33 + KAPPA(r) + 4 * half], S[r], O[m], 0, 0, 0);
+        if (kbi + 1 < kb_end) write_tile();
+        __syncthreads();  // xch reads of this block done before the next block's writes
+    }
+    // partial out: ws[b][sp][c][row], then m, l rows
+    float* wp = ws + ((long long)b * nsplit + sp) * (XCM + 2) * 32;
+    const float l = lrun + __shfl_xor(lrun, 32, 64);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wp[(c0 + m * 32 + KAPPA(r) + 4 * half) * 32 + l31] = O[m][r];
+    if (wave == 0 && half == 0) {
+        wp[XCM * 32 + l31] = mrun;
+        wp[(XCM + 1) * 32 + l31] = l;
+    }
+}
+
+__global__ __launch_bounds__(256) void smm_xattn_combine_kernel(const float* __restrict__ ws, float* __restrict__ o, int rows, int nsplit) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over rows*XCM
+    if (i >= rows * XCM) return;
+    const int row = i / XCM, c = i % XCM;
+    const float* wb = ws + (long long)b * nsplit * (XCM + 2) * 32;
+    float M = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, wb[(long long)s * (XCM + 2) * 32 + XCM * 32 + row]);
+    float L = 0.f, acc = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float* w = wb + (long long)s * (XCM + 2) * 32;
+        const float ms = w[XCM * 32 + row];
+        const float f = ms == -INFINITY ? 0.f : __expf(ms - M);
+        L += w[(XCM + 1) * 32 + row] * f;
+        acc += w[c * 32 + row] * f;
+    }
+    o[((long long)b * rows + row) * XCM + c] = acc / L;
+}
+
+inline void smm_split(int B, int N, int* nsplit, int* kps) {
+    const int nkb = (N + 31) / 32;
+    int target = 1024 / (B > 0 ? B : 1);
+    if (target < 1) target = 1;
+    int k = (nkb + target - 1) / target;
+    if (k < 2) k = 2;
+    if (k > nkb) k = nkb;
+    *kps = k;
+    *nsplit = (nkb + k - 1) / k;
+}
+
+}  // namespace
+
+extern "C" int idiff_attn_self_fwd(const float* qkv, float* out, float* lse, int B, int C, int N, int heads, float scale, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(qkv && out && B > 0 && C > 0 && N > 0 && heads > 0 && C % heads == 0, "attn_self: bad args");
+    const int dh = C / heads;
+    IDIFF_CHECK_ARG(dh == 64 || dh == 32, "attn_self: head dim must be 32 or 64 (got %d)", dh);
+    IDIFF_CHECK_ARG(N % 4 == 0, "attn_self: N must be a multiple of 4");
+    dim3 grid((N + 127) / 128, B * heads);
+    hipStream_t st = (hipStream_t)stream;
+    if (dh == 64) {
+        const size_t lds = 2 * (64 * 32 + 64 * 33 + 3) * sizeof(float);
+        hipLaunchKernelGGL(attn_self_kernel<64>, grid, dim3(256), lds, st, qkv, out, lse, C, N, heads, scale);
+    } else {
+        const size_t lds = 2 * (32 * 32 + 32 * 33 + 3) * sizeof(float);
+        hipLaunchKernelGGL(attn_self_kernel<32>, grid, dim3(256), lds, st, qkv, out, lse, C, N, heads, scale);
+    }
+    IDIFF_CHECK_LAUNCH("attn_self_fwd");
+    return IDIFF_OK;
+}
+
+extern "C" int idiff_attn_ctx_fwd(const float* q, const float* k, const float* v, float* out, int B, int C, int N, int M, int heads, float scale,
+                                  idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(q && k && v && out && B > 0 && C > 0 && N > 0 && heads > 0 && C % heads == 0, "attn_ctx: bad args");
+    IDIFF_CHECK_ARG(M >= 1 && M <= 32, "attn_ctx: M must be in 1..32 (got %d)", M);
+    const int dh = C / heads;
+    dim3 grid((N + 255) / 256, heads, B);
+    const size_t lds = (size_t)2 * M * dh * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (dh == 16)
+        hipLaunchKernelGGL(attn_ctx_kernel<16>, grid, dim3(256), lds, st, q, k, v, out, C, N, M, scale);
+    else if (dh == 32)
+        hipLaunchKernelGGL(attn_ctx_kernel<32>, grid, dim3(256), lds, st, q, k, v, out, C, N, M, scale);
+    else if (dh == 64)
+        hipLaunchKernelGGL(attn_ctx_kernel<64>, grid, dim3(256), lds, st, q, k, v, out, C, N, M, scale);
+    else
+        IDIFF_FAIL(IDIFF_E_UNSUPPORTED, "attn_ctx: head dim must be 16, 32 or 64 (got %d)", dh);
+    IDIFF_CHECK_LAUNCH("attn_ctx_fwd");
+    return IDIFF_OK;
+}
+
+extern "C" int idiff_attn_tokens_fwd(const float* q, const float* k, const float* v, float* out, int B, int Nq, int M, int C, int heads,
+                                     float scale, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(q && k && v && out && B > 0 && Nq > 0 && C > 0 && heads > 0 && C % heads == 0, "attn_tokens: bad args");
+    IDIFF_CHECK_ARG(M >= 1 && M <= 64, "attn_tokens: M must be in 1..64 (got %d)", M);
+    hipLaunchKernelGGL(attn_tokens_kernel, dim3(B * heads * Nq), dim3(64), 0, (hipStream_t)stream, q, k, v, out, Nq, M, C, heads, scale);
+    IDIFF_CHECK_LAUNCH("attn_tokens_fwd");
+    return IDIFF_OK;
+}
+
+extern "C" int64_t idiff_smm_xattn_ws_floats(int B, int Nq, int heads, int Cm, int N) {
+    (void)Nq;
+    (void)heads;
+    int ns, kps;
+    smm_split(B, N, &ns, &kps);
+    return (int64_t)B * ns * (Cm + 2) * 32;
+}
+
+extern "C" int idiff_smm_xattn_fwd(const float* qf, const float* mem, float* o, float* ws, int B, int Nq, int heads, int Cm, int N, float scale,
+                                   idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(qf && mem && o && ws && B > 0 && Nq > 0 && heads > 0 && N > 0, "smm_xattn: bad args");
+    IDIFF_CHECK_ARG(Cm == XCM, "smm_xattn: Cm must be %d (got %d)", XCM, Cm);
+    IDIFF_CHECK_ARG(Nq * heads <= 32, "smm_xattn: Nq*heads must be <= 32 (got %d)", Nq * heads);
+    IDIFF_CHECK_ARG(N % 4 == 0, "smm_xattn: N must be a multiple of 4");
+    int ns, kps;
+    smm_split(B, N, &ns, &kps);
+    const int rows = Nq * heads;
+    const size_t lds = (size_t)(4 * XTILE + 4 * 16 * 64) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(smm_xattn_kernel, dim3(ns, B), dim3(256), lds, st, qf, mem, ws, rows, N, ns, kps, scale);
+    IDIFF_CHECK_LAUNCH("smm_xattn_fwd");
+    hipLaunchKernelGGL(smm_xattn_combine_kernel, dim3((rows * XCM + 255) / 256, B), dim3(256), 0, st, ws, o, rows, ns);
+    IDIFF_CHECK_LAUNCH("smm_xattn_combine");
+    return IDIFF_OK;
+}

@@ -1,0 +1,473 @@
+// Implicit-GEMM 2-D convolution for gfx950 on the f32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+//   GEMM view:  M = Cout (64 per workgroup), N = output pixels (256 per workgroup, a TH x TW patch of one
+//   sample, TW in {32,16,8}), K = taps * Cin, walked in chunks of CK input channels.
+//   A (weights) and B (input patch with halo) are staged through LDS, double buffered, register-staged
+//   (issue global loads for chunk c+1, run the MFMAs of chunk c, then write LDS; one barrier per chunk).
+//   Each of the 4 waves owns all 64 output channels x 64 pixels = 2x2 accumulators of 32x32.
+//   NCHW keeps the N (pixel) index contiguous along W, so the B-operand LDS reads, the global gathers and
+//   the epilogue stores (32 consecutive pixels per half-wave) are all unit-stride.
+//
+//   Fused in the gather   : virtual channel concat of two sources, nearest x2 upsample, pixel-unshuffle(2),
+//                           GroupNorm/FiLM affine + SiLU of the producer (zero padding applied after it).
+//   Fused in the epilogue : bias, residual, per-(b,c) vector, "+ silu(a*aux+b)" term, and deterministic
+//                           per-(b,c,tile) sum / sum-of-squares partials for the next GroupNorm.
+//
+// f32 MFMA is an exact k-ordered fp32 fma chain (MI355X_MICROARCH.md), i.e. same numerics class as the
+// reference's fp32 cuDNN/ATen convs; roofline for this kernel = 157.3 TFLOP/s (f32 matrix peak).
+#include "common.h"
+
+namespace {
+
+struct ConvArgs {
+    const float* src0;
+    const float* src1;
+    long long bs0, bs1;
+    int C0v, C1v;  // virtual channel counts (x4 for unshuffle)
+    int C0r;       // real channel count of src0 (prologue tables are indexed by real channel)
+    int Cin;       // C0v + C1v
+    int B, Hin, Win, Hout, Wout;
+    int Cout;
+    const float* wpk;
+    const float* bias;
+    const float* pro_a;
+    const float* pro_b;
+    float* out;
+    long long obs;
+    const float* res;
+    long long rbs;
+    const float* vec;
+    const float* aux;
+    long long abs_;
+    const float* aux_a;
+    const float* aux_b;
+    float* stats;
+    int tiles_x, ntiles, ncob;
+    unsigned total_wg;
+};
+
+constexpr int BM = 64;
+
+template <int KS, int CK, int TWL, int MODE, bool VECW>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+    constexpr int TW = 1 << TWL;
+    constexpr int TH = 256 / TW;
+    constexpr int PAD = KS / 2;
+    constexpr int TRH = TH + KS - 1;
+    constexpr int RS = TW + KS - 1;
+    constexpr int PS = TRH * RS;
+    constexpr int IN_TILE = ((CK * PS + 3) / 4) * 4;
+    constexpr int TAPS = KS * KS;
+    constexpr int W_TILE = TAPS * CK * BM;
+    constexpr int BUF = IN_TILE + W_TILE;
+    constexpr int NL = (CK * PS + 255) / 256;
+    constexpr int NW = VECW ? (W_TILE / 4 + 255) / 256 : (W_TILE + 255) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+
+    const unsigned logical = xcd_remap(blockIdx.x, a.total_wg);
+    const int cob = logical % a.ncob;
+    const int tile = (logical / a.ncob) % a.ntiles;
+    const int b = logical / (a.ncob * a.ntiles);
+    const int co0 = cob * BM;
+    const int y0 = (tile / a.tiles_x) * TH;
+    const int x0 = (tile % a.tiles_x) * TW;
+
+    const int HWin = a.Hin * a.Win;
+
+    // ---- per-thread gather descriptors (constant across chunks) ---------------------------------
+    int goff[NL];
+    bool gval[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int e = tid + i * 256;
+        const int ci = e / PS;
+        const int rem = e - ci * PS;
+        const int r = rem / RS;
+        const int c = rem - r * RS;
+        const int oy = y0 - PAD + r;
+        const int ox = x0 - PAD + c;
+        bool v = (e < CK * PS) && oy >= 0 && oy < a.Hout && ox >= 0 && ox < a.Wout;
+        int off;
+        if (MODE == IDIFF_CONV_UPSAMPLE2) {
+            off = ci * HWin + (oy >> 1) * a.Win + (ox >> 1);
+        } else if (MODE == IDIFF_CONV_UNSHUFFLE2) {
+            off = (ci >> 2) * HWin + (2 * oy + ((ci >> 1) & 1)) * a.Win + 2 * ox + (ci & 1);
+        } else {
+            off = ci * HWin + oy * a.Win + ox;
+        }
+        goff[i] = v ? off : 0;
+        gval[i] = v;
+    }
+
+    float rin[NL];
+    floatx4 rwv[VECW ? NW : 1];
+    float rws[VECW ? 1 : NW];
+
+    const int nchunks = (a.Cin + CK - 1) / CK;
+
+    auto load_regs = [&](int cc) {
+        const int cb = cc * CK;
+        const float* base;
+        int cbl;      // channel base inside the selected source (virtual)
+        int climit;   // virtual channels available in that source
+        const float* pa = nullptr;
+        const float* pb = nullptr;
+        if (cb < a.C0v) {
+            cbl = cb;
+            climit = a.C0v;
+            base = a.src0 + (long long)b * a.bs0;
+            if (a.pro_a) {
+                pa = a.pro_a + (long long)b * a.C0r;
+                pb = a.pro_b + (long long)b * a.C0r;
+            }
+        } else {
+            cbl = cb - a.C0v;
+            climit = a.C1v;
+            base = a.src1 + (long long)b * a.bs1;
+        }
+        base += (long long)(MODE == IDIFF_CONV_UNSHUFFLE2 ? (cbl >> 2) : cbl) * HWin;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int e = tid + i * 256;
+            const int ci = e / PS;
+            const bool v = gval[i] && (cbl + ci < climit);
+            float x = 0.f;
+            if (v) {
+                x = base[goff[i]];
+                if (pa) {
+                    const int ch = MODE == IDIFF_CONV_UNSHUFFLE2 ? ((cbl + ci) >> 2) : (cbl + ci);
+                    x = silu_f(pa[ch] * x + pb[ch]);
+                }
+            }
+            rin[i] = x;
+        }
+        if (VECW) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const int f = tid + i * 256;
+                const int row = f >> 4;  // (tap, ci)
+                const int c4 = f & 15;
+                const int tap = row / CK;
+                const int ci = row - tap * CK;
+                floatx4 w = {0.f, 0.f, 0.f, 0.f};
+                if (f < W_TILE / 4 && cb + ci < a.Cin)
+                    w = *reinterpret_cast<const floatx4*>(a.wpk + ((long long)tap * a.Cin + cb + ci) * a.Cout + co0 + c4 * 4);
+                rwv[i] = w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const int f = tid + i * 256;
+                const int row = f >> 6;
+                const int col = f & 63;
+                const int tap = row / CK;
+                const int ci = row - tap * CK;
+                float w = 0.f;
+                if (f < W_TILE && cb + ci < a.Cin && co0 + col < a.Cout)
+                    w = a.wpk[((long long)tap * a.Cin + cb + ci) * a.Cout + co0 + col];
+                rws[i] = w;
+            }
+        }
+    };
+
+    auto write_lds = [&](int buf) {
+        float* ib = smem + buf * BUF;
+        float* wb = ib + IN_TILE;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int e = tid + i * 256;
+            if (e < CK * PS) ib[e] = rin[i];
+        }
+        if (VECW) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const int f = tid + i * 256;
+                if (f < W_TILE / 4) *reinterpret_cast<floatx4*>(wb + f * 4) = rwv[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const int f = tid + i * 256;
+                if (f < W_TILE) wb[f] = rws[i];
+            }
+        }
+    };
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    // B-operand pixel of this lane in each of the wave's two 32-pixel blocks
+    int pixoff[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int p = wave * 64 + nb * 32 + l31;
+        pixoff[nb] = (p >> TWL) * RS + (p & (TW - 1));
+    }
+
+    load_regs(0);
+    write_lds(0);
+    __syncthreads();
+
+    for (int cc = 0; cc < nchunks; ++cc) {
+        const int buf = cc & 1;
+        if (cc + 1 < nchunks) load_regs(cc + 1);
+
+        const float* ib = smem + buf * BUF;
+        const float* wl = ib + IN_TILE + half * BM + l31;
+        const float* il0 = ib + half * PS + pixoff[0];
+        const float* il1 = ib + half * PS + pixoff[1];
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int ky = tap / KS, kx = tap % KS;
+#pragma unroll
+            for (int cp = 0; cp < CK / 2; ++cp) {
+                const float a0 = wl[(tap * CK + 2 * cp) * BM];
+                const float a1 = wl[(tap * CK + 2 * cp) * BM + 32];
+                const float b0 = il0[2 * cp * PS + ky * RS + kx];
+                const float b1 = il1[2 * cp * PS + ky * RS + kx];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+        if (cc + 1 < nchunks) write_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue -------------------------------------------------------------------------------
+    const int HWo = a.Hout * a.Wout;
+    int opix[2];
+    bool pval[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int p = wave * 64 + nb * 32 + l31;
+        const int oy = y0 + (p >> TWL), ox = x0 + (p & (TW - 1));
+        pval[nb] = oy < a.Hout && ox < a.Wout;
+        opix[nb] = oy * a.Wout + ox;
+    }
+    float* outb = a.out + (long long)b * a.obs;
+    const float* resb = a.res ? a.res + (long long)b * a.rbs : nullptr;
+    const float* auxb = a.aux ? a.aux + (long long)b * a.abs_ : nullptr;
+    float* red = smem;  // [4 waves][64 co][2]
+
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int col = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int co = co0 + col;
+            const bool cval = co < a.Cout;
+            const float bv = (a.bias && cval) ? a.bias[co] : 0.f;
+            float s = 0.f, q = 0.f;
+            float add = 0.f, aa = 0.f, ab = 0.f;
+            if (cval) {
+                if (a.vec) add = a.vec[(long long)b * a.Cout + co];
+                if (auxb) {
+                    aa = a.aux_a[(long long)b * a.Cout + co];
+                    ab = a.aux_b[(long long)b * a.Cout + co];
+                }
+            }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                float v = acc[mb][nb][r] + bv;
+                if (pval[nb] && cval) {
+                    s += v;
+                    q += v * v;
+                    const long long o = (long long)co * HWo + opix[nb];
+                    v += add;
+                    if (resb) v += resb[o];
+                    if (auxb) v += silu_f(aa * auxb[o] + ab);
+                    outb[o] = v;
+                }
+            }
+            if (a.stats) {
+                s = half_sum(s);
+                q = half_sum(q);
+                if (l31 == 0) {
+                    red[(wave * 64 + col) * 2 + 0] = s;
+                    red[(wave * 64 + col) * 2 + 1] = q;
+                }
+            }
+        }
+    }
+    if (a.stats) {
+        __syncthreads();
+        if (tid < 128) {
+            const int col = tid >> 1, w = tid & 1;
+            const int co = co0 + col;
+            if (co < a.Cout) {
+                const float t = red[(0 * 64 + col) * 2 + w] + red[(1 * 64 + col) * 2 + w] + red[(2 * 64 + col) * 2 + w] +
+                                red[(3 * 64 + col) * 2 + w];
+                a.stats[(((long long)b * a.ntiles + tile) * a.Cout + co) * 2 + w] = t;
+            }
+        }
+    }
+}
+
+template <int KS, int CK, int TWL, int MODE, bool VECW>
+int launch_conv(const ConvArgs& a, hipStream_t st) {
+    constexpr int TW = 1 << TWL;
+    constexpr int TH = 256 / TW;
+    constexpr int TRH = TH + KS - 1;
+    constexpr int RS = TW + KS - 1;
+    constexpr int IN_TILE = ((CK * TRH * RS + 3) / 4) * 4;
+    constexpr int W_TILE = KS * KS * CK * BM;
+    constexpr size_t lds = (size_t)2 * (IN_TILE + W_TILE) * sizeof(float);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool attr_set = false;
+    auto kern = conv_igemm_kernel<KS, CK, TWL, MODE, VECW>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "conv2d: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.total_wg), dim3(256), lds, st, a);
+    IDIFF_CHECK_LAUNCH("conv2d_fwd");
+    return IDIFF_OK;
+}
+
+template <int KS, int CK, int MODE>
+int dispatch_tw(const ConvArgs& a, int twl, bool vecw, hipStream_t st) {
+    if (twl == 5) return vecw ? launch_conv<KS, CK, 5, MODE, true>(a, st) : launch_conv<KS, CK, 5, MODE, false>(a, st);
+    if (twl == 4) return vecw ? launch_conv<KS, CK, 4, MODE, true>(a, st) : launch_conv<KS, CK, 4, MODE, false>(a, st);
+    return vecw ? launch_conv<KS, CK, 3, MODE, true>(a, st) : launch_conv<KS, CK, 3, MODE, false>(a, st);
+}
+
+inline int pick_twl(int Wout) { return Wout >= 32 ? 5 : (Wout >= 16 ? 4 : 3); }
+
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int taps, int transpose) {
+    // transpose == 0: out[tap][ci][co] = w[co][ci][tap]
+    // transpose == 1: out[tap][co][ci] = w[co][ci][taps-1-tap]   (flipped kernel, in/out swapped)
+    const long long n = (long long)Cout * Cin * taps;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        if (!transpose) {
+            const int co = i % Cout;
+            const int ci = (i / Cout) % Cin;
+            const int tap = i / ((long long)Cout * Cin);
+            out[i] = w[((long long)co * Cin + ci) * taps + tap];
+        } else {
+            const int ci = i % Cin;
+            const int co = (i / Cin) % Cout;
+            const int tap = i / ((long long)Cout * Cin);
+            out[i] = w[((long long)co * Cin + ci) * taps + (taps - 1 - tap)];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int idiff_conv2d_num_tiles(int Hout, int Wout) {
+    const int twl = pick_twl(Wout);
+    const int TW = 1 << twl, TH = 256 / TW;
+    return ((Wout + TW - 1) / TW) * ((Hout + TH - 1) / TH);
+}
+
+extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(d && d->src0 && d->wpk && d->out, "conv2d: null pointer");
+    IDIFF_CHECK_ARG(d->B > 0 && d->C0 > 0 && d->Cout > 0 && d->Hin > 0 && d->Win > 0, "conv2d: bad dims");
+    IDIFF_CHECK_ARG(d->ks == 1 || d->ks == 3 || d->ks == 7, "conv2d: ks must be 1, 3 or 7 (got %d)", d->ks);
+    IDIFF_CHECK_ARG(d->mode >= 0 && d->mode <= 2, "conv2d: bad mode %d", d->mode);
+    IDIFF_CHECK_ARG((d->C1 > 0) == (d->src1 != nullptr), "conv2d: src1/C1 mismatch");
+    IDIFF_CHECK_ARG(!(d->pro_a && d->C1 > 0), "conv2d: prologue needs a single source");
+    IDIFF_CHECK_ARG((d->pro_a == nullptr) == (d->pro_b == nullptr), "conv2d: pro_a/pro_b must both be set");
+    IDIFF_CHECK_ARG(!d->aux || (d->aux_a && d->aux_b), "conv2d: aux needs aux_a/aux_b");
+    ConvArgs a;
+    a.src0 = d->src0;
+    a.src1 = d->src1;
+    a.bs0 = d->src0_bstride;
+    a.bs1 = d->src1_bstride;
+    a.B = d->B;
+    a.C0r = d->C0;
+    a.Hin = d->Hin;
+    a.Win = d->Win;
+    a.Cout = d->Cout;
+    a.wpk = d->wpk;
+    a.bias = d->bias;
+    a.pro_a = d->pro_a;
+    a.pro_b = d->pro_b;
+    a.out = d->out;
+    a.obs = d->out_bstride;
+    a.res = d->res;
+    a.rbs = d->res_bstride;
+    a.vec = d->vec;
+    a.aux = d->aux;
+    a.abs_ = d->aux_bstride;
+    a.aux_a = d->aux_a;
+    a.aux_b = d->aux_b;
+    a.stats = d->stats;
+    int ck;
+    if (d->mode == IDIFF_CONV_UNSHUFFLE2) {
+        IDIFF_CHECK_ARG(d->ks == 1 && d->C1 == 0, "conv2d: unshuffle mode needs ks=1 and a single source");
+        IDIFF_CHECK_ARG(d->Hin % 2 == 0 && d->Win % 2 == 0, "conv2d: unshuffle needs even H, W");
+        a.C0v = d->C0 * 4;
+        a.C1v = 0;
+        a.Hout = d->Hin / 2;
+        a.Wout = d->Win / 2;
+    } else if (d->mode == IDIFF_CONV_UPSAMPLE2) {
+        a.C0v = d->C0;
+        a.C1v = d->C1;
+        a.Hout = d->Hin * 2;
+        a.Wout = d->Win * 2;
+    } else {
+        a.C0v = d->C0;
+        a.C1v = d->C1;
+        a.Hout = d->Hin;
+        a.Wout = d->Win;
+    }
+    a.Cin = a.C0v + a.C1v;
+    ck = d->ks == 3 ? 8 : (d->ks == 1 ? 16 : 2);
+    IDIFF_CHECK_ARG(a.C1v == 0 || a.C0v % ck == 0, "conv2d: with two sources C0 (%d) must be a multiple of %d", a.C0v, ck);
+    IDIFF_CHECK_ARG(d->ks != 7 || a.Cin <= 2, "conv2d: ks=7 supports Cin <= 2");
+    IDIFF_CHECK_ARG(a.bs0 >= (long long)d->C0 * d->Hin * d->Win, "conv2d: src0_bstride too small");
+    IDIFF_CHECK_ARG(d->C1 == 0 || a.bs1 >= (long long)d->C1 * d->Hin * d->Win, "conv2d: src1_bstride too small");
+    IDIFF_CHECK_ARG(a.obs >= (long long)d->Cout * a.Hout * a.Wout, "conv2d: out_bstride too small");
+    const int twl = pick_twl(a.Wout);
+    const int TW = 1 << twl, TH = 256 / TW;
+    a.tiles_x = (a.Wout + TW - 1) / TW;
+    a.ntiles = a.tiles_x * ((a.Hout + TH - 1) / TH);
+    a.ncob = (a.Cout + BM - 1) / BM;
+    const long long total = (long long)a.B * a.ntiles * a.ncob;
+    IDIFF_CHECK_ARG(total < (1ll << 31), "conv2d: grid too large");
+    a.total_wg = (unsigned)total;
+    const bool vecw = (a.Cout % BM == 0) && ((reinterpret_cast<uintptr_t>(a.wpk) & 15) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->ks == 3) {
+        if (d->mode == IDIFF_CONV_NORMAL) return dispatch_tw<3, 8, IDIFF_CONV_NORMAL>(a, twl, vecw, st);
+        return dispatch_tw<3, 8, IDIFF_CONV_UPSAMPLE2>(a, twl, vecw, st);
+    }
+    if (d->ks == 1) {
+        IDIFF_CHECK_ARG(d->mode != IDIFF_CONV_UPSAMPLE2, "conv2d: upsample mode needs ks=3");
+        if (d->mode == IDIFF_CONV_NORMAL) return dispatch_tw<1, 16, IDIFF_CONV_NORMAL>(a, twl, vecw, st);
+        return dispatch_tw<1, 16, IDIFF_CONV_UNSHUFFLE2>(a, twl, vecw, st);
+    }
+    IDIFF_CHECK_ARG(d->mode == IDIFF_CONV_NORMAL, "conv2d: ks=7 needs normal mode");
+    return dispatch_tw<7, 2, IDIFF_CONV_NORMAL>(a, twl, vecw, st);
+}
+
+static int pack_common(const float* w, float* wpk, int Cout, int Cin, int ks, int tr, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(w && wpk && Cout > 0 && Cin > 0 && ks > 0, "pack_conv_weight: bad args");
+    const long long n = (long long)Cout * Cin * ks * ks;
+    const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wpk, Cout, Cin, ks * ks, tr);
+    IDIFF_CHECK_LAUNCH("pack_conv_weight");
+    return IDIFF_OK;
+}
+extern "C" int idiff_pack_conv_weight(const float* w, float* wpk, int Cout, int Cin, int ks, idiff_stream_t stream) {
+    return pack_common(w, wpk, Cout, Cin, ks, 0, stream);
+}
+extern "C" int idiff_pack_conv_weight_T(const float* w, float* wpk, int Cout, int Cin, int ks, idiff_stream_t stream) {
+    return pack_common(w, wpk, Cout, Cin, ks, 1, stream);
+}

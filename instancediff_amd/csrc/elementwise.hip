@@ -1,0 +1,362 @@
+// HBM-bound kernels of the UNet forward path: GroupNorm finalize, affine+SiLU+residual, channel
+// LayerNorm, token LayerNorm / Linear, time embedding, score map, channel gather.  gfx950, fp32.
+#include "common.h"
+
+thread_local char g_idiff_err[512] = "";
+
+extern "C" const char* idiff_last_error(void) { return g_idiff_err; }
+extern "C" int idiff_version(void) { return 1; }
+extern "C" int idiff_device_info(int* num_cu, int* wave_size, char* arch_name, int arch_name_len) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "hipGetDevice: %s", hipGetErrorString(e));
+    hipDeviceProp_t p;
+    e = hipGetDeviceProperties(&p, dev);
+    if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (num_cu) *num_cu = p.multiProcessorCount;
+    if (wave_size) *wave_size = p.warpSize;
+    if (arch_name && arch_name_len > 0) {
+        strncpy(arch_name, p.gcnArchName, arch_name_len - 1);
+        arch_name[arch_name_len - 1] = 0;
+    }
+    return IDIFF_OK;
+}
+
+namespace {
+
+inline int grid_for(long long n, int per_block, int cap = 256 * 16) {
+    long long g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return (int)(g > cap ? cap : g);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GroupNorm finalize: one wave per (b, group); fp64 reduction of the conv partials (deterministic order)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ stats, int ntiles, int C, int groups, int HW,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ film, long long film_ld, float eps,
+                                                         float* __restrict__ out_a, float* __restrict__ out_b,
+                                                         float* __restrict__ mean_rstd) {
+    const int b = blockIdx.x / groups, g = blockIdx.x % groups;
+    const int cpg = C / groups;
+    const int lane = threadIdx.x;
+    const float* sp = stats + (long long)b * ntiles * C * 2;
+    double s = 0.0, q = 0.0;
+    const int n = ntiles * cpg;
+    for (int i = lane; i < n; i += 64) {
+        const int t = i / cpg, c = g * cpg + (i - t * cpg);
+        s += (double)sp[((long long)t * C + c) * 2 + 0];
+        q += (double)sp[((long long)t * C + c) * 2 + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        q += __shfl_xor(q, o, 64);
+    }
+    const double cnt = (double)cpg * (double)HW;
+    const double mean = s / cnt;
+    double var = q / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    if (mean_rstd && lane == 0) {
+        mean_rstd[((long long)b * groups + g) * 2 + 0] = (float)mean;
+        mean_rstd[((long long)b * groups + g) * 2 + 1] = (float)rstd;
+    }
+    for (int i = lane; i < cpg; i += 64) {
+        const int c = g * cpg + i;
+        const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+        float a = (float)rstd * ga;
+        float bb = be - (float)mean * a;
+        if (film) {
+            const float sc = 1.f + film[(long long)b * film_ld + c];
+            const float sh = film[(long long)b * film_ld + C + c];
+            a *= sc;
+            bb = bb * sc + sh;
+        }
+        out_a[(long long)b * C + c] = a;
+        out_b[(long long)b * C + c] = bb;
+    }
+}
+
+// out = silu(a*h+b) + res + vec ; planes of HW elements, float4 when HW % 4 == 0
+template <bool VEC>
+__global__ __launch_bounds__(256) void affine_silu_add_kernel(const float* __restrict__ h, long long hbs, const float* __restrict__ a,
+                                                              const float* __restrict__ bcoef, const float* __restrict__ res,
+                                                              long long rbs, const float* __restrict__ vec, float* __restrict__ out,
+                                                              long long obs, int B, int C, int HW) {
+    constexpr int V = VEC ? 4 : 1;
+    const int pv = HW / V;  // vectors per plane
+    const long long total = (long long)B * C * pv;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long plane = i / pv;
+        const int p = (int)(i - plane * pv) * V;
+        const int b = (int)(plane / C), c = (int)(plane - (long long)b * C);
+        const float aa = a ? a[plane] : 1.f, bb = a ? bcoef[plane] : 0.f;
+        const float vv = vec ? vec[plane] : 0.f;
+        const long long ho = (long long)b * hbs + (long long)c * HW + p;
+        const long long oo = (long long)b * obs + (long long)c * HW + p;
+        const long long ro = (long long)b * rbs + (long long)c * HW + p;
+        if (VEC) {
+            floatx4 x = *reinterpret_cast<const floatx4*>(h + ho);
+            floatx4 r = {0.f, 0.f, 0.f, 0.f};
+            if (res) r = *reinterpret_cast<const floatx4*>(res + ro);
+            floatx4 y;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float t = a ? silu_f(aa * x[k] + bb) : x[k];
+                y[k] = t + r[k] + vv;
+            }
+            *reinterpret_cast<floatx4*>(out + oo) = y;
+        } else {
+            const float x = h[ho];
+            const float t = a ? silu_f(aa * x + bb) : x;
+            out[oo] = t + (res ? res[ro] : 0.f) + vv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Linear on few rows: one wave per (output feature n, chunk of 8 rows); lanes stride over K
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == IDIFF_ACT_SILU) return silu_f(v);
+    if (act == IDIFF_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    return v;
+}
+
+constexpr int LIN_ROWS = 8;
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ w, long long ldw,
+                                                     const float* __restrict__ bias, const float* __restrict__ res, long long ldr,
+                                                     const float* __restrict__ gscale, float* __restrict__ out, long long ldo, int R, int K,
+                                                     int N, int act_in, int act_out) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r0 = blockIdx.y * LIN_ROWS;
+    if (n >= N) return;
+    float acc[LIN_ROWS];
+#pragma unroll
+    for (int r = 0; r < LIN_ROWS; ++r) acc[r] = 0.f;
+    const float* wr = w + (long long)n * ldw;
+    for (int k = lane; k < K; k += 64) {
+        const float wv = wr[k];
+#pragma unroll
+        for (int r = 0; r < LIN_ROWS; ++r) {
+            if (r0 + r < R) acc[r] += act_apply(x[(long long)(r0 + r) * ldx + k], act_in) * wv;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < LIN_ROWS; ++r) acc[r] = wave_sum(acc[r]);
+    if (lane == 0) {
+        const float bv = bias ? bias[n] : 0.f;
+        const float gs = gscale ? gscale[n] : 1.f;
+#pragma unroll
+        for (int r = 0; r < LIN_ROWS; ++r) {
+            if (r0 + r < R) {
+                float v = gs * (acc[r] + bv);
+                if (res) v += res[(long long)(r0 + r) * ldr + n];
+                out[(long long)(r0 + r) * ldo + n] = act_apply(v, act_out);
+            }
+        }
+    }
+}
+
+// LayerNorm over rows of C elements: one wave per row (two-pass, like ATen's fp32 path)
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ out, long long ldo, int R,
+                                                             int C, float eps, float* __restrict__ mean_rstd) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float* xr = x + (long long)r * ldx;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float d = xr[c] - mean;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    if (mean_rstd && lane == 0) {
+        mean_rstd[2 * r] = mean;
+        mean_rstd[2 * r + 1] = rstd;
+    }
+    for (int c = lane; c < C; c += 64) {
+        const float g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
+        out[(long long)r * ldo + c] = (xr[c] - mean) * rstd * g + bb;
+    }
+}
+
+__global__ void time_embed_kernel(const float* __restrict__ t, const float* __restrict__ freqs, int B, int dim, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * dim) return;
+    const int b = i / dim, j = i % dim, half = dim / 2;
+    const int f = j < half ? j : j - half;
+    const float freq = freqs ? freqs[f] : expf((float)f * (-logf(10000.0f) / (float)(half - 1)));
+    const float arg = __fmul_rn(t[b], freq);
+    out[i] = j < half ? sinf(arg) : cosf(arg);
+}
+
+// LayerNorm across channels of an NCHW map: thread = pixel, coalesced along p; two-pass
+__global__ __launch_bounds__(256) void chan_layernorm_kernel(const float* __restrict__ x, long long xbs, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ out, long long obs, int C,
+                                                             int HW, float eps, float* __restrict__ mean_rstd) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const float* xb = x + (long long)b * xbs + p;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += xb[(long long)c * HW];
+    const float mean = s / (float)C;
+    float q = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float d = xb[(long long)c * HW] - mean;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(q / (float)C + eps);
+    if (mean_rstd) {
+        mean_rstd[((long long)b * HW + p) * 2] = mean;
+        mean_rstd[((long long)b * HW + p) * 2 + 1] = rstd;
+    }
+    float* ob = out + (long long)b * obs + p;
+    for (int c = 0; c < C; ++c) ob[(long long)c * HW] = (xb[(long long)c * HW] - mean) * rstd * gamma[c] + beta[c];
+}
+
+// score map: normalized feature (per pixel over C) . normalized text vectors
+constexpr int SM_KMAX = 8;
+__global__ __launch_bounds__(256) void scoremap_kernel(const float* __restrict__ feat, long long fbs, const float* __restrict__ tv,
+                                                       float* __restrict__ out, const int* __restrict__ idx, float* __restrict__ sel, int C,
+                                                       int HW, int K) {
+    extern __shared__ float tvn[];  // [K][C]
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = wave; k < K; k += 4) {
+        const float* tr = tv + ((long long)b * K + k) * C;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += tr[c] * tr[c];
+        const float nrm = fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+        for (int c = lane; c < C; c += 64) tvn[k * C + c] = tr[c] / nrm;
+    }
+    __syncthreads();
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const float* fb = feat + (long long)b * fbs + p;
+    float dot[SM_KMAX];
+#pragma unroll
+    for (int k = 0; k < SM_KMAX; ++k) dot[k] = 0.f;
+    float n2 = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float f = fb[(long long)c * HW];
+        n2 += f * f;
+#pragma unroll
+        for (int k = 0; k < SM_KMAX; ++k)
+            if (k < K) dot[k] += f * tvn[k * C + c];
+    }
+    const float nrm = fmaxf(sqrtf(n2), 1e-12f);
+    const int ksel = idx ? idx[b] : -1;
+#pragma unroll
+    for (int k = 0; k < SM_KMAX; ++k) {
+        if (k < K) {
+            const float v = dot[k] / nrm;
+            out[((long long)b * K + k) * HW + p] = v;
+            if (k == ksel) sel[(long long)b * HW + p] = v;
+        }
+    }
+}
+
+__global__ void gather_channel_kernel(const float* __restrict__ x, const int* __restrict__ idx, float* __restrict__ out, int B, int C, int HW) {
+    const long long total = (long long)B * HW;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW), p = (int)(i - (long long)b * HW);
+        out[i] = x[((long long)b * C + idx[b]) * HW + p];
+    }
+}
+
+}  // namespace
+
+extern "C" int idiff_gn_finalize(const float* stats, int ntiles, int B, int C, int groups, int HW, const float* gamma, const float* beta,
+                                 const float* film, int64_t film_ld, float eps, float* out_a, float* out_b, float* mean_rstd,
+                                 idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(stats && out_a && out_b, "gn_finalize: null pointer");
+    IDIFF_CHECK_ARG(B > 0 && C > 0 && groups > 0 && C % groups == 0 && ntiles > 0 && HW > 0, "gn_finalize: bad dims");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, (hipStream_t)stream, stats, ntiles, C, groups, HW, gamma, beta,
+                       film, (long long)film_ld, eps, out_a, out_b, mean_rstd);
+    IDIFF_CHECK_LAUNCH("gn_finalize");
+    return IDIFF_OK;
+}
+
+extern "C" int idiff_affine_silu_add(const float* h, int64_t h_bstride, const float* a, const float* b, const float* res,
+                                     int64_t res_bstride, const float* vec, float* out, int64_t out_bstride, int B, int C, int HW,
+                                     idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(h && out && B > 0 && C > 0 && HW > 0, "affine_silu_add: bad args");
+    IDIFF_CHECK_ARG((a == nullptr) == (b == nullptr), "affine_silu_add: a/b must both be set");
+    const bool vec4 = (HW % 4 == 0) && (h_bstride % 4 == 0) && (out_bstride % 4 == 0) && (!res || res_bstride % 4 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(res)) & 15) == 0;
+    const long long total = (long long)B * C * (vec4 ? HW / 4 : HW);
+    const int grid = grid_for(total, 256, 256 * 32);
+    if (vec4)
+        hipLaunchKernelGGL(affine_silu_add_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, h, (long long)h_bstride, a, b, res,
+                           (long long)res_bstride, vec, out, (long long)out_bstride, B, C, HW);
+    else
+        hipLaunchKernelGGL(affine_silu_add_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, h, (long long)h_bstride, a, b, res,
+                           (long long)res_bstride, vec, out, (long long)out_bstride, B, C, HW);
+    IDIFF_CHECK_LAUNCH("affine_silu_add");
+    return IDIFF_OK;
+}
+
+extern "C" int idiff_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* res, int64_t ldr,
+                                const float* gscale, float* out, int64_t ldo, int R, int K, int N, int act_in, int act_out,
+                                idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(x && w && out && R > 0 && K > 0 && N > 0, "linear_fwd: bad args");
+    IDIFF_CHECK_ARG(ldx >= K && ldw >= K && ldo >= N, "linear_fwd: bad leading dims");
+    dim3 grid((N + 3) / 4, (R + LIN_ROWS - 1) / LIN_ROWS);
+    hipLaunchKernelGGL(linear_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (long long)ldx, w, (long long)ldw, bias, res,
+                       (long long)ldr, gscale, out, (long long)ldo, R, K, N, act_in, act_out);
+    IDIFF_CHECK_LAUNCH("linear_fwd");
+    return IDIFF_OK;
+}
+
+extern "C" int idiff_layernorm_rows_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out, int64_t ldo, int R,
+                                        int C, float eps, float* mean_rstd, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(x && out && R > 0 && C > 0, "layernorm_rows: bad args");
+    hipLaunchKernelGGL(layernorm_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, (long long)ldx, gamma, beta, out,
+                       (long long)ldo, R, C, eps, mean_rstd);
+    IDIFF_CHECK_LAUNCH("layernorm_rows");
+    return IDIFF_OK;
+}
+
+extern "C" int idiff_time_embed_fwd(const float* t, const float* freqs, int B, int dim, float* out, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(t && out && B > 0 && dim >= 4 && dim % 2 == 0, "time_embed: bad args");
+    hipLaunchKernelGGL(time_embed_kernel, dim3((B * dim + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, freqs, B, dim, out);
+    IDIFF_CHECK_LAUNCH("time_embed");
+    return IDIFF_OK;
+}
+
+extern "C" int idiff_chan_layernorm_fwd(const float* x, int64_t x_bstride, const float* gamma, const float* beta, float* out,
+                                        int64_t out_bstride, int B, int C, int HW, float eps, float* mean_rstd, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(x && out && gamma && beta && B > 0 && C > 0 && HW > 0, "chan_layernorm: bad args");
+    hipLaunchKernelGGL(chan_layernorm_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, (long long)x_bstride, gamma,
+                       beta, out, (long long)out_bstride, C, HW, eps, mean_rstd);
+    IDIFF_CHECK_LAUNCH("chan_layernorm");
+    return IDIFF_OK;
+}
+
+extern "C" int idiff_scoremap_fwd(const float* feat, int64_t feat_bstride, const float* tv, float* out, const int32_t* idx, float* sel,
+                                  int B, int C, int HW, int K, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(feat && tv && out && B > 0 && C > 0 && HW > 0, "scoremap: bad args");
+    IDIFF_CHECK_ARG(K > 0 && K <= SM_KMAX, "scoremap: K must be in 1..%d", SM_KMAX);
+    IDIFF_CHECK_ARG((idx == nullptr) == (sel == nullptr), "scoremap: idx/sel must both be set");
+    hipLaunchKernelGGL(scoremap_kernel, dim3((HW + 255) / 256, B), dim3(256), (size_t)K * C * sizeof(float), (hipStream_t)stream, feat,
+                       (long long)feat_bstride, tv, out, idx, sel, C, HW, K);
+    IDIFF_CHECK_LAUNCH("scoremap");
+    return IDIFF_OK;
+}
+
+extern "C" int idiff_gather_channel(const float* x, const int32_t* idx, float* out, int B, int C, int HW, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(x && idx && out && B > 0 && C > 0 && HW > 0, "gather_channel: bad args");
+    hipLaunchKernelGGL(gather_channel_kernel, dim3(grid_for((long long)B * HW, 256)), dim3(256), 0, (hipStream_t)stream, x, idx, out, B, C,
+                       HW);
+    IDIFF_CHECK_LAUNCH("gather_channel");
+    return IDIFF_OK;
+}

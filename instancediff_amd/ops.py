@@ -1,0 +1,317 @@
+"""Thin torch-tensor wrappers over the C ABI (include/idiff.h).  torch supplies device memory and the
+stream; every arithmetic operation below runs in the hand-written HIP kernels.  No fallbacks."""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check
+
+CONV_NORMAL, CONV_UPSAMPLE2, CONV_UNSHUFFLE2 = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+SDE_STEP, SDE_MEAN, SDE_ODE = 0, 1, 2
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(t, name="tensor", dtype=torch.float32):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise _lib.IdiffError(f"{name} must live on the GPU (the hot path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise _lib.IdiffError(f"{name} must be {dtype}, got {t.dtype}")
+
+
+def _bs(t, name="tensor"):
+    """batch stride of an NCHW tensor whose samples are contiguous (channel slices of a bigger buffer allowed)."""
+    _chk(t, name)
+    exp = 1
+    for d in range(t.dim() - 1, 0, -1):
+        if t.shape[d] != 1 and t.stride(d) != exp:
+            raise _lib.IdiffError(f"{name}: samples must be contiguous (shape {tuple(t.shape)}, strides {t.stride()})")
+        exp *= t.shape[d]
+    return t.stride(0) if t.shape[0] > 1 else max(exp, t.stride(0))
+
+
+def _c(t, name="tensor", dtype=torch.float32):
+    _chk(t, name, dtype)
+    if t is not None and not t.is_contiguous():
+        raise _lib.IdiffError(f"{name} must be contiguous")
+    return t
+
+
+# ---------------------------------------------------------------------------------------------------
+def pack_conv_weight(w, transpose=False):
+    """[Cout,Cin,k,k] -> packed [k*k][Cin][Cout] (or the flipped/transposed pack for the data gradient)."""
+    lib = _lib.load()
+    _c(w, "weight")
+    co, ci, k, _ = w.shape
+    out = torch.empty((k * k, co, ci) if transpose else (k * k, ci, co), device=w.device, dtype=torch.float32)
+    fn = lib.idiff_pack_conv_weight_T if transpose else lib.idiff_pack_conv_weight
+    check(fn(_p(w), _p(out), co, ci, k, _stream()), "pack_conv_weight")
+    return out
+
+
+def conv_num_tiles(Hout, Wout):
+    return _lib.load().idiff_conv2d_num_tiles(Hout, Wout)
+
+
+def conv2d(src0, wpk, bias, ks, Cout, src1=None, mode=CONV_NORMAL, pro=None, out=None, res=None, vec=None, aux=None,
+           want_stats=False):
+    """Implicit-GEMM conv.  pro=(a,b): per-(b,c) affine+SiLU applied to src0 while it is gathered;
+    aux=(tensor,a,b): adds silu(a*tensor+b) in the epilogue.  Returns out or (out, stats)."""
+    lib = _lib.load()
+    B, C0, Hin, Win = src0.shape
+    d = ConvDesc()
+    d.src0, d.src0_bstride, d.C0 = src0.data_ptr(), _bs(src0, "src0"), C0
+    if src1 is not None:
+        assert src1.shape[0] == B and src1.shape[2:] == src0.shape[2:]
+        d.src1, d.src1_bstride, d.C1 = src1.data_ptr(), _bs(src1, "src1"), src1.shape[1]
+    d.B, d.Hin, d.Win, d.mode, d.ks, d.Cout = B, Hin, Win, mode, ks, Cout
+    _c(wpk, "wpk")
+    d.wpk = wpk.data_ptr()
+    if bias is not None:
+        d.bias = _c(bias, "bias").data_ptr()
+    if pro is not None:
+        d.pro_a, d.pro_b = _c(pro[0], "pro_a").data_ptr(), _c(pro[1], "pro_b").data_ptr()
+    if mode == CONV_UPSAMPLE2:
+        Hout, Wout = Hin * 2, Win * 2
+    elif mode == CONV_UNSHUFFLE2:
+        Hout, Wout = Hin // 2, Win // 2
+    else:
+        Hout, Wout = Hin, Win
+    if out is None:
+        out = torch.empty((B, Cout, Hout, Wout), device=src0.device, dtype=torch.float32)
+    else:
+        assert tuple(out.shape) == (B, Cout, Hout, Wout), (out.shape, (B, Cout, Hout, Wout))
+    d.out, d.out_bstride = out.data_ptr(), _bs(out, "out")
+    if res is not None:
+        assert res.shape == out.shape
+        d.res, d.res_bstride = res.data_ptr(), _bs(res, "res")
+    if vec is not None:
+        assert tuple(vec.shape) == (B, Cout)
+        d.vec = _c(vec, "vec").data_ptr()
+    if aux is not None:
+        t, a, b = aux
+        assert t.shape == out.shape
+        d.aux, d.aux_bstride = t.data_ptr(), _bs(t, "aux")
+        d.aux_a, d.aux_b = _c(a, "aux_a").data_ptr(), _c(b, "aux_b").data_ptr()
+    stats = None
+    if want_stats:
+        nt = lib.idiff_conv2d_num_tiles(Hout, Wout)
+        stats = torch.empty((B, nt, Cout, 2), device=src0.device, dtype=torch.float32)
+        d.stats = stats.data_ptr()
+    check(lib.idiff_conv2d_fwd(C.byref(d), _stream()), "conv2d_fwd")
+    return (out, stats) if want_stats else out
+
+
+def gn_finalize(stats, groups, HW, gamma, beta, film=None, eps=1e-5, want_mean_rstd=False):
+    lib = _lib.load()
+    B, nt, Cc, _ = stats.shape
+    a = torch.empty((B, Cc), device=stats.device, dtype=torch.float32)
+    b = torch.empty_like(a)
+    mr = torch.empty((B, groups, 2), device=stats.device, dtype=torch.float32) if want_mean_rstd else None
+    film_ld = 0
+    if film is not None:
+        _chk(film, "film")
+        assert film.shape[0] == B and film.shape[1] == 2 * Cc and film.stride(1) == 1
+        film_ld = film.stride(0)
+    check(lib.idiff_gn_finalize(_p(_c(stats)), nt, B, Cc, groups, HW, _p(_c(gamma)), _p(_c(beta)), _p(film), film_ld, eps,
+                                _p(a), _p(b), _p(mr), _stream()), "gn_finalize")
+    return (a, b, mr) if want_mean_rstd else (a, b)
+
+
+def affine_silu_add(h, ab=None, res=None, vec=None, out=None):
+    lib = _lib.load()
+    B, Cc = h.shape[:2]
+    HW = h.shape[2] * h.shape[3]
+    if out is None:
+        out = torch.empty(h.shape, device=h.device, dtype=torch.float32)
+    a, b = ab if ab is not None else (None, None)
+    check(lib.idiff_affine_silu_add(_p(h), _bs(h, "h"), _p(_c(a)), _p(_c(b)), _p(res), _bs(res, "res") if res is not None else 0,
+                                    _p(_c(vec)), _p(out), _bs(out, "out"), B, Cc, HW, _stream()), "affine_silu_add")
+    return out
+
+
+def linear(x, w, bias=None, res=None, gscale=None, act_in=ACT_NONE, act_out=ACT_NONE, out=None):
+    """x [R,K] (row-strided ok), w [N,K] (row-strided ok) -> [R,N]."""
+    lib = _lib.load()
+    _chk(x, "x"), _chk(w, "w")
+    assert x.dim() == 2 and w.dim() == 2 and x.stride(1) == 1 and w.stride(1) == 1 and x.shape[1] == w.shape[1]
+    R, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((R, N), device=x.device, dtype=torch.float32)
+    assert out.stride(1) == 1 and tuple(out.shape) == (R, N)
+    if res is not None:
+        assert res.stride(1) == 1 and tuple(res.shape) == (R, N)
+    check(lib.idiff_linear_fwd(_p(x), x.stride(0), _p(w), w.stride(0), _p(_c(bias)), _p(res), res.stride(0) if res is not None else 0,
+                               _p(_c(gscale)), _p(out), out.stride(0), R, K, N, act_in, act_out, _stream()), "linear_fwd")
+    return out
+
+
+def layernorm_rows(x, gamma, beta, eps=1e-5, want_mean_rstd=False):
+    lib = _lib.load()
+    _chk(x, "x")
+    assert x.dim() == 2 and x.stride(1) == 1
+    R, Cc = x.shape
+    out = torch.empty((R, Cc), device=x.device, dtype=torch.float32)
+    mr = torch.empty((R, 2), device=x.device, dtype=torch.float32) if want_mean_rstd else None
+    check(lib.idiff_layernorm_rows_fwd(_p(x), x.stride(0), _p(_c(gamma)), _p(_c(beta)), _p(out), Cc, R, Cc, eps, _p(mr), _stream()),
+          "layernorm_rows")
+    return (out, mr) if want_mean_rstd else out
+
+
+def time_embed(t, dim, freqs=None):
+    lib = _lib.load()
+    _c(t, "t"), _c(freqs, "freqs")
+    B = t.numel()
+    out = torch.empty((B, dim), device=t.device, dtype=torch.float32)
+    check(lib.idiff_time_embed_fwd(_p(t), _p(freqs), B, dim, _p(out), _stream()), "time_embed")
+    return out
+
+
+def chan_layernorm(x, gamma, beta, eps=1e-5, want_mean_rstd=False):
+    lib = _lib.load()
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, Cc, H, W), device=x.device, dtype=torch.float32)
+    mr = torch.empty((B, H * W, 2), device=x.device, dtype=torch.float32) if want_mean_rstd else None
+    check(lib.idiff_chan_layernorm_fwd(_p(x), _bs(x, "x"), _p(_c(gamma)), _p(_c(beta)), _p(out), Cc * H * W, B, Cc, H * W, eps, _p(mr),
+                                       _stream()), "chan_layernorm")
+    return (out, mr) if want_mean_rstd else out
+
+
+def attn_self(qkv, heads, scale, want_lse=False):
+    """qkv [B,3C,H,W] -> [B,C,H,W]"""
+    lib = _lib.load()
+    _c(qkv, "qkv")
+    B, C3, H, W = qkv.shape
+    Cc, N = C3 // 3, H * W
+    out = torch.empty((B, Cc, H, W), device=qkv.device, dtype=torch.float32)
+    lse = torch.empty((B, heads, N), device=qkv.device, dtype=torch.float32) if want_lse else None
+    check(lib.idiff_attn_self_fwd(_p(qkv), _p(out), _p(lse), B, Cc, N, heads, scale, _stream()), "attn_self_fwd")
+    return (out, lse) if want_lse else out
+
+
+def attn_ctx(q, k, v, heads, scale):
+    """q [B,C,H,W]; k,v [B,M,C] -> [B,C,H,W]"""
+    lib = _lib.load()
+    _c(q, "q"), _c(k, "k"), _c(v, "v")
+    B, Cc, H, W = q.shape
+    M = k.shape[1]
+    out = torch.empty_like(q)
+    check(lib.idiff_attn_ctx_fwd(_p(q), _p(k), _p(v), _p(out), B, Cc, H * W, M, heads, scale, _stream()), "attn_ctx_fwd")
+    return out
+
+
+def attn_tokens(q, k, v, heads, scale):
+    """q [B,Nq,C]; k,v [B,M,C] -> [B,Nq,C]"""
+    lib = _lib.load()
+    _c(q, "q"), _c(k, "k"), _c(v, "v")
+    B, Nq, Cc = q.shape
+    M = k.shape[1]
+    out = torch.empty_like(q)
+    check(lib.idiff_attn_tokens_fwd(_p(q), _p(k), _p(v), _p(out), B, Nq, M, Cc, heads, scale, _stream()), "attn_tokens_fwd")
+    return out
+
+
+def smm_xattn(qf, mem, scale):
+    """qf [B,Nq,heads,Cm]; mem [B,Cm,N] -> o [B,Nq,heads,Cm] (attention-weighted mem rows)."""
+    lib = _lib.load()
+    _c(qf, "qf"), _c(mem, "mem")
+    B, Nq, heads, Cm = qf.shape
+    N = mem.shape[2]
+    nws = lib.idiff_smm_xattn_ws_floats(B, Nq, heads, Cm, N)
+    ws = torch.empty((nws,), device=qf.device, dtype=torch.float32)
+    o = torch.empty_like(qf)
+    check(lib.idiff_smm_xattn_fwd(_p(qf), _p(mem), _p(o), _p(ws), B, Nq, heads, Cm, N, scale, _stream()), "smm_xattn_fwd")
+    return o
+
+
+def scoremap(feat, tv, idx=None):
+    """feat [B,C,H,W], tv [B,K,C] -> score [B,K,H,W] (+ sel [B,1,H,W] = score[b, idx[b]])."""
+    lib = _lib.load()
+    B, Cc, H, W = feat.shape
+    K = tv.shape[1]
+    _c(tv, "tv")
+    out = torch.empty((B, K, H, W), device=feat.device, dtype=torch.float32)
+    sel = None
+    if idx is not None:
+        _c(idx, "idx", torch.int32)
+        sel = torch.empty((B, 1, H, W), device=feat.device, dtype=torch.float32)
+    check(lib.idiff_scoremap_fwd(_p(feat), _bs(feat, "feat"), _p(tv), _p(out), _p(idx), _p(sel), B, Cc, H * W, K, _stream()), "scoremap")
+    return out, sel
+
+
+def gather_channel(x, idx):
+    lib = _lib.load()
+    _c(x, "x"), _c(idx, "idx", torch.int32)
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, 1, H, W), device=x.device, dtype=torch.float32)
+    check(lib.idiff_gather_channel(_p(x), _p(idx), _p(out), B, Cc, H * W, _stream()), "gather_channel")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+def irsde_reverse_step(x, mu, noise_pred, z, theta, sigma, sigma_bar, dt, sqrt_dt, mode=SDE_STEP, seed=0, offset=0, out=None):
+    lib = _lib.load()
+    _c(x, "x"), _c(mu, "mu"), _c(noise_pred, "noise_pred"), _c(z, "z")
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.idiff_irsde_reverse_step(_p(x), _p(mu), _p(noise_pred), _p(z), _p(out), x.numel(), theta, sigma, sigma_bar, dt, sqrt_dt, mode,
+                                       seed, offset, _stream()), "irsde_reverse_step")
+    return out
+
+
+def drift_reverse_step(x, r_hat, e_hat, z, a, b, c, cond=None, seed=0, offset=0, out=None, xa_out=None):
+    lib = _lib.load()
+    _c(x, "x"), _c(r_hat, "r_hat"), _c(e_hat, "e_hat"), _c(z, "z"), _c(cond, "cond")
+    if out is None:
+        out = torch.empty_like(x)
+    if cond is not None and xa_out is None:
+        xa_out = torch.empty_like(x)
+    check(lib.idiff_drift_reverse_step(_p(x), _p(r_hat), _p(e_hat), _p(z), _p(cond), _p(out), _p(xa_out), x.numel(), a, b, c, seed, offset,
+                                       _stream()), "drift_reverse_step")
+    return (out, xa_out) if cond is not None else out
+
+
+def randn(shape, device, seed, offset=0):
+    lib = _lib.load()
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    check(lib.idiff_randn(_p(out), out.numel(), seed, offset, _stream()), "randn")
+    return out
+
+
+def philox_raw(ncounters, device, seed, offset=0):
+    lib = _lib.load()
+    out = torch.empty((ncounters, 4), device=device, dtype=torch.int32)
+    check(lib.idiff_philox_raw(_p(out), ncounters, seed, offset, _stream()), "philox_raw")
+    return out
+
+
+def axpby(x, y, alpha, beta, out=None):
+    lib = _lib.load()
+    _c(x, "x"), _c(y, "y")
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.idiff_axpby(_p(x), _p(y), _p(out), x.numel(), alpha, beta, _stream()), "axpby")
+    return out
+
+
+def mix3_per_sample(x0, cond, eps, c0, c1, c2):
+    lib = _lib.load()
+    for t in (x0, cond, eps, c0, c1, c2):
+        _c(t)
+    B = x0.shape[0]
+    out = torch.empty_like(x0)
+    check(lib.idiff_mix3_per_sample(_p(x0), _p(cond), _p(eps), _p(c0), _p(c1), _p(c2), _p(out), B, x0.numel() // B, _stream()),
+          "mix3_per_sample")
+    return out

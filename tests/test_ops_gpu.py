@@ -1,0 +1,297 @@
+"""Op-level parity: every C-ABI kernel vs a plain PyTorch CPU (fp64 where cheap) reference of the same op.
+Runs on the GPU box only (-m gpu)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from instancediff_amd import ops  # noqa: E402
+from oracle import philox_ref, sde_ref  # noqa: E402
+
+DEV = "cuda"
+
+
+def _close(got, ref, tol, what=""):
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    scale = max(float(ref.abs().max()), 1e-6)
+    err = float((got - ref).abs().max())
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (tol {tol})"
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def silu64(x):
+    return x / (1 + torch.exp(-x))
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,Cin,Cout,H,W,ks", [
+    (2, 64, 64, 32, 32, 3),     # TW=32, vector weight path
+    (1, 16, 128, 16, 16, 3),    # TW=16
+    (2, 24, 64, 8, 8, 3),       # TW=8, tile bigger than the image
+    (1, 8, 5, 40, 36, 3),       # ragged H/W, Cout < 64 (scalar weight path)
+    (2, 64, 192, 32, 32, 1),    # 1x1
+    (1, 40, 64, 16, 48, 1),     # 1x1, Cin not a multiple of the chunk
+    (2, 2, 64, 32, 32, 7),      # 7x7 input layer
+    (1, 1, 64, 24, 40, 7),
+    (1, 128, 128, 64, 64, 3),
+])
+def test_conv_plain(B, Cin, Cout, H, W, ks):
+    g = _g(1)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(Cin * ks * ks)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=ks // 2)
+    wpk = ops.pack_conv_weight(w.to(DEV))
+    out = ops.conv2d(x.to(DEV), wpk, b.to(DEV), ks, Cout)
+    _close(out, ref, 2e-6, "conv")
+
+
+def test_conv_concat_prologue_epilogue_stats():
+    g = _g(2)
+    B, C0, C1, Cout, H, W = 2, 32, 48, 64, 32, 32
+    x0 = torch.randn(B, C0, H, W, generator=g)
+    x1 = torch.randn(B, C1, H, W, generator=g)
+    w = torch.randn(Cout, C0 + C1, 3, 3, generator=g) / math.sqrt((C0 + C1) * 9)
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(B, Cout, H, W, generator=g)
+    vec = torch.randn(B, Cout, generator=g)
+    aux = torch.randn(B, Cout, H, W, generator=g)
+    aa, ab = torch.randn(B, Cout, generator=g), torch.randn(B, Cout, generator=g)
+    raw = F.conv2d(torch.cat([x0, x1], 1).double(), w.double(), b.double(), padding=1)
+    ref = raw + res.double() + vec.double()[:, :, None, None] + silu64(aa.double()[:, :, None, None] * aux.double() + ab.double()[:, :, None, None])
+    # src1 as a channel slice of a bigger buffer (batch stride > C1*H*W)
+    big = torch.zeros(B, C1 + 16, H, W)
+    big[:, :C1] = x1
+    bigd = big.to(DEV)
+    wpk = ops.pack_conv_weight(w.to(DEV))
+    out, stats = ops.conv2d(x0.to(DEV), wpk, b.to(DEV), 3, Cout, src1=bigd[:, :C1], res=res.to(DEV), vec=vec.to(DEV),
+                            aux=(aux.to(DEV), aa.to(DEV), ab.to(DEV)), want_stats=True)
+    _close(out, ref, 2e-6, "conv concat+epilogue")
+    # stats are of the raw conv output (acc + bias)
+    s = stats.cpu().double().sum(dim=1)  # [B, Cout, 2]
+    _close(s[..., 0], raw.sum(dim=(2, 3)), 1e-5, "stats sum")
+    _close(s[..., 1], (raw ** 2).sum(dim=(2, 3)), 1e-5, "stats sumsq")
+    # prologue (single source): silu(a*x+b) applied before zero padding
+    pa, pb = torch.randn(B, C0, generator=g), torch.randn(B, C0, generator=g)
+    w2 = torch.randn(Cout, C0, 3, 3, generator=g) / math.sqrt(C0 * 9)
+    act = silu64(pa.double()[:, :, None, None] * x0.double() + pb.double()[:, :, None, None])
+    ref2 = F.conv2d(act, w2.double(), None, padding=1)
+    out2 = ops.conv2d(x0.to(DEV), ops.pack_conv_weight(w2.to(DEV)), None, 3, Cout, pro=(pa.to(DEV), pb.to(DEV)))
+    _close(out2, ref2, 2e-6, "conv prologue")
+
+
+@pytest.mark.parametrize("H,W", [(16, 16), (8, 8), (32, 64)])
+def test_conv_upsample_and_unshuffle(H, W):
+    g = _g(3)
+    B, Cin, Cout = 2, 32, 64
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), w.double(), b.double(), padding=1)
+    out = ops.conv2d(x.to(DEV), ops.pack_conv_weight(w.to(DEV)), b.to(DEV), 3, Cout, mode=ops.CONV_UPSAMPLE2)
+    _close(out, ref, 2e-6, "upsample conv")
+    w1 = torch.randn(Cout, Cin * 4, 1, 1, generator=g) / math.sqrt(Cin * 4)
+    ref = F.conv2d(F.pixel_unshuffle(x.double(), 2), w1.double(), b.double())
+    out = ops.conv2d(x.to(DEV), ops.pack_conv_weight(w1.to(DEV)), b.to(DEV), 1, Cout, mode=ops.CONV_UNSHUFFLE2)
+    _close(out, ref, 2e-6, "unshuffle conv")
+
+
+def test_conv_bad_args_raise():
+    x = torch.zeros(1, 8, 8, 8, device=DEV)
+    w = ops.pack_conv_weight(torch.zeros(8, 8, 3, 3, device=DEV))
+    with pytest.raises(RuntimeError):
+        ops.conv2d(x, w, None, 5, 8)
+    with pytest.raises(RuntimeError):
+        ops.conv2d(x.cpu(), w, None, 3, 8)
+
+
+def test_groupnorm_via_stats_matches_torch():
+    g = _g(4)
+    B, C, H, W, G = 2, 64, 32, 32, 8
+    x = torch.randn(B, 16, H, W, generator=g)
+    w = torch.randn(C, 16, 3, 3, generator=g) / 12
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    film = torch.randn(B, 2 * C, generator=g) * 0.3
+    res = torch.randn(B, C, H, W, generator=g)
+    vec = torch.randn(B, C, generator=g)
+    h = F.conv2d(x.double(), w.double(), None, padding=1)
+    gn = F.group_norm(h, G, gamma.double(), beta.double(), 1e-5)
+    sc, sh = film.double()[:, :C, None, None], film.double()[:, C:, None, None]
+    ref = silu64(gn * (sc + 1) + sh) + res.double() + vec.double()[:, :, None, None]
+    hd, stats = ops.conv2d(x.to(DEV), ops.pack_conv_weight(w.to(DEV)), None, 3, C, want_stats=True)
+    a, b, mr = ops.gn_finalize(stats, G, H * W, gamma.to(DEV), beta.to(DEV), film=film.to(DEV), want_mean_rstd=True)
+    out = ops.affine_silu_add(hd, (a, b), res=res.to(DEV), vec=vec.to(DEV))
+    _close(out, ref, 5e-6, "gn+film+silu+res")
+    hg = h.reshape(B, G, -1)
+    _close(mr[..., 0], hg.mean(-1), 1e-5, "gn mean")
+    _close(mr[..., 1], 1 / torch.sqrt(hg.var(-1, unbiased=False) + 1e-5), 1e-5, "gn rstd")
+
+
+def test_linear_layernorm_time_embed():
+    g = _g(5)
+    R, K, N = 21, 300, 77
+    x = torch.randn(R, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    res = torch.randn(R, N, generator=g)
+    gs = torch.randn(N, generator=g)
+    ref = res.double() + gs.double() * (F.silu(x.double()) @ w.double().T + b.double())
+    ref = F.gelu(ref)
+    out = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), res=res.to(DEV), gscale=gs.to(DEV), act_in=ops.ACT_SILU, act_out=ops.ACT_GELU)
+    _close(out, ref, 3e-6, "linear")
+    # strided slices (per-head folding uses these)
+    xs = torch.randn(R, 4 * 64, generator=g)
+    ws = torch.randn(256, 128, generator=g)
+    outs = ops.linear(xs.to(DEV)[:, 64:128], ws.to(DEV)[:, 32:96])
+    _close(outs, xs.double()[:, 64:128] @ ws.double()[:, 32:96].T, 3e-6, "linear strided")
+    ga, be = torch.randn(K, generator=g), torch.randn(K, generator=g)
+    ln = ops.layernorm_rows(x.to(DEV), ga.to(DEV), be.to(DEV))
+    _close(ln, F.layer_norm(x.double(), (K,), ga.double(), be.double(), 1e-5), 3e-6, "layernorm")
+    t = torch.tensor([0.0, 1.0, 37.0, 100.0, 998.0])
+    half = 32
+    freq = torch.exp(torch.arange(half, dtype=torch.float32) * (-math.log(10000.0) / (half - 1)))
+    te = ops.time_embed(t.to(DEV), 64, freq.to(DEV))
+    a = (t[:, None] * freq[None]).double()  # fp32 product like the oracle, then exact sin/cos
+    _close(te, torch.cat([a.sin(), a.cos()], -1), 1e-6, "time_embed")
+    _close(ops.time_embed(t.to(DEV), 64), torch.cat([a.sin(), a.cos()], -1), 2e-4, "time_embed (device freqs)")
+
+
+def test_chan_layernorm_scoremap_gather():
+    g = _g(6)
+    B, C, H, W, K = 2, 64, 16, 24, 5
+    x = torch.randn(B, C, H, W, generator=g) * 2 + 0.5
+    ga, be = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = F.layer_norm(x.double().permute(0, 2, 3, 1), (C,), ga.double(), be.double(), 1e-5).permute(0, 3, 1, 2)
+    _close(ops.chan_layernorm(x.to(DEV), ga.to(DEV), be.to(DEV)), ref, 3e-6, "chan_layernorm")
+    tv = torch.randn(B, K, C, generator=g)
+    idx = torch.tensor([3, 1], dtype=torch.int32)
+    ref = torch.einsum('bchw,bkc->bkhw', F.normalize(x.double(), dim=1), F.normalize(tv.double(), dim=2))
+    sm, sel = ops.scoremap(x.to(DEV), tv.to(DEV), idx.to(DEV))
+    _close(sm, ref, 3e-6, "scoremap")
+    _close(sel, ref[torch.arange(B), idx.long()][:, None], 3e-6, "scoremap sel")
+    _close(ops.gather_channel(x.to(DEV), idx.to(DEV)), x[torch.arange(B), idx.long()][:, None], 0, "gather")
+
+
+def _attn_ref(q, k, v, heads, scale):
+    B, N, C = q.shape
+    M = k.shape[1]
+    q = q.reshape(B, N, heads, C // heads)
+    k = k.reshape(B, M, heads, C // heads)
+    v = v.reshape(B, M, heads, C // heads)
+    attn = (torch.einsum('bnkc,bmkc->bknm', q, k) * scale).softmax(-1)
+    return torch.einsum('bknm,bmkc->bnkc', attn, v).reshape(B, N, C)
+
+
+@pytest.mark.parametrize("C,heads,H,W", [(256, 4, 32, 32), (256, 4, 8, 8), (128, 4, 12, 12), (256, 4, 20, 28)])
+def test_attn_self(C, heads, H, W):
+    g = _g(7)
+    B, N = 2, H * W
+    qkv = torch.randn(B, 3 * C, H, W, generator=g)
+    qkv[0, :C] *= 3.0  # some peaky rows
+    scale = (C // heads) ** -0.5
+    q, k, v = qkv.double().reshape(B, 3, C, N).permute(1, 0, 3, 2)
+    ref = _attn_ref(q, k, v, heads, scale).permute(0, 2, 1).reshape(B, C, H, W)
+    out, lse = ops.attn_self(qkv.to(DEV), heads, scale, want_lse=True)
+    _close(out, ref, 5e-6, "attn_self")
+    s = torch.einsum('bnkc,bmkc->bknm', q.reshape(B, N, heads, -1), k.reshape(B, N, heads, -1)) * scale
+    _close(lse, torch.logsumexp(s, -1), 5e-6, "lse")
+
+
+@pytest.mark.parametrize("C,M", [(64, 1), (128, 3), (256, 7)])
+def test_attn_ctx_and_tokens(C, M):
+    g = _g(8)
+    B, H, W, heads = 2, 16, 20, 4
+    q = torch.randn(B, C, H, W, generator=g)
+    k, v = torch.randn(B, M, C, generator=g), torch.randn(B, M, C, generator=g)
+    scale = (C // heads) ** -0.5
+    ref = _attn_ref(q.double().reshape(B, C, -1).permute(0, 2, 1), k.double(), v.double(), heads, scale)
+    out = ops.attn_ctx(q.to(DEV), k.to(DEV), v.to(DEV), heads, scale)
+    _close(out, ref.permute(0, 2, 1).reshape(B, C, H, W), 5e-6, "attn_ctx")
+    qt = torch.randn(B, 5, C, generator=g)
+    out = ops.attn_tokens(qt.to(DEV), k.to(DEV), v.to(DEV), heads, scale)
+    _close(out, _attn_ref(qt.double(), k.double(), v.double(), heads, scale), 5e-6, "attn_tokens")
+
+
+@pytest.mark.parametrize("N,B", [(1024, 2), (64, 1), (4096, 3), (784, 2)])
+def test_smm_xattn(N, B):
+    g = _g(9)
+    Nq, heads, Cm = 5, 4, 256
+    qf = torch.randn(B, Nq, heads, Cm, generator=g) * 0.2
+    mem = torch.randn(B, Cm, N, generator=g)
+    scale = 0.125
+    s = torch.einsum('bqhc,bcn->bqhn', qf.double(), mem.double()) * scale
+    ref = torch.einsum('bqhn,bcn->bqhc', s.softmax(-1), mem.double())
+    out = ops.smm_xattn(qf.to(DEV), mem.to(DEV), scale)
+    _close(out, ref, 1e-5, "smm_xattn")
+
+
+# ---------------------------------------------------------------------------------------------------
+def test_irsde_step_bit_exact_vs_oracle(golden_sde):
+    gd = golden_sde
+    sde = sde_ref.IRSDERef(0.4, T=100, sample_T=50, schedule="cosine", eps=0.01)
+    mu = torch.from_numpy(gd["t64/mu"])
+    x = torch.from_numpy(gd["t64/xT"])
+    noises = torch.from_numpy(gd["t64/noises"])
+    sde.set_mu(mu)
+    g = _g(10)
+    for i, t in enumerate([50, 49, 2]):
+        npred = torch.randn(x.shape, generator=g)
+        score = sde.get_score_from_noise(npred, t)
+        kw = dict(theta=float(sde.thetas[t]), sigma=float(sde.sigmas[t]), sigma_bar=float(sde.sigma_bars[t]), dt=float(sde.dt),
+                  sqrt_dt=math.sqrt(float(sde.dt)))
+        for mode, ref in [(ops.SDE_STEP, sde.reverse_sde_step(x, score, t, noises[i])),
+                          (ops.SDE_MEAN, sde.reverse_sde_step_mean(x, score, t)), (ops.SDE_ODE, sde.reverse_ode_step(x, score, t))]:
+            out = ops.irsde_reverse_step(x.to(DEV), mu.to(DEV), npred.to(DEV), noises[i].to(DEV) if mode == ops.SDE_STEP else None,
+                                         mode=mode, **kw)
+            assert torch.equal(out.cpu(), ref), f"mode {mode} t {t}: max diff {(out.cpu() - ref).abs().max()}"
+    # golden trajectory from the REAL reference: 3 steps with the analytic model evaluated on the host
+    xs = torch.from_numpy(gd["t64/xT"]).to(DEV)
+    top = gd["t64/top_steps"]
+    for i, t in enumerate(gd["t64/top_ts"].tolist()):
+        xc = xs.cpu()
+        npred = 0.3 * xc - 0.2 * mu + 0.01 * float(t * sde.sample_scale) * torch.tanh(xc + mu)
+        xs = ops.irsde_reverse_step(xs, mu.to(DEV), npred.to(DEV), noises[i].to(DEV), theta=float(sde.thetas[t]), sigma=float(sde.sigmas[t]),
+                                    sigma_bar=float(sde.sigma_bars[t]), dt=float(sde.dt), sqrt_dt=math.sqrt(float(sde.dt)))
+        assert np.array_equal(xs.cpu().numpy(), top[i][3])
+
+
+def test_drift_step_and_mixes():
+    g = _g(11)
+    shp = (3, 1, 20, 24)
+    x, r, e, z, cond = [torch.randn(shp, generator=g) for _ in range(5)]
+    a, b, c = 0.013, 0.0071, 0.0042
+    ref = sde_ref.drift_reverse_update(x, r, e, z, torch.tensor(a), torch.tensor(b), torch.tensor(c))
+    out, xa = ops.drift_reverse_step(x.to(DEV), r.to(DEV), e.to(DEV), z.to(DEV), a, b, c, cond=cond.to(DEV))
+    assert torch.equal(out.cpu(), ref)
+    assert torch.equal(xa.cpu(), ref - cond)
+    _close(ops.axpby(x.to(DEV), r.to(DEV), 1.0, -1.0), x - r, 0, "axpby")
+    c0, c1, c2 = [torch.randn(3, generator=g) for _ in range(3)]
+    ref = c0[:, None, None, None] * x + c1[:, None, None, None] * r + c2[:, None, None, None] * e
+    _close(ops.mix3_per_sample(x.to(DEV), r.to(DEV), e.to(DEV), c0.to(DEV), c1.to(DEV), c2.to(DEV)), ref, 1e-6, "mix3")
+
+
+def test_philox_bit_exact_and_randn():
+    raw = ops.philox_raw(1000, DEV, seed=0x123456789ABCDEF, offset=(1 << 32) - 3).cpu().numpy().view(np.uint32)
+    ref = philox_ref.philox_raw(1000, 0x123456789ABCDEF, (1 << 32) - 3)
+    assert np.array_equal(raw, ref)
+    z = ops.randn((1 << 16) + 3, DEV, seed=99, offset=5).cpu().numpy()
+    zr = philox_ref.randn((1 << 16) + 3, 99, 5)
+    assert np.abs(z - zr).max() < 1e-4
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02
+    # on-device noise inside the step == injected idiff_randn noise
+    shp = (2, 1, 32, 32)
+    x = torch.randn(shp, device=DEV)
+    mu, npred = torch.randn_like(x), torch.randn_like(x)
+    kw = dict(theta=0.3, sigma=0.2, sigma_bar=0.25, dt=0.09, sqrt_dt=0.3)
+    zz = ops.randn(shp, DEV, seed=7, offset=100)
+    a = ops.irsde_reverse_step(x, mu, npred, zz, **kw)
+    b = ops.irsde_reverse_step(x, mu, npred, None, seed=7, offset=100, **kw)
+    assert torch.equal(a, b)
