@@ -4,6 +4,10 @@
 // contraction, IEEE division, so with injected noise the result is bit-identical to the CPU reference.
 #include "common.h"
 
+// hipcc defaults to -ffp-contract=fast-honor-pragmas: without this the separate mul/sub below fuse to FMAs
+// and the result differs from the reference's op-by-op fp32 arithmetic in the last bit.
+#pragma clang fp contract(off)
+
 namespace {
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
@@ -75,7 +79,9 @@ __global__ __launch_bounds__(256) void irsde_step_kernel(const float* __restrict
         floatx4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float score = __fdiv_rn(-nv4[k], sigma_bar);
+            // correctly rounded fp32 quotient: an fp64 divide rounded to fp32 is exact for p=24 (53 >= 2p+2),
+            // independent of how the compiler lowers fp32 division by a loop-invariant scalar.
+            const float score = (float)((double)(-nv4[k]) / (double)sigma_bar);
             const float t1 = __fsub_rn(mv[k], xv[k]);
             const float t2 = __fmul_rn(theta, t1);
             const float t3 = __fmul_rn(coef, score);

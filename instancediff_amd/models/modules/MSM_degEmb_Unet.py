@@ -1,0 +1,517 @@
+"""`LearnableForwardUNet_MultiScoreMap` and `ScoreMapModule` -- the score-SDE UNet of InstanceDiff on
+hand-written gfx950 HIP kernels.
+
+The reference imports these names from models/modules/MSM_degEmb_Unet.py (models/drift_noise_model.py:18,
+Configurations/config.yml:107-108) but the file is absent from the reference snapshot; the
+architecture implemented here is the build's frozen spec, constrained by the forward
+contract (drift_noise_model.py:250-268), config.yml:106-136, figures/LDD_Overall2.png and the attention /
+decoder blocks of models/_modified_BiomedCLIP.py:448-590,1194-1244.
+
+nn.Modules here are PARAMETER CONTAINERS (state_dict / optimizer / DDP compatibility, same keys as the
+oracle in oracle/unet_ref.py); every arithmetic operation of forward() runs in the kernels behind
+include/idiff.h via instancediff_amd.ops.  There is no ATen fallback: on a machine without the built
+library or without a GPU, forward() raises.
+"""
+import math
+import weakref
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+
+ARTIFACT_TYPES = ['speckle in OCT', 'speckle in ultra sound', 'noise in cryo-EM image', 'noise in low dose CT',
+                  'Gaussian noise in MRI']  # Configurations/config.yml:15
+
+
+def _trunc_normal_(t, std=0.02):
+    return nn.init.trunc_normal_(t, std=std, a=-2 * std, b=2 * std)
+
+
+# ---------------------------------------------------------------------------------------------------
+# prepared-weight cache: packed conv weights, concatenated / transposed linear weights.  Keyed on the
+# parameters' (data_ptr, _version) so optimizer steps and load_state_dict invalidate it.
+# ---------------------------------------------------------------------------------------------------
+class _Prepared:
+    """per-owner-module cache (weakly keyed, so it dies with the module and ids can never alias)."""
+
+    def __init__(self):
+        self.store = weakref.WeakKeyDictionary()
+
+    def get(self, key, params, build):
+        owner, name = key[1], key[0]
+        sig = tuple((p.data_ptr(), p._version) for p in params)
+        slot = self.store.setdefault(owner, {})
+        hit = slot.get(name)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        with torch.no_grad():
+            val = build()
+        slot[name] = (sig, val)
+        return val
+
+    def clear(self):
+        self.store = weakref.WeakKeyDictionary()
+
+
+_PREP = _Prepared()
+
+
+def packed(conv):
+    return _PREP.get(("pk", conv), (conv.weight,), lambda: ops.pack_conv_weight(conv.weight.detach().contiguous()))
+
+
+# ---------------------------------------------------------------------------------------------------
+# parameter containers (attribute names == oracle/unet_ref.py)
+# ---------------------------------------------------------------------------------------------------
+class Attention(nn.Module):  # parameters of _modified_BiomedCLIP.py:448-478 (qkv_bias=False)
+    def __init__(self, dim, num_heads=8):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.q_proj = nn.Linear(dim, dim, bias=False)
+        self.k_proj = nn.Linear(dim, dim, bias=False)
+        self.v_proj = nn.Linear(dim, dim, bias=False)
+        self.proj = nn.Linear(dim, dim)
+
+
+class TransformerDecoderLayer(nn.Module):  # :520-549
+    def __init__(self, d_model, nhead):
+        super().__init__()
+        self.self_attn = Attention(d_model, nhead)
+        self.cross_attn = Attention(d_model, nhead)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.mlp = nn.Sequential(nn.Linear(d_model, d_model * 4), nn.GELU(), nn.Identity(), nn.Linear(d_model * 4, d_model))
+
+
+class ContextDecoder(nn.Module):  # :1194-1244
+    def __init__(self, transformer_width=256, transformer_heads=4, transformer_layers=3, visual_dim=512, text_dim=512):
+        super().__init__()
+        self.width, self.heads = transformer_width, transformer_heads
+        self.memory_proj = nn.Sequential(nn.LayerNorm(visual_dim), nn.Linear(visual_dim, transformer_width),
+                                         nn.LayerNorm(transformer_width))
+        self.text_proj = nn.Sequential(nn.LayerNorm(text_dim), nn.Linear(text_dim, transformer_width))
+        self.decoder = nn.ModuleList([TransformerDecoderLayer(transformer_width, transformer_heads)
+                                      for _ in range(transformer_layers)])
+        self.out_proj = nn.Sequential(nn.LayerNorm(transformer_width), nn.Linear(transformer_width, visual_dim))
+        self.apply(self._init_weights)
+
+    @staticmethod
+    def _init_weights(m):  # :1227-1234
+        if isinstance(m, nn.Linear):
+            _trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+
+def _class_tokens(n_cls, prompt_len, names=ARTIFACT_TYPES):
+    """Deterministic stand-in token ids for the class prompts (no tokenizer/vocab offline): a stable hash of
+    the prompt words, EOT (= max id, as CLIP's argmax convention, _modified_BiomedCLIP.py:868) at the end."""
+    tok = torch.zeros(n_cls, prompt_len, dtype=torch.long)
+    for i in range(n_cls):
+        words = (names[i] if i < len(names) else f"class {i}").split()
+        tok[i, 0] = 49406
+        for j, w in enumerate(words[:prompt_len - 2]):
+            hsh = 0
+            for ch in w:
+                hsh = (hsh * 131 + ord(ch)) % 40000
+            tok[i, 1 + j] = 1000 + hsh
+        tok[i, min(len(words), prompt_len - 2) + 1] = 49407
+    return tok
+
+
+class ScoreMapModule(nn.Module):
+    """class prompts (+) learnable context -> frozen text encoder -> text emb; MHCA stack over the conv
+    feature (ContextDecoder) added back to the text emb; text (x) feature -> score map [B,K,h,w]."""
+
+    def __init__(self, visual_dim=64, CLIP_Type="CLIP", token_embed_dim=512, text_dim=512, n_ctx=8, n_cls=5, prompt_len=10,
+                 decoder_layers=3, decoder_width=256, decoder_heads=4):
+        super().__init__()
+        self.visual_dim, self.n_cls, self.text_dim = visual_dim, n_cls, text_dim
+        self.contexts = nn.Parameter(torch.zeros(1, n_ctx, token_embed_dim))
+        _trunc_normal_(self.contexts, std=0.02)
+        self.register_buffer("tokens", _class_tokens(n_cls, prompt_len))
+        self.text_to_visual = nn.Linear(text_dim, visual_dim)
+        self.context_decoder = ContextDecoder(decoder_width, decoder_heads, decoder_layers, visual_dim, text_dim)
+        self.gamma = nn.Parameter(torch.ones(visual_dim) * 1e-4)
+        self._text_cache = None
+
+    # ---- text branch (frozen encoder: out of the accelerated scope, cached at inference) ---------
+    def text_embeddings(self, text_encoder, B):
+        if not torch.is_grad_enabled() or not self.contexts.requires_grad:
+            key = (B, self.contexts.data_ptr(), self.contexts._version)
+            c = self._text_cache
+            if c is not None and c[0] == key and c[2]() is text_encoder:
+                return c[1]
+            with torch.no_grad():
+                text = text_encoder(self.tokens, self.contexts.expand(B, -1, -1)).float().contiguous()
+            self._text_cache = (key, text, weakref.ref(text_encoder))
+            return text
+        return text_encoder(self.tokens, self.contexts.expand(B, -1, -1)).float().contiguous()
+
+    def forward(self, feat, text_encoder, idx=None):
+        """feat [B,C,h,w] -> (score [B,K,h,w], sel [B,1,h,w] or None)."""
+        B, C, H, W = feat.shape
+        K = self.n_cls
+        dec = self.context_decoder
+        Wd, heads = dec.width, dec.heads
+        dh = Wd // heads
+        text = self.text_embeddings(text_encoder, B)  # [B,K,text_dim]
+        t2d = text.reshape(B * K, self.text_dim)
+        # memory = LN(Linear(LN(feature tokens)))  (channel-major: [B, Wd, h*w])
+        mp = dec.memory_proj
+        fn = ops.chan_layernorm(feat, mp[0].weight, mp[0].bias)
+        wmp = _PREP.get(("mp", mp[1]), (mp[1].weight,),
+                        lambda: ops.pack_conv_weight(mp[1].weight.detach().reshape(Wd, C, 1, 1).contiguous()))
+        m1 = ops.conv2d(fn, wmp, mp[1].bias, 1, Wd)
+        mem = ops.chan_layernorm(m1, mp[2].weight, mp[2].bias).reshape(B, Wd, H * W)
+        tp = dec.text_proj
+        x = ops.linear(ops.layernorm_rows(t2d, tp[0].weight, tp[0].bias), tp[1].weight, tp[1].bias)  # [B*K, Wd]
+        for li, layer in enumerate(dec.decoder):
+            sa, ca = layer.self_attn, layer.cross_attn
+            wqkv = _PREP.get(("qkv", sa), (sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight),
+                             lambda: torch.cat([sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight], 0).detach().contiguous())
+            n1 = ops.layernorm_rows(x, layer.norm1.weight, layer.norm1.bias)
+            qkv = ops.linear(n1, wqkv).reshape(B, K, 3, Wd)
+            a = ops.attn_tokens(qkv[:, :, 0].contiguous(), qkv[:, :, 1].contiguous(), qkv[:, :, 2].contiguous(), heads, sa.scale)
+            x = ops.linear(a.reshape(B * K, Wd), sa.proj.weight, sa.proj.bias, res=x)
+            # cross attention, k/v projections folded onto the (few) queries
+            n2 = ops.layernorm_rows(x, layer.norm2.weight, layer.norm2.bias)
+            qc = ops.linear(n2, ca.q_proj.weight)
+            wkT = _PREP.get(("wkT", ca), (ca.k_proj.weight,),
+                            lambda: [ca.k_proj.weight[h * dh:(h + 1) * dh].detach().t().contiguous() for h in range(heads)])
+            qf = torch.empty((B * K, heads * Wd), device=feat.device, dtype=torch.float32)
+            for h in range(heads):
+                ops.linear(qc[:, h * dh:(h + 1) * dh], wkT[h], out=qf[:, h * Wd:(h + 1) * Wd])
+            o = ops.smm_xattn(qf.reshape(B, K, heads, Wd), mem, ca.scale).reshape(B * K, heads * Wd)
+            av = torch.empty((B * K, Wd), device=feat.device, dtype=torch.float32)
+            for h in range(heads):
+                ops.linear(o[:, h * Wd:(h + 1) * Wd], ca.v_proj.weight[h * dh:(h + 1) * dh], out=av[:, h * dh:(h + 1) * dh])
+            x = ops.linear(av, ca.proj.weight, ca.proj.bias, res=x)
+            n3 = ops.layernorm_rows(x, layer.norm3.weight, layer.norm3.bias)
+            hm = ops.linear(n3, layer.mlp[0].weight, layer.mlp[0].bias, act_out=ops.ACT_GELU)
+            x = ops.linear(hm, layer.mlp[3].weight, layer.mlp[3].bias, res=x)
+        op = dec.out_proj
+        t2v = ops.linear(t2d, self.text_to_visual.weight, self.text_to_visual.bias)
+        tv = ops.linear(ops.layernorm_rows(x, op[0].weight, op[0].bias), op[1].weight, op[1].bias, res=t2v, gscale=self.gamma)
+        return ops.scoremap(feat, tv.reshape(B, K, C), idx)
+
+
+class ResBlock(nn.Module):
+    def __init__(self, dim_in, dim_out, time_dim, groups=8):
+        super().__init__()
+        self.dim_in, self.dim_out, self.groups = dim_in, dim_out, groups
+        self.mlp = nn.Linear(time_dim, dim_out * 2)
+        self.conv1 = nn.Conv2d(dim_in, dim_out, 3, padding=1)
+        self.norm1 = nn.GroupNorm(groups, dim_out)
+        self.conv2 = nn.Conv2d(dim_out, dim_out, 3, padding=1)
+        self.norm2 = nn.GroupNorm(groups, dim_out)
+        self.res_conv = nn.Conv2d(dim_in, dim_out, 1) if dim_in != dim_out else nn.Identity()
+
+    def run(self, src0, src1, film, vec=None, out=None):
+        """conv3x3 -> GN -> FiLM -> SiLU -> conv3x3 -> GN -> SiLU, + res(src) [+ vec]; src = cat(src0, src1)."""
+        B, _, H, W = src0.shape
+        Co, G, HW = self.dim_out, self.groups, H * W
+        h1, st1 = ops.conv2d(src0, packed(self.conv1), self.conv1.bias, 3, Co, src1=src1, want_stats=True)
+        ab1 = ops.gn_finalize(st1, G, HW, self.norm1.weight, self.norm1.bias, film=film, eps=self.norm1.eps)
+        h2, st2 = ops.conv2d(h1, packed(self.conv2), self.conv2.bias, 3, Co, pro=ab1, want_stats=True)
+        a2, b2 = ops.gn_finalize(st2, G, HW, self.norm2.weight, self.norm2.bias, eps=self.norm2.eps)
+        if isinstance(self.res_conv, nn.Identity):
+            assert src1 is None
+            return ops.affine_silu_add(h2, (a2, b2), res=src0, vec=vec, out=out)
+        return ops.conv2d(src0, packed(self.res_conv), self.res_conv.bias, 1, Co, src1=src1, aux=(h2, a2, b2), vec=vec, out=out)
+
+
+class ChanLayerNorm(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+
+class CrossAttention(nn.Module):
+    """Q <- feature map, K/V <- image-embedding tokens [B,M,ctx_dim]."""
+
+    def __init__(self, dim, ctx_dim, num_heads=4):
+        super().__init__()
+        self.dim, self.num_heads = dim, num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.norm = ChanLayerNorm(dim)
+        self.q_proj = nn.Conv2d(dim, dim, 1, bias=False)
+        self.k_proj = nn.Linear(ctx_dim, dim, bias=False)
+        self.v_proj = nn.Linear(ctx_dim, dim, bias=False)
+        self.proj = nn.Conv2d(dim, dim, 1)
+
+    def single_token_vec(self, ctx):
+        """M == 1: softmax over one key is exactly 1, so the block's output is proj(v_proj(ctx)) at every
+        pixel: a per-(sample, channel) vector [B, C] (exact, not an approximation)."""
+        B = ctx.shape[0]
+        v = ops.linear(ctx.reshape(B, -1), self.v_proj.weight)
+        return ops.linear(v, self.proj.weight.reshape(self.dim, self.dim), self.proj.bias)
+
+    def run(self, x, ctx, out=None):
+        """general M: returns x + proj(attn(q_proj(norm(x)), k_proj(ctx), v_proj(ctx)))."""
+        B, C, H, W = x.shape
+        M = ctx.shape[1]
+        xn = ops.chan_layernorm(x, self.norm.weight, self.norm.bias)
+        q = ops.conv2d(xn, packed(self.q_proj), None, 1, C)
+        c2 = ctx.reshape(B * M, -1)
+        k = ops.linear(c2, self.k_proj.weight).reshape(B, M, C)
+        v = ops.linear(c2, self.v_proj.weight).reshape(B, M, C)
+        o = ops.attn_ctx(q, k, v, self.num_heads, self.scale)
+        return ops.conv2d(o, packed(self.proj), self.proj.bias, 1, C, res=x, out=out)
+
+
+class SelfAttention(nn.Module):
+    def __init__(self, dim, num_heads=4):
+        super().__init__()
+        self.dim, self.num_heads = dim, num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.norm = ChanLayerNorm(dim)
+        self.qkv = nn.Conv2d(dim, dim * 3, 1, bias=False)
+        self.proj = nn.Conv2d(dim, dim, 1)
+
+    def run(self, x, vec=None):
+        xn = ops.chan_layernorm(x, self.norm.weight, self.norm.bias)
+        qkv = ops.conv2d(xn, packed(self.qkv), None, 1, 3 * self.dim)
+        o = ops.attn_self(qkv, self.num_heads, self.scale)
+        return ops.conv2d(o, packed(self.proj), self.proj.bias, 1, self.dim, res=x, vec=vec)
+
+
+class Downsample(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.dim_out = dim_out
+        self.conv = nn.Conv2d(dim_in * 4, dim_out, 1)
+
+    def run(self, x):
+        return ops.conv2d(x, packed(self.conv), self.conv.bias, 1, self.dim_out, mode=ops.CONV_UNSHUFFLE2)
+
+
+class Upsample(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.dim_out = dim_out
+        self.conv = nn.Conv2d(dim_in, dim_out, 3, padding=1)
+
+    def run(self, x):
+        return ops.conv2d(x, packed(self.conv), self.conv.bias, 3, self.dim_out, mode=ops.CONV_UPSAMPLE2)
+
+
+class SameConv(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.dim_out = dim_out
+        self.conv = nn.Conv2d(dim_in, dim_out, 3, padding=1)
+
+    def run(self, x):
+        return ops.conv2d(x, packed(self.conv), self.conv.bias, 3, self.dim_out)
+
+
+class Level(nn.Module):
+    pass
+
+
+class LearnableForwardUNet_MultiScoreMap(nn.Module):
+    """forward(x_a, x_b, t, names, text_encoder, image_context=None) -> (pred [B,1,H,W], [sm_0..sm_3])
+    (text_module == 'scoremap') or pred -- the contract of models/drift_noise_model.py:250-268."""
+
+    def __init__(self, in_nc=2, out_nc=5, nf=64, ch_mult=(1, 2, 4, 4), context_dim=512, text_module="scoremap", score_map_chan=16,
+                 if_MultiScoreMap=True, score_map_ch_mult=(1, 1, 2, 4), score_map_ngf=16, use_image_context=False,
+                 use_degra_context=False, CLIP_ScoreMapModule=None, artifact_types=ARTIFACT_TYPES, gn_groups=8, attn_heads=4,
+                 **_ignored):
+        super().__init__()
+        if use_degra_context:
+            raise NotImplementedError("use_degra_context=True is outside the hot-path scope (config.yml:133 sets it False)")
+        self.text_module = text_module
+        self.use_image_context = use_image_context
+        self.type_map_ind = {n: i for i, n in enumerate(artifact_types)}
+        self.depth = len(ch_mult)
+        self.nf, self.out_nc, self.in_nc = nf, out_nc, in_nc
+        K = len(artifact_types)
+        time_dim = nf * 4
+        self.time_dim = time_dim
+        mult = [1] + list(ch_mult)
+        self.init_conv = nn.Conv2d(in_nc, nf, 7, padding=3)
+        self.time_mlp = nn.Sequential(nn.Linear(nf, time_dim), nn.GELU(), nn.Linear(time_dim, time_dim))
+        half = nf // 2
+        self.register_buffer("time_freqs", torch.exp(torch.arange(half, dtype=torch.float32) * (-math.log(10000.0) / (half - 1))),
+                             persistent=False)
+        use_sm = text_module == "scoremap"
+        self.CLIP_ScoreMapModule = CLIP_ScoreMapModule if use_sm else None
+        self.downs = nn.ModuleList()
+        self.ups = nn.ModuleList()
+        self.sm_embed = nn.ModuleList()
+        self.level_dims = []
+        for i in range(self.depth):
+            din, dout = nf * mult[i], nf * mult[i + 1]
+            smc = score_map_ngf * score_map_ch_mult[i] if use_sm else 0
+            self.level_dims.append((din, dout, smc))
+            lv = Level()
+            lv.res1 = ResBlock(din, din, time_dim, gn_groups)
+            lv.res2 = ResBlock(din, din, time_dim, gn_groups)
+            if use_image_context:
+                lv.ca1 = CrossAttention(din, context_dim, attn_heads)
+                lv.ca2 = CrossAttention(din, context_dim, attn_heads)
+            lv.down = Downsample(din, dout) if i != self.depth - 1 else SameConv(din, dout)
+            self.downs.append(lv)
+            if use_sm:
+                self.sm_embed.append(nn.Conv2d(K, smc, 3, padding=1))
+            up = Level()
+            up.res1 = ResBlock(dout + din + smc, dout, time_dim, gn_groups)
+            up.res2 = ResBlock(dout + din, dout, time_dim, gn_groups)
+            if use_image_context:
+                up.ca1 = CrossAttention(dout, context_dim, attn_heads)
+                up.ca2 = CrossAttention(dout, context_dim, attn_heads)
+            up.up = Upsample(dout, din) if i != 0 else SameConv(dout, din)
+            self.ups.insert(0, up)
+        mid = nf * mult[-1]
+        self.mid_res1 = ResBlock(mid, mid, time_dim, gn_groups)
+        self.mid_attn = SelfAttention(mid, attn_heads)
+        if use_image_context:
+            self.mid_ca = CrossAttention(mid, context_dim, attn_heads)
+        self.mid_res2 = ResBlock(mid, mid, time_dim, gn_groups)
+        self.final_res = ResBlock(nf * 2, nf, time_dim, gn_groups)
+        self.final_conv = nn.Conv2d(nf, out_nc, 3, padding=1)
+        self._ctx_cache = None
+        self._idx_cache = {}
+
+    # ---- helpers ---------------------------------------------------------------------------------
+    def resblocks(self):
+        rbs = []
+        for lv in self.downs:
+            rbs += [lv.res1, lv.res2]
+        rbs += [self.mid_res1, self.mid_res2]
+        for up in self.ups:
+            rbs += [up.res1, up.res2]
+        rbs.append(self.final_res)
+        return rbs
+
+    def cross_attns(self):
+        if not self.use_image_context:
+            return []
+        cas = []
+        for lv in self.downs:
+            cas += [lv.ca1, lv.ca2]
+        cas.append(self.mid_ca)
+        for up in self.ups:
+            cas += [up.ca1, up.ca2]
+        return cas
+
+    def class_index(self, names, device):
+        key = (tuple(names), str(device))
+        hit = self._idx_cache.get(key)
+        if hit is None:
+            hit = torch.tensor([self.type_map_ind[n] for n in names], dtype=torch.int32, device=device)
+            self._idx_cache[key] = hit
+        return hit
+
+    def _films(self, temb):
+        """all ResBlock time projections Linear(SiLU(temb)) in ONE launch -> per-block [B, 2C] views."""
+        rbs = self.resblocks()
+        w, b = _PREP.get(("film", self), [p for rb in rbs for p in (rb.mlp.weight, rb.mlp.bias)],
+                         lambda: (torch.cat([rb.mlp.weight for rb in rbs], 0).detach().contiguous(),
+                                  torch.cat([rb.mlp.bias for rb in rbs], 0).detach().contiguous()))
+        allf = ops.linear(temb, w, b, act_in=ops.ACT_SILU)
+        out, o = {}, 0
+        for rb in rbs:
+            out[id(rb)] = allf[:, o:o + 2 * rb.dim_out]
+            o += 2 * rb.dim_out
+        return out
+
+    def _ctx_vecs(self, ctx):
+        """single-token image context: per-block vectors, cached across denoising steps (ctx is constant)."""
+        cas = self.cross_attns()
+        key = (ctx._version, tuple(ctx.shape)) + tuple((p.data_ptr(), p._version) for ca in cas
+                                                        for p in (ca.v_proj.weight, ca.proj.weight, ca.proj.bias))
+        c = self._ctx_cache
+        if c is not None and c[0] == key and c[2]() is ctx:
+            return c[1]
+        vecs = {id(ca): ca.single_token_vec(ctx) for ca in cas}
+        self._ctx_cache = (key, vecs, weakref.ref(ctx))
+        return vecs
+
+    # ---- forward ---------------------------------------------------------------------------------
+    def forward(self, x_a, x_b, t, names, text_encoder, image_context=None):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .unet_autograd import forward_train  # hand-written backward kernels
+            return forward_train(self, x_a, x_b, t, names, text_encoder, image_context)
+        return self.forward_infer(x_a, x_b, t, names, text_encoder, image_context)
+
+    @torch.no_grad()
+    def forward_infer(self, x_a, x_b, t, names, text_encoder, image_context=None):
+        dev = x_a.device
+        B, _, H, W = x_a.shape
+        if not torch.is_tensor(t):
+            t = torch.full((B,), float(t), dtype=torch.float32, device=dev)
+        t = t.reshape(-1).to(device=dev, dtype=torch.float32)
+        if t.numel() == 1 and B > 1:
+            t = t.expand(B)
+        t = t.contiguous()
+        idx = self.class_index(names, dev)
+        ctx = image_context if self.use_image_context else None
+        single = ctx is not None and ctx.shape[1] == 1
+        general = ctx is not None and not single
+        if ctx is not None:
+            ctx = ctx.contiguous()
+        vecs = self._ctx_vecs(ctx) if single else {}
+
+        def ca_vec(ca_name, holder):
+            return vecs[id(getattr(holder, ca_name))] if single else None
+
+        temb0 = ops.time_embed(t, self.nf, self.time_freqs)
+        temb = ops.linear(ops.linear(temb0, self.time_mlp[0].weight, self.time_mlp[0].bias, act_out=ops.ACT_GELU),
+                          self.time_mlp[2].weight, self.time_mlp[2].bias)
+        films = self._films(temb)
+
+        x = ops.conv2d(x_a, packed(self.init_conv), self.init_conv.bias, 7, self.nf, src1=x_b)
+        x_ = x
+        hs, sms = [], []
+        use_sm = self.CLIP_ScoreMapModule is not None
+        for i, lv in enumerate(self.downs):
+            din, dout, smc = self.level_dims[i]
+            Hi, Wi = x.shape[2], x.shape[3]
+            x = lv.res1.run(x, None, films[id(lv.res1)], vec=ca_vec("ca1", lv))
+            if general:
+                x = lv.ca1.run(x, ctx)
+            hs.append(x)
+            if use_sm:
+                skip = torch.empty((B, din + smc, Hi, Wi), device=dev, dtype=torch.float32)
+                xo = skip[:, :din]
+            else:
+                skip, xo = None, None
+            x = lv.res2.run(x, None, films[id(lv.res2)], vec=ca_vec("ca2", lv), out=None if general else xo)
+            if general:
+                x = lv.ca2.run(x, ctx, out=xo)
+            if use_sm:
+                score, sel = self.CLIP_ScoreMapModule[i](x, text_encoder, idx)
+                sms.append(sel)
+                ops.conv2d(score, packed(self.sm_embed[i]), self.sm_embed[i].bias, 3, smc, out=skip[:, din:])
+                hs.append(skip)
+            else:
+                hs.append(x)
+            x = lv.down.run(x)
+        x = self.mid_res1.run(x, None, films[id(self.mid_res1)])
+        x = self.mid_attn.run(x, vec=ca_vec("mid_ca", self))
+        if general:
+            x = self.mid_ca.run(x, ctx)
+        x = self.mid_res2.run(x, None, films[id(self.mid_res2)])
+        for up in self.ups:
+            x = up.res1.run(x, hs.pop(), films[id(up.res1)], vec=ca_vec("ca1", up))
+            if general:
+                x = up.ca1.run(x, ctx)
+            x = up.res2.run(x, hs.pop(), films[id(up.res2)], vec=ca_vec("ca2", up))
+            if general:
+                x = up.ca2.run(x, ctx)
+            x = up.up.run(x)
+        x = self.final_res.run(x, x_, films[id(self.final_res)])
+        out = ops.conv2d(x, packed(self.final_conv), self.final_conv.bias, 3, self.out_nc)
+        pred = ops.gather_channel(out, idx)
+        if self.text_module == "scoremap":
+            return pred, sms
+        return pred
