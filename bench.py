@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoising steps/sec of the InstanceDiff sampling loop on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank/GPU)
+
+Workload (BASELINE.json configs[1]): 256x256 1-channel synthetic batch of 16, T=1000 reverse chain; one STEP =
+one reverse-loop iteration of CLIPDriftModel.test()/driftSDE.reverse_ddpm = 2 UNet forwards (drift_net +
+noise_net, each with its 4 ScoreMapModules and single-token image-context cross-attention) + the fused reverse
+update, fp32, random-init weights (seed 0), inputs resident in HBM, on-device Philox noise.  Multi-GPU = N
+independent replicas (sampling shards by image, no data-path collective) -> weak scaling.
+
+Prints ONE JSON line: metric/value/... plus
+  roofline     : dominant kernel = 3x3 implicit-GEMM conv on the f32 matrix cores; algorithmic FLOP per launch /
+                 average launch duration (HIP events on the launch stream, second pass over the same K steps),
+                 against the 157.3 TFLOP/s f32-MFMA peak (MI355X_MICROARCH.md)
+  cpu_baseline : the oracle (plain PyTorch fp32 restatement of the same step) on the host cores, bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--T", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=1)
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+class StepRunner:
+    """The body of driftSDE.reverse_ddpm's loop, one iteration per call (same kernels, same order)."""
+
+    def __init__(self, model, sde, batch):
+        from instancediff_amd import ops
+        self.ops, self.model, self.sde = ops, model, sde
+        dev = model.device
+        self.cond = batch['input'].to(dev).contiguous()
+        self.names = batch['names']
+        self.ctx = batch['A_emb'].to(dev).contiguous()
+        self.x = ops.axpby(self.cond, ops.randn(self.cond.shape, dev, 4321, 0), 1.0, sde.max_sigma)
+        self.xa = ops.axpby(self.x, self.cond, 1.0, -1.0)
+        self.x2, self.xa2 = torch.empty_like(self.x), torch.empty_like(self.x)
+        self.tdev = torch.empty((self.cond.shape[0],), dtype=torch.float32, device=dev)
+        self.t = sde.T
+        self.calls = 1
+
+    @torch.no_grad()
+    def step(self):
+        sde, m, ops = self.sde, self.model, self.ops
+        t = self.t
+        self.tdev.fill_(float(t))
+        r_hat = m.drift_net(self.xa, self.cond, self.tdev, self.names, m.text_encoder, image_context=self.ctx)[0]
+        e_hat = m.noise_net(self.xa, self.x, self.tdev, self.names, m.text_encoder, image_context=self.ctx)[0]
+        off = self.calls * ((self.x.numel() + 3) // 4)
+        self.calls += 1
+        ops.drift_reverse_step(self.x, r_hat, e_hat, None, float(sde._a[t]), float(sde._b[t]), float(sde._c[t]), cond=self.cond, seed=4321,
+                               offset=off, out=self.x2, xa_out=self.xa2)
+        self.x, self.x2 = self.x2, self.x
+        self.xa, self.xa2 = self.xa2, self.xa
+        self.t = t - 1 if t > 1 else sde.T
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota (a GPU box exposes
+    every host core to os.cpu_count() but grants a share; oversubscribing it makes the oracle crawl)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                        n = min(n, max(1, int(q / int(f2.read()))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    env = os.environ.get("IDIFF_CPU_THREADS")
+    if env:
+        n = int(env)
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(args, batch_full):
+    """Oracle step (2 oracle UNet forwards + oracle reverse update) on the host cores, on a bounded sample of the
+    same workload: the first `cpu_sample_batch` images of the batch; steps/s is scaled to the full batch."""
+    import torch.nn as nn
+    from oracle import sde_ref, unet_ref
+    from instancediff_amd import pipeline
+    ncores = host_cores()
+    torch.set_num_threads(ncores)
+    bs = min(args.cpu_sample_batch, args.batch)
+    opt = pipeline.load_options()
+    mo = opt['models']['DriftNoise']
+    nets = []
+    torch.manual_seed(0)
+    for key in ('dnet_settings', 'nnet_settings'):
+        s = {k: v for k, v in dict(mo[key]).items() if k not in ("module_name", "class_name")}
+        smm = nn.ModuleList([unet_ref.ScoreMapModule(visual_dim=mo['score_map_ngf'] * m) for m in mo['score_map_ch_mult']])
+        nets.append(unet_ref.LearnableForwardUNet_MultiScoreMap(CLIP_ScoreMapModule=smm, use_image_context=True, **s).eval())
+    te = unet_ref.StubTextEncoder()
+    sde = sde_ref.DriftSDERef(args.T, nets[0], nets[1], max_sigma=0.4)
+    cond = batch_full['input'][:bs]
+    names = batch_full['names'][:bs]
+    ctx = batch_full['A_emb'][:bs]
+    g = torch.Generator().manual_seed(4321)
+    x = cond + 0.4 * torch.randn(cond.shape, generator=g)
+
+    def one(x, t):
+        tt = torch.full((bs,), t, dtype=torch.long)
+        with torch.no_grad():
+            rd = nets[0](x - cond, cond, tt, names, te, image_context=ctx)[0]
+            rn = nets[1](x - cond, x, tt, names, te, image_context=ctx)[0]
+        z = torch.randn(cond.shape, generator=g)
+        return sde_ref.drift_reverse_update(x, rd, rn, z, sde.a[t], sde.b[t], sde.c[t])
+
+    log("cpu oracle built, warm step (B=%d)" % bs)
+    x = one(x, args.T)  # warm
+    log("cpu warm step done")
+    n, t0 = 0, time.time()
+    while True:
+        x = one(x, args.T - 1 - n)
+        n += 1
+        el = time.time() - t0
+        if el > 12.0 or n >= 3:
+            break
+    sps_sample = n / el
+    return {"value": sps_sample * bs / args.batch, "unit": "denoising steps/s (batch %d)" % args.batch, "cores": ncores, "kind": "port",
+            "sample": "%d timed step(s) of the oracle on the first %d of %d images (%.2f s/step at B=%d), scaled by %d/%d; torch %d threads"
+                      % (n, bs, args.batch, el / n, bs, bs, args.batch, ncores)}
+
+
+def log(msg):
+    print("[bench %7.1fs] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.time()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU: the hot path has no CPU fallback", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    from instancediff_amd import ops, pipeline
+    from instancediff_amd.utils.synthetic import make_batch
+
+    model, sde = pipeline.build(phase="test", device=dev, T=args.T, seed=0)
+    model.set_eval()
+    batch = make_batch(args.batch, args.size, seed=1234 + rank, mixed=True)
+    run = StepRunner(model, sde, batch)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log("model built; warmup")
+    for _ in range(args.warmup):
+        run.step()
+    barrier()
+    log("warmup done; timing %d steps" % args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run.step()
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        el = float(tmax.item())
+    assert torch.isfinite(run.x).all(), "non-finite state after the timed steps"
+    log("timed region: %.3f s for %d steps" % (el, args.steps))
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        ops.PROFILE = []
+        run.t = sde.T - args.warmup if sde.T > args.warmup else sde.T
+        for _ in range(args.steps):
+            run.step()
+        torch.cuda.synchronize()
+        recs = [r for r in ops.PROFILE if r['ks'] == 3 and r['Cin'] >= 64 and r['Cout'] >= 64]
+        allrecs = ops.PROFILE
+        ops.PROFILE = None
+        tot_ms = sum(r['e0'].elapsed_time(r['e1']) for r in recs)
+        tot_fl = sum(r['flops'] for r in recs)
+        all_ms = sum(r['e0'].elapsed_time(r['e1']) for r in allrecs)
+        all_fl = sum(r['flops'] for r in allrecs)
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<3x3> (f32 MFMA implicit GEMM)", "achieved": round(ach, 2),
+                "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches": len(recs), "avg_launch_ms": round(tot_ms / max(len(recs), 1), 4),
+                "gflop_per_launch": round(tot_fl / max(len(recs), 1) / 1e9, 3),
+                "conv_share_of_step": round(all_ms / args.steps / (el / args.steps * 1e3), 3),
+                "all_conv_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2),
+                "step_conv_gflop": round(all_fl / args.steps / 1e9, 1)}
+    if world > 1:
+        barrier()
+
+    if rank == 0:
+        cpu = None
+        if not args.no_cpu_baseline:
+            log("cpu baseline (oracle) ...")
+            try:
+                cpu = cpu_baseline(args, batch)
+            except Exception as e:  # the baseline is a reported side measurement; never hide the GPU result
+                cpu = {"error": repr(e)}
+        value = world * args.steps / el
+        line = {"metric": "denoising steps/sec (%dx%d bs%d)" % (args.size, args.size, args.batch), "value": round(value, 4),
+                "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "%dx%d 1-ch synthetic, %d-step reverse chain, batch %d per GPU, 2 UNet fwd + reverse update per step"
+                                       % (args.size, args.size, args.T, args.batch),
+                           "global_batch": args.batch * world, "parallelism": "replicas x%d (no collective)" % world,
+                           "image_steps_per_s": round(value * args.batch, 2)},
+                "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -70,7 +70,7 @@ def header_symbols(path=HEADER_PATH):
     with open(path) as f:
         txt = f.read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(idiff_[a-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(idiff_[A-Za-z0-9_]+)\s*\(", txt)))
 
 
 class IdiffError(RuntimeError):

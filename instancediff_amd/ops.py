@@ -12,6 +12,9 @@ CONV_NORMAL, CONV_UPSAMPLE2, CONV_UNSHUFFLE2 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 SDE_STEP, SDE_MEAN, SDE_ODE = 0, 1, 2
 
+# bench.py sets this to a list to time every conv launch with events on the launch stream (roofline leg)
+PROFILE = None
+
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -109,7 +112,16 @@ def conv2d(src0, wpk, bias, ks, Cout, src1=None, mode=CONV_NORMAL, pro=None, out
         nt = lib.idiff_conv2d_num_tiles(Hout, Wout)
         stats = torch.empty((B, nt, Cout, 2), device=src0.device, dtype=torch.float32)
         d.stats = stats.data_ptr()
-    check(lib.idiff_conv2d_fwd(C.byref(d), _stream()), "conv2d_fwd")
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.idiff_conv2d_fwd(C.byref(d), _stream()), "conv2d_fwd")
+        e1.record()
+        Cin = (C0 * 4 if mode == CONV_UNSHUFFLE2 else C0) + (src1.shape[1] if src1 is not None else 0)
+        PROFILE.append(dict(ks=ks, mode=mode, Cin=Cin, Cout=Cout, B=B, Hout=Hout, Wout=Wout, e0=e0, e1=e1,
+                            flops=2.0 * Cin * Cout * ks * ks * Hout * Wout * B))
+    else:
+        check(lib.idiff_conv2d_fwd(C.byref(d), _stream()), "conv2d_fwd")
     return (out, stats) if want_stats else out
 
 

@@ -1,0 +1,38 @@
+"""Assembles the reference pipeline objects (option dict -> model -> sde) the way trainUM.py:189-217 /
+testUM.py:66-96 do, for drivers, bench.py, __graft_entry__.smoke() and tests."""
+import copy
+import os
+
+import torch
+
+from . import options as option
+from .models import create_model
+from .models.SDEs import create_sde
+
+DEFAULT_YAML = os.path.join(os.path.dirname(os.path.abspath(__file__)), "Configurations", "um_iddm.yml")
+
+
+def load_options(path=DEFAULT_YAML, is_train=False):
+    return option.dict_to_nonedict(option.parse(path, is_train=is_train))
+
+
+def build(opt=None, phase="test", device=None, T=None, seed=0, dist=False, sde_overrides=None):
+    """-> (model: CLIPDriftModel, sde).  Random-init weights (seed) as the reference does for a fresh run."""
+    opt = opt or load_options()
+    train_opt = copy.deepcopy(dict(opt['train']))
+    train_opt['dist'] = dist
+    which = (opt['test'] or {}).get('which_model') if phase == 'test' and opt['test'] else None
+    model_opt = opt['models'][which or train_opt['which_model']]
+    torch.manual_seed(seed)
+    from .models.drift_noise_model import create_CLIPDriftModel  # registry target, imported for the device kwarg
+    model = create_CLIPDriftModel(train_opt, model_opt, phase=phase, device=device) if device is not None else \
+        create_model(train_opt, model_opt, phase=phase)
+    sde_opt = dict(opt['sdes'][train_opt['which_sde']])
+    if T is not None:
+        sde_opt['T'] = T
+    if sde_overrides:
+        sde_opt.update(sde_overrides)
+    sde = create_sde(model.get_nets(), sde_opt)
+    sde.set_gpu(model.device)
+    model.set_sde(sde)
+    return model, sde

@@ -253,13 +253,16 @@ def test_irsde_step_bit_exact_vs_oracle(golden_sde):
                                          mode=mode, **kw)
             assert torch.equal(out.cpu(), ref), f"mode {mode} t {t}: max diff {(out.cpu() - ref).abs().max()}"
     # golden trajectory from the REAL reference: 3 steps with the analytic model evaluated on the host
+    # (schedule scalars are taken from the golden tables: cos/exp on another host CPU may differ by an ulp)
     xs = torch.from_numpy(gd["t64/xT"]).to(DEV)
     top = gd["t64/top_steps"]
+    gth, gsg, gsb = gd["cos100_s50/thetas"], gd["cos100_s50/sigmas"], gd["cos100_s50/sigma_bars"]
+    gdt = float(gd["cos100_s50/dt"])
     for i, t in enumerate(gd["t64/top_ts"].tolist()):
         xc = xs.cpu()
         npred = 0.3 * xc - 0.2 * mu + (0.01 * float(t * sde.sample_scale)) * (xc * mu)
-        xs = ops.irsde_reverse_step(xs, mu.to(DEV), npred.to(DEV), noises[i].to(DEV), theta=float(sde.thetas[t]), sigma=float(sde.sigmas[t]),
-                                    sigma_bar=float(sde.sigma_bars[t]), dt=float(sde.dt), sqrt_dt=math.sqrt(float(sde.dt)))
+        xs = ops.irsde_reverse_step(xs, mu.to(DEV), npred.to(DEV), noises[i].to(DEV), theta=float(gth[t]), sigma=float(gsg[t]),
+                                    sigma_bar=float(gsb[t]), dt=gdt, sqrt_dt=math.sqrt(gdt))
         assert np.array_equal(xs.cpu().numpy(), top[i][3])
 
 
