@@ -212,7 +212,8 @@ def main():
         for _ in range(args.steps):
             run.step()
         torch.cuda.synchronize()
-        recs = [r for r in ops.PROFILE if r['ks'] == 3 and r['Cin'] >= 64 and r['Cout'] >= 64]
+        # dominant kernel = conv_igemm_kernel<3,8,5,0,true>: plain 3x3, 32-wide tiles, Cout % 64 == 0
+        recs = [r for r in ops.PROFILE if r['ks'] == 3 and r['mode'] == 0 and r['Cout'] % 64 == 0 and r['Wout'] >= 32]
         allrecs = ops.PROFILE
         ops.PROFILE = None
         tot_ms = sum(r['e0'].elapsed_time(r['e1']) for r in recs)

@@ -1,0 +1,91 @@
+"""Data parallelism for the InstanceDiff hot path on one MI355X node: one process per GPU,
+`torch.distributed` (backend "nccl" == RCCL on ROCm, over xGMI).
+
+Replaces the reference's 10 `DistributedDataParallel` wrappers with `find_unused_parameters=True`
+(models/drift_noise_model.py:115-146) and its hard-coded `world_size=2` (trainUM.py:66) by
+  * ONE flat fp32 gradient buffer (both nets, ~50 M parameters = ~200 MB) whose slices ARE the
+    parameters' .grad tensors, so "packing" is free, and
+  * ONE all-reduce(SUM) per step followed by a 1/world scale (fused into the optimizer's grad scale).
+xGMI is point-to-point (7 links/GPU): a single large message lets RCCL drive all links; 200 MB is far
+above the latency-bound regime, and the exchange is << the ~100 ms backward.
+
+Sampling needs no collective: images are independent, ranks take `indices[rank::world]`
+(data/data_sampler.py:59 semantics) -- `shard_indices`.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """env:// rendezvous from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (torchrun); returns
+    (rank, world, local_rank).  No-op for WORLD_SIZE<=1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, world, local
+
+
+def shard_indices(n, rank, world):
+    """indices[rank::world] -- the reference sampler's partition (data/data_sampler.py:59)."""
+    return list(range(n))[rank::world]
+
+
+class FlatGradAllReduce:
+    """Owns one flat gradient buffer; every parameter's .grad is a view into it."""
+
+    def __init__(self, params, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        assert self.params, "no trainable parameters"
+        dev, dt = self.params[0].device, self.params[0].dtype
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, device=dev, dtype=dt)
+        o = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[o:o + n].view_as(p)
+            o += n
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def zero(self):
+        self.flat.zero_()
+
+    def rebind(self):
+        """re-attach .grad views (an optimizer's zero_grad(set_to_none=True) would drop them)."""
+        o = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.flat[o:o + n].data_ptr():
+                p.grad = self.flat[o:o + n].view_as(p)
+            o += n
+
+    @torch.no_grad()
+    def broadcast_parameters(self, src=0):
+        """rank-0 weights -> all ranks (what DDP does at construction; reference C2)."""
+        if self.world <= 1:
+            return
+        for p in self.params:
+            dist.broadcast(p.data, src=src, group=self.group)
+
+    @torch.no_grad()
+    def all_reduce(self, average=True):
+        """SUM over ranks; returns the factor the caller must still apply (1/world when averaging is deferred to
+        the optimizer's fused grad scale) -- or applies it here when average=True."""
+        if self.world <= 1:
+            return 1.0
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        if average:
+            self.flat.mul_(1.0 / self.world)
+            return 1.0
+        return 1.0 / self.world

@@ -150,6 +150,7 @@ class IRSDE:
     def reverse_ode_step(self, x, noise_pred, t):
         return self._step(x, noise_pred, t, ops.SDE_ODE)
 
+    @torch.no_grad()
     def _loop(self, xt, T, mode, noises=None, **kwargs):
         T = self.sample_T if T < 0 else T
         x = xt.contiguous().clone()

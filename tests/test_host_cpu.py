@@ -1,0 +1,217 @@
+"""CPU-only tests (-m "not gpu"): the C-ABI library loads and exports every symbol of include/idiff.h,
+host logic (options, registries, schedules, caches, sharding) and the loud-failure contract.  No kernel
+is launched here."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from instancediff_amd import _lib, options, pipeline  # noqa: E402
+from instancediff_amd.models import create_model  # noqa: E402
+from instancediff_amd.models.SDEs import create_sde  # noqa: E402
+from instancediff_amd.models.modules import create_net  # noqa: E402
+from instancediff_amd.utils.sde_utils import IRSDE  # noqa: E402
+from instancediff_amd.utils.synthetic import ARTIFACT_TYPES, make_batch  # noqa: E402
+from oracle import sde_ref  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "instancediff_amd", "csrc"), "-j", "4"], check=True)
+    return _lib.load()
+
+
+def test_cabi_exports_every_header_symbol(built_lib):
+    syms = _lib.header_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(built_lib, s), f"{s} declared in include/idiff.h but not exported"
+    assert sorted(_lib.SIGNATURES) == syms
+    assert built_lib.idiff_version() >= 1
+    assert built_lib.idiff_conv2d_num_tiles(256, 256) == 256  # 8x32 tiles
+    assert built_lib.idiff_conv2d_num_tiles(16, 16) == 1
+    assert built_lib.idiff_smm_xattn_ws_floats(16, 5, 4, 256, 65536) > 0
+
+
+def test_cabi_argument_errors_are_reported_not_crashes(built_lib):
+    import ctypes as C
+    d = _lib.ConvDesc()
+    assert built_lib.idiff_conv2d_fwd(C.byref(d), None) == -1
+    assert b"null pointer" in built_lib.idiff_last_error()
+    assert built_lib.idiff_irsde_reverse_step(None, None, None, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, None) == -1
+    assert built_lib.idiff_linear_fwd(None, 0, None, 0, None, None, 0, None, None, 0, 1, 1, 1, 0, 0, None) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libidiff_hip.so")
+    with pytest.raises(_lib.IdiffError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_ops_refuse_cpu_tensors(built_lib):
+    from instancediff_amd import ops
+    x = torch.zeros(1, 8, 8, 8)
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.affine_silu_add(x)
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.irsde_reverse_step(x, x, x, None, 0.1, 0.1, 0.1, 0.1, 0.3)
+
+
+# ---- options / registries ---------------------------------------------------------------------------
+def test_options_parse_train_and_test(tmp_path):
+    opt = options.parse(pipeline.DEFAULT_YAML, is_train=True)
+    assert opt["is_train"] and opt["path"]["models"].endswith(os.path.join("experiments", "UM_IDDM_SM_IB", "models"))
+    assert opt["datasets"]["train"]["phase"] == "train" and opt["datasets"]["val"]["scale"] == 1
+    assert opt["models"]["DriftNoise"]["nnet_settings"]["ch_mult"] == [1, 2, 4, 4]
+    assert opt["models"]["DriftNoise"]["drift_net_lr"] == pytest.approx(2e-5)
+    nd = options.dict_to_nonedict(opt)
+    assert nd["no_such_key"] is None and nd["train"]["no_such_key"] is None
+    t = options.parse(pipeline.DEFAULT_YAML, is_train=False)
+    assert "results_root" in t["path"] and "experiments_root" not in t["path"]
+    assert "train" in options.dict2str(opt)
+    # debug names switch the frequencies (options.py:80-83)
+    p = tmp_path / "dbg.yml"
+    p.write_text(open(pipeline.DEFAULT_YAML).read().replace("name: UM_IDDM_SM_IB", "name: debug_run"))
+    d = options.parse(str(p), is_train=True)
+    assert d["train"]["val_freq"] == 8 and d["logger"]["print_freq"] == 1
+
+
+def test_registry_builds_reference_config_on_cpu():
+    model, sde = pipeline.build(phase="test", device=torch.device("cpu"), T=20)
+    from instancediff_amd.models.drift_noise_model import CLIPDriftModel
+    assert isinstance(model, CLIPDriftModel)
+    for name in ("feed_data", "set_sde", "optimize_parameters", "test", "get_visuals", "get_nets", "save", "load",
+                 "save_training_state", "resume_training", "set_eval", "set_train", "set_gpu", "reinit_loss_message",
+                 "get_loss_message", "get_current_learning_rate", "update_lr", "optimize_parameters_inputRes"):
+        assert hasattr(model, name), name
+    nets = model.get_nets()
+    assert set(nets) == {"noise_net", "drift_net"}
+    n_params = sum(p.numel() for p in nets["drift_net"].parameters())
+    assert 30e6 < n_params < 40e6
+    keys = list(nets["drift_net"].state_dict().keys())
+    assert any(k.startswith("CLIP_ScoreMapModule.0.") for k in keys)
+    assert sde.T == 20 and sde.max_sigma == 0.4 and len(sde.drift_schedule) == 21
+    # the CPU has no kernels: forward must raise, not fall back
+    b = make_batch(1, 32)
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            nets["drift_net"](b["input"], b["input"], torch.tensor([3.0]), b["names"], model.text_encoder, image_context=b["A_emb"])
+
+
+def test_create_model_and_create_sde_registry_names():
+    opt = pipeline.load_options()
+    m = create_model({"dist": False, "nepoch": 1}, opt["models"]["DriftNoise"], phase="test")
+    s = create_sde(m.get_nets(), opt["sdes"]["driftSDE"])
+    assert type(s).__name__ == "driftSDE" and s.T == 100
+    with pytest.raises((ImportError, AttributeError)):
+        create_net({"module_name": "MSM_degEmb_Unet", "class_name": "NoSuchNet"})
+
+
+def test_checkpoint_file_names_roundtrip(tmp_path):
+    model, _ = pipeline.build(phase="test", device=torch.device("cpu"), T=4)
+    model.save(123, str(tmp_path))
+    names = sorted(os.listdir(tmp_path))
+    assert names == sorted(["123_DP.pth", "123_NP.pth", "123_DN.pth", "123_NN.pth", "lastest_DP_ema.pth", "lastest_NP_ema.pth",
+                            "lastest_DN_ema.pth", "lastest_NN_ema.pth"])
+    sd = torch.load(tmp_path / "lastest_DN_ema.pth")
+    assert any(k.startswith("online_model.") for k in sd) and any(k.startswith("ema_model.") for k in sd)
+    w0 = model.drift_net.init_conv.weight.detach().clone()
+    with torch.no_grad():
+        model.drift_net.init_conv.weight.zero_()
+    # a reference-era DDP checkpoint has 'module.' prefixes (drift_noise_model.py:712-730)
+    dn = torch.load(tmp_path / "123_DN.pth")
+    torch.save({("module." + k): v for k, v in dn.items()}, tmp_path / "123_DN.pth")
+    model.load(123, str(tmp_path))
+    assert torch.equal(model.drift_net.init_conv.weight, w0)
+
+
+# ---- schedules ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,kw", [("cos100", dict(max_sigma=0.4, T=100, schedule="cosine", eps=0.01)),
+                                     ("cos100_s50", dict(max_sigma=0.4, T=100, sample_T=50, schedule="cosine", eps=0.01)),
+                                     ("cos1000", dict(max_sigma=0.4, T=1000, schedule="cosine", eps=0.01)),
+                                     ("lin100", dict(max_sigma=0.4, T=100, schedule="linear", eps=0.01)),
+                                     ("const100", dict(max_sigma=0.4, T=100, schedule="constant", eps=0.01)),
+                                     ("cos100_ms50", dict(max_sigma=50, T=100, schedule="cosine", eps=0.01))])
+def test_product_irsde_tables_bit_exact_vs_reference_golden(golden_sde, name, kw):
+    sde = IRSDE(device=torch.device("cpu"), **kw)
+    for k in ["thetas", "sigmas", "thetas_cumsum", "sigma_bars"]:
+        assert np.array_equal(getattr(sde, k).numpy(), golden_sde[f"{name}/{k}"]), k
+    assert float(sde.dt) == float(golden_sde[f"{name}/dt"])
+    assert sde.max_sigma == float(golden_sde[f"{name}/max_sigma"]) and sde.sample_scale == float(golden_sde[f"{name}/sample_scale"])
+    with pytest.raises(ValueError):
+        IRSDE(0.4, schedule="nope")
+
+
+def test_product_drift_sde_tables_equal_oracle():
+    from instancediff_amd.models.SDEs.driftSDE import driftSDE
+    for sched in ("sigmoid", "cosine", "linear"):
+        p = driftSDE(nets={}, T=50, max_sigma=0.3, drift_schedule=sched, noise_schedule=sched)
+        o = sde_ref.DriftSDERef(50, None, None, max_sigma=0.3, drift_schedule=sched, noise_schedule=sched)
+        assert torch.equal(p.drift_schedule, o.drift_schedule) and torch.equal(p.noise_schedule, o.noise_schedule)
+        assert torch.equal(p._a, o.a) and torch.equal(p._b, o.b) and torch.equal(p._c, o.c)
+    assert float(p._c[1]) == 0.0  # last step is noise free (s_0 = 0)
+
+
+def test_synthetic_batch_layout():
+    b = make_batch(7, 32, seed=3)
+    assert set(b) == {"input", "target", "names", "A_emb"}
+    assert b["input"].shape == b["target"].shape == (7, 1, 32, 32) and b["A_emb"].shape == (7, 1, 512)
+    assert set(b["names"]) <= set(ARTIFACT_TYPES) and len(set(b["names"])) == 5
+    assert float(b["target"].min()) >= -1.0 and float(b["target"].max()) <= 1.0
+    assert torch.allclose(b["A_emb"].norm(dim=-1), torch.ones(7, 1))
+    b2 = make_batch(7, 32, seed=3)
+    assert torch.equal(b["input"], b2["input"])
+
+
+# ---- multi-process (gloo, world_size 2) ----------------------------------------------------------------
+WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["IDIFF_ROOT"])
+import torch.distributed as dist
+from instancediff_amd import parallel
+rank, world, local = parallel.init_distributed(backend="gloo")
+assert world == 2 and dist.get_world_size() == 2
+torch.manual_seed(100 + rank)           # different init per rank: broadcast must equalise it
+net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 4))
+sync = parallel.FlatGradAllReduce(list(net.parameters()))
+sync.broadcast_parameters()
+w = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+ws = [torch.zeros_like(w) for _ in range(2)]
+dist.all_gather(ws, w)
+assert torch.equal(ws[0], ws[1])
+x = torch.full((3, 8), float(rank + 1))
+net(x).sum().backward()
+for p in net.parameters():              # grads landed in the flat buffer (views)
+    assert p.grad.data_ptr() >= sync.flat.data_ptr()
+g_local = sync.flat.clone()
+gs = [torch.zeros_like(g_local) for _ in range(2)]
+dist.all_gather(gs, g_local)
+f = sync.all_reduce(average=False)
+assert abs(f - 0.5) < 1e-12
+assert torch.allclose(sync.flat, gs[0] + gs[1])
+# sampling shards: disjoint cover (data_sampler.py:59 semantics)
+idx = parallel.shard_indices(11, rank, world)
+alli = [None, None]
+dist.all_gather_object(alli, idx)
+assert sorted(alli[0] + alli[1]) == list(range(11)) and not set(alli[0]) & set(alli[1])
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_gloo_world2_flat_grad_allreduce_and_sharding(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, IDIFF_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29531", str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
