@@ -30,6 +30,8 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE divide: used on the conv gather/epilogue
+__device__ __forceinline__ float silu_fast(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 // XCD-aware bijective remap of a linear workgroup id: blocks b and b+8 share an XCD (observed
 // round-robin dispatch), so give each XCD a contiguous chunk of the logical grid.  Speed only.

@@ -1,17 +1,18 @@
 // Implicit-GEMM 2-D convolution for gfx950 on the f32 matrix cores (v_mfma_f32_32x32x2_f32).
 //
-//   GEMM view:  M = Cout (64 per workgroup), N = output pixels (256 per workgroup, a TH x TW patch of one
-//   sample, TW in {32,16,8}), K = taps * Cin, walked in chunks of CK input channels.
+//   GEMM view:  M = Cout (BM = 64 or 32 per workgroup), N = output pixels (256 per workgroup, a TH x TW patch
+//   of one sample, TW in {32,16,8}), K = taps * Cin, walked in chunks of CK input channels.
 //   A (weights) and B (input patch with halo) are staged through LDS, double buffered, register-staged
-//   (issue global loads for chunk c+1, run the MFMAs of chunk c, then write LDS; one barrier per chunk).
-//   Each of the 4 waves owns all 64 output channels x 64 pixels = 2x2 accumulators of 32x32.
+//   (issue global loads for chunk c+1, run the MFMAs of chunk c, then activate + write LDS; one barrier per
+//   chunk).  Each of the 4 waves owns all BM output channels x 64 pixels = MB x 2 accumulators of 32x32.
 //   NCHW keeps the N (pixel) index contiguous along W, so the B-operand LDS reads, the global gathers and
 //   the epilogue stores (32 consecutive pixels per half-wave) are all unit-stride.
 //
 //   Fused in the gather   : virtual channel concat of two sources, nearest x2 upsample, pixel-unshuffle(2),
 //                           GroupNorm/FiLM affine + SiLU of the producer (zero padding applied after it).
 //   Fused in the epilogue : bias, residual, per-(b,c) vector, "+ silu(a*aux+b)" term, and deterministic
-//                           per-(b,c,tile) sum / sum-of-squares partials for the next GroupNorm.
+//                           per-(b,c,tile) sum / sum-of-squares partials for the next GroupNorm
+//                           (butterfly reduce-scatter over the 32 pixel lanes: 62 cross-lane moves per wave).
 //
 // f32 MFMA is an exact k-ordered fp32 fma chain (MI355X_MICROARCH.md), i.e. same numerics class as the
 // reference's fp32 cuDNN/ATen convs; roofline for this kernel = 157.3 TFLOP/s (f32 matrix peak).
@@ -46,10 +47,9 @@ struct ConvArgs {
     unsigned total_wg;
 };
 
-constexpr int BM = 64;
-
-template <int KS, int CK, int TWL, int MODE, bool VECW>
+template <int KS, int CK, int TWL, int MODE, bool VECW, int MB>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+    constexpr int BM = 32 * MB;
     constexpr int TW = 1 << TWL;
     constexpr int TH = 256 / TW;
     constexpr int PAD = KS / 2;
@@ -62,8 +62,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int BUF = IN_TILE + W_TILE;
     constexpr int NL = (CK * PS + 255) / 256;
     constexpr int NW = VECW ? (W_TILE / 4 + 255) / 256 : (W_TILE + 255) / 256;
+    constexpr int NS = TAPS * (CK / 2);  // k-steps (of 2) per chunk
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* protab = smem + 2 * BUF;  // [2][C0r] GroupNorm/FiLM affine of this sample (only when pro_a)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -80,6 +82,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const int x0 = (tile % a.tiles_x) * TW;
 
     const int HWin = a.Hin * a.Win;
+    const bool has_pro = a.pro_a != nullptr;
 
     // ---- per-thread gather descriptors (constant across chunks) ---------------------------------
     int goff[NL];
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         const int c = rem - r * RS;
         const int oy = y0 - PAD + r;
         const int ox = x0 - PAD + c;
-        bool v = (e < CK * PS) && oy >= 0 && oy < a.Hout && ox >= 0 && ox < a.Wout;
+        const bool v = (e < CK * PS) && oy >= 0 && oy < a.Hout && ox >= 0 && ox < a.Wout;
         int off;
         if (MODE == IDIFF_CONV_UPSAMPLE2) {
             off = ci * HWin + (oy >> 1) * a.Win + (ox >> 1);
@@ -106,91 +109,107 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         gval[i] = v;
     }
 
+    if (has_pro) {
+        for (int i = tid; i < a.C0r; i += 256) {
+            protab[i] = a.pro_a[(long long)b * a.C0r + i];
+            protab[a.C0r + i] = a.pro_b[(long long)b * a.C0r + i];
+        }
+    }
+
     float rin[NL];
     floatx4 rwv[VECW ? NW : 1];
     float rws[VECW ? 1 : NW];
 
     const int nchunks = (a.Cin + CK - 1) / CK;
+    const float* const sample0 = a.src0 + (long long)b * a.bs0;  // always-valid address for masked lanes
 
+    // issue the global loads of chunk cc (no dependent arithmetic here: the MFMAs of the current chunk run
+    // while these are in flight).  Masked elements load a valid dummy address and are zeroed at write time.
     auto load_regs = [&](int cc) {
         const int cb = cc * CK;
-        // virtual channel cb+ci comes from src0 while < C0v, else from src1 (a chunk may straddle the seam);
-        // goff[] already contains ci*HWin, so both bases are offset by the chunk's first channel.
-        const float* base0 = a.src0 + (long long)b * a.bs0 + (long long)(MODE == IDIFF_CONV_UNSHUFFLE2 ? (cb >> 2) : cb) * HWin;
-        const float* base1 = a.src1 ? a.src1 + (long long)b * a.bs1 + (long long)(cb - a.C0v) * HWin : nullptr;
-        const float* pa = a.pro_a ? a.pro_a + (long long)b * a.C0r : nullptr;
-        const float* pb = a.pro_a ? a.pro_b + (long long)b * a.C0r : nullptr;
+        const float* base0 = sample0 + (long long)(MODE == IDIFF_CONV_UNSHUFFLE2 ? (cb >> 2) : cb) * HWin;
+        const float* base1 = a.src1 ? a.src1 + (long long)b * a.bs1 + (long long)(cb - a.C0v) * HWin : sample0;
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             const int e = tid + i * 256;
-            const int ci = e / PS;
-            const int ch = cb + ci;
+            const int ch = cb + e / PS;
             const bool v = gval[i] && ch < a.Cin;
-            float x = 0.f;
-            if (v) {
-                x = (ch < a.C0v ? base0 : base1)[goff[i]];
-                if (pa) {
-                    const int chr = MODE == IDIFF_CONV_UNSHUFFLE2 ? (ch >> 2) : ch;
-                    x = silu_f(pa[chr] * x + pb[chr]);
-                }
-            }
-            rin[i] = x;
+            const float* p = v ? (ch < a.C0v ? base0 : base1) + goff[i] : sample0;
+            rin[i] = *p;
         }
         if (VECW) {
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
                 const int f = tid + i * 256;
-                const int row = f >> 4;  // (tap, ci)
-                const int c4 = f & 15;
+                const int row = f / (BM / 4);  // (tap, ci)
+                const int c4 = f - row * (BM / 4);
                 const int tap = row / CK;
                 const int ci = row - tap * CK;
-                floatx4 w = {0.f, 0.f, 0.f, 0.f};
-                if (f < W_TILE / 4 && cb + ci < a.Cin)
-                    w = *reinterpret_cast<const floatx4*>(a.wpk + ((long long)tap * a.Cin + cb + ci) * a.Cout + co0 + c4 * 4);
-                rwv[i] = w;
+                const bool v = f < W_TILE / 4 && cb + ci < a.Cin;
+                const float* p = v ? a.wpk + ((long long)tap * a.Cin + cb + ci) * a.Cout + co0 + c4 * 4 : a.wpk;
+                rwv[i] = *reinterpret_cast<const floatx4*>(p);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
                 const int f = tid + i * 256;
-                const int row = f >> 6;
-                const int col = f & 63;
+                const int row = f / BM;
+                const int col = f - row * BM;
                 const int tap = row / CK;
                 const int ci = row - tap * CK;
-                float w = 0.f;
-                if (f < W_TILE && cb + ci < a.Cin && co0 + col < a.Cout)
-                    w = a.wpk[((long long)tap * a.Cin + cb + ci) * a.Cout + co0 + col];
-                rws[i] = w;
+                const bool v = f < W_TILE && cb + ci < a.Cin && co0 + col < a.Cout;
+                const float* p = v ? a.wpk + ((long long)tap * a.Cin + cb + ci) * a.Cout + co0 + col : a.wpk;
+                rws[i] = *p;
             }
         }
     };
 
-    auto write_lds = [&](int buf) {
+    // activation (GroupNorm/FiLM affine + SiLU of the producer) + zero padding + LDS write of chunk cc
+    auto write_lds = [&](int cc, int buf) {
+        const int cb = cc * CK;
         float* ib = smem + buf * BUF;
         float* wb = ib + IN_TILE;
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             const int e = tid + i * 256;
-            if (e < CK * PS) ib[e] = rin[i];
+            const int ch = cb + e / PS;
+            const bool v = gval[i] && ch < a.Cin;
+            float x = rin[i];
+            if (has_pro) {
+                const int chr = MODE == IDIFF_CONV_UNSHUFFLE2 ? (ch >> 2) : ch;
+                const int chc = chr < a.C0r ? chr : 0;
+                x = silu_fast(protab[chc] * x + protab[a.C0r + chc]);
+            }
+            if (e < CK * PS) ib[e] = v ? x : 0.f;
         }
         if (VECW) {
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
                 const int f = tid + i * 256;
-                if (f < W_TILE / 4) *reinterpret_cast<floatx4*>(wb + f * 4) = rwv[i];
+                const int row = f / (BM / 4);
+                const int tap = row / CK;
+                const int ci = row - tap * CK;
+                floatx4 w = rwv[i];
+                if (!(cb + ci < a.Cin)) w = floatx4{0.f, 0.f, 0.f, 0.f};
+                if (f < W_TILE / 4) *reinterpret_cast<floatx4*>(wb + f * 4) = w;
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
                 const int f = tid + i * 256;
-                if (f < W_TILE) wb[f] = rws[i];
+                const int row = f / BM;
+                const int col = f - row * BM;
+                const int tap = row / CK;
+                const int ci = row - tap * CK;
+                const bool v = cb + ci < a.Cin && co0 + col < a.Cout;
+                if (f < W_TILE) wb[f] = v ? rws[i] : 0.f;
             }
         }
     };
 
-    floatx16 acc[2][2];
+    floatx16 acc[MB][2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -205,7 +224,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     }
 
     load_regs(0);
-    write_lds(0);
+    if (has_pro) __syncthreads();  // protab visible
+    write_lds(0, 0);
     __syncthreads();
 
     for (int cc = 0; cc < nchunks; ++cc) {
@@ -216,22 +236,34 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         const float* wl = ib + IN_TILE + half * BM + l31;
         const float* il0 = ib + half * PS + pixoff[0];
         const float* il1 = ib + half * PS + pixoff[1];
+        // k-step s covers channels (2cp, 2cp+1) of tap: A rows 2s, 2s+1 of the [tap][ci] weight image
+        float an[MB], bn0, bn1;
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int ky = tap / KS, kx = tap % KS;
+        for (int m = 0; m < MB; ++m) an[m] = wl[m * 32];
+        bn0 = il0[0];
+        bn1 = il1[0];
 #pragma unroll
-            for (int cp = 0; cp < CK / 2; ++cp) {
-                const float a0 = wl[(tap * CK + 2 * cp) * BM];
-                const float a1 = wl[(tap * CK + 2 * cp) * BM + 32];
-                const float b0 = il0[2 * cp * PS + ky * RS + kx];
-                const float b1 = il1[2 * cp * PS + ky * RS + kx];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int s = 0; s < NS; ++s) {
+            float ac[MB];
+#pragma unroll
+            for (int m = 0; m < MB; ++m) ac[m] = an[m];
+            const float b0 = bn0, b1 = bn1;
+            if (s + 1 < NS) {  // operands of the next k-step are requested before this step's MFMAs issue
+                const int s1 = s + 1;
+                const int tap = s1 / (CK / 2), cp = s1 % (CK / 2);
+                const int ky = tap / KS, kx = tap % KS;
+#pragma unroll
+                for (int m = 0; m < MB; ++m) an[m] = wl[2 * s1 * BM + m * 32];
+                bn0 = il0[2 * cp * PS + ky * RS + kx];
+                bn1 = il1[2 * cp * PS + ky * RS + kx];
+            }
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[m], b0, acc[m][0], 0, 0, 0);
+                acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[m], b1, acc[m][1], 0, 0, 0);
             }
         }
-        if (cc + 1 < nchunks) write_lds(buf ^ 1);
+        if (cc + 1 < nchunks) write_lds(cc + 1, buf ^ 1);
         __syncthreads();
     }
 
@@ -249,10 +281,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     float* outb = a.out + (long long)b * a.obs;
     const float* resb = a.res ? a.res + (long long)b * a.rbs : nullptr;
     const float* auxb = a.aux ? a.aux + (long long)b * a.abs_ : nullptr;
-    float* red = smem;  // [4 waves][64 co][2]
+    float* red = smem;  // [4 waves][BM co][2]
+    const bool want_stats = a.stats != nullptr;
 
+    float sv[MB * 32];  // per (mb, r): {sum, sumsq} over this lane's two pixels
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
+    for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int col = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -277,61 +311,92 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                     const long long o = (long long)co * HWo + opix[nb];
                     v += add;
                     if (resb) v += resb[o];
-                    if (auxb) v += silu_f(aa * auxb[o] + ab);
+                    if (auxb) v += silu_fast(aa * auxb[o] + ab);
                     outb[o] = v;
                 }
             }
-            if (a.stats) {
-                s = half_sum(s);
-                q = half_sum(q);
-                if (l31 == 0) {
-                    red[(wave * 64 + col) * 2 + 0] = s;
-                    red[(wave * 64 + col) * 2 + 1] = q;
+            sv[(mb * 16 + r) * 2 + 0] = s;
+            sv[(mb * 16 + r) * 2 + 1] = q;
+        }
+    }
+    if (want_stats) {
+        // butterfly reduce-scatter over the 32 lanes of each half-wave: after the step with mask m a lane keeps
+        // the half of its values selected by its bit m; lane l31 ends with the totals of (mb, r) = (l31>>4, l31&15).
+        constexpr int NV = MB * 32;
+#pragma unroll
+        for (int step = 0; step < 5; ++step) {
+            const int m = 16 >> step;
+            const int n = NV >> (step + 1);  // values kept after this step
+            if (n >= 1) {
+                const bool up = (l31 & m) != 0;
+#pragma unroll
+                for (int j = 0; j < n; ++j) {
+                    const float lo = sv[j], hi = sv[j + n];
+                    const float send = up ? lo : hi;
+                    const float keep = up ? hi : lo;
+                    sv[j] = keep + __shfl_xor(send, m, 64);
                 }
             }
         }
-    }
-    if (a.stats) {
+        // NV = 64: 2 values/lane (sum, sumsq) for (mb, r) = (l31>>4, l31&15).  NV = 32: after 4 steps 2 values for
+        // r = l31>>1 ... handled by the generic index below (the last step with n = 1 leaves 1 value).
+        if (MB == 2) {
+            const int mbq = l31 >> 4, r = l31 & 15;
+            const int col = mbq * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            red[(wave * BM + col) * 2 + 0] = sv[0];
+            red[(wave * BM + col) * 2 + 1] = sv[1];
+        } else {
+            // NV = 32 -> after 5 steps one value per lane: index j = l31  (= r*2 + w)
+            const int r = l31 >> 1, w = l31 & 1;
+            const int col = (r & 3) + 8 * (r >> 2) + 4 * half;
+            red[(wave * BM + col) * 2 + w] = sv[0];
+        }
         __syncthreads();
-        if (tid < 128) {
+        if (tid < BM * 2) {
             const int col = tid >> 1, w = tid & 1;
             const int co = co0 + col;
             if (co < a.Cout) {
-                const float t = red[(0 * 64 + col) * 2 + w] + red[(1 * 64 + col) * 2 + w] + red[(2 * 64 + col) * 2 + w] +
-                                red[(3 * 64 + col) * 2 + w];
+                const float t = red[(0 * BM + col) * 2 + w] + red[(1 * BM + col) * 2 + w] + red[(2 * BM + col) * 2 + w] +
+                                red[(3 * BM + col) * 2 + w];
                 a.stats[(((long long)b * a.ntiles + tile) * a.Cout + co) * 2 + w] = t;
             }
         }
     }
 }
 
-template <int KS, int CK, int TWL, int MODE, bool VECW>
+template <int KS, int CK, int TWL, int MODE, bool VECW, int MB>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
+    constexpr int BM = 32 * MB;
     constexpr int TW = 1 << TWL;
     constexpr int TH = 256 / TW;
     constexpr int TRH = TH + KS - 1;
     constexpr int RS = TW + KS - 1;
     constexpr int IN_TILE = ((CK * TRH * RS + 3) / 4) * 4;
     constexpr int W_TILE = KS * KS * CK * BM;
-    constexpr size_t lds = (size_t)2 * (IN_TILE + W_TILE) * sizeof(float);
-    static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    auto kern = conv_igemm_kernel<KS, CK, TWL, MODE, VECW>;
-    if (!attr_set) {
+    const size_t lds = ((size_t)2 * (IN_TILE + W_TILE) + (a.pro_a ? 2 * (size_t)a.C0r : 0)) * sizeof(float);
+    if (lds > 160 * 1024) IDIFF_FAIL(IDIFF_E_UNSUPPORTED, "conv2d: LDS budget exceeded (%zu bytes)", lds);
+    static size_t attr_set = 0;
+    auto kern = conv_igemm_kernel<KS, CK, TWL, MODE, VECW, MB>;
+    if (lds > attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "conv2d: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
+        attr_set = lds;
     }
     hipLaunchKernelGGL(kern, dim3(a.total_wg), dim3(256), lds, st, a);
     IDIFF_CHECK_LAUNCH("conv2d_fwd");
     return IDIFF_OK;
 }
 
-template <int KS, int CK, int MODE>
+template <int KS, int CK, int MODE, int MB>
 int dispatch_tw(const ConvArgs& a, int twl, bool vecw, hipStream_t st) {
-    if (twl == 5) return vecw ? launch_conv<KS, CK, 5, MODE, true>(a, st) : launch_conv<KS, CK, 5, MODE, false>(a, st);
-    if (twl == 4) return vecw ? launch_conv<KS, CK, 4, MODE, true>(a, st) : launch_conv<KS, CK, 4, MODE, false>(a, st);
-    return vecw ? launch_conv<KS, CK, 3, MODE, true>(a, st) : launch_conv<KS, CK, 3, MODE, false>(a, st);
+    if (twl == 5) return vecw ? launch_conv<KS, CK, 5, MODE, true, MB>(a, st) : launch_conv<KS, CK, 5, MODE, false, MB>(a, st);
+    if (twl == 4) return vecw ? launch_conv<KS, CK, 4, MODE, true, MB>(a, st) : launch_conv<KS, CK, 4, MODE, false, MB>(a, st);
+    return vecw ? launch_conv<KS, CK, 3, MODE, true, MB>(a, st) : launch_conv<KS, CK, 3, MODE, false, MB>(a, st);
+}
+
+template <int KS, int CK, int MODE>
+int dispatch_mb(const ConvArgs& a, int twl, int mb, bool vecw, hipStream_t st) {
+    return mb == 2 ? dispatch_tw<KS, CK, MODE, 2>(a, twl, vecw, st) : dispatch_tw<KS, CK, MODE, 1>(a, twl, vecw, st);
 }
 
 inline int pick_twl(int Wout) { return Wout >= 32 ? 5 : (Wout >= 16 ? 4 : 3); }
@@ -396,7 +461,6 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
     a.aux_a = d->aux_a;
     a.aux_b = d->aux_b;
     a.stats = d->stats;
-    int ck;
     if (d->mode == IDIFF_CONV_UNSHUFFLE2) {
         IDIFF_CHECK_ARG(d->ks == 1 && d->C1 == 0, "conv2d: unshuffle mode needs ks=1 and a single source");
         IDIFF_CHECK_ARG(d->Hin % 2 == 0 && d->Win % 2 == 0, "conv2d: unshuffle needs even H, W");
@@ -416,32 +480,32 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
         a.Wout = d->Win;
     }
     a.Cin = a.C0v + a.C1v;
-    ck = d->ks == 3 ? 8 : (d->ks == 1 ? 16 : 2);
-    (void)ck;
     IDIFF_CHECK_ARG(a.bs0 >= (long long)d->C0 * d->Hin * d->Win, "conv2d: src0_bstride too small");
     IDIFF_CHECK_ARG(d->C1 == 0 || a.bs1 >= (long long)d->C1 * d->Hin * d->Win, "conv2d: src1_bstride too small");
     IDIFF_CHECK_ARG(a.obs >= (long long)d->Cout * a.Hout * a.Wout, "conv2d: out_bstride too small");
     const int twl = pick_twl(a.Wout);
     const int TW = 1 << twl, TH = 256 / TW;
+    const int mb = a.Cout <= 32 ? 1 : 2;
+    const int bm = 32 * mb;
     a.tiles_x = (a.Wout + TW - 1) / TW;
     a.ntiles = a.tiles_x * ((a.Hout + TH - 1) / TH);
-    a.ncob = (a.Cout + BM - 1) / BM;
+    a.ncob = (a.Cout + bm - 1) / bm;
     const long long total = (long long)a.B * a.ntiles * a.ncob;
     IDIFF_CHECK_ARG(total < (1ll << 31), "conv2d: grid too large");
     a.total_wg = (unsigned)total;
-    const bool vecw = (a.Cout % BM == 0) && ((reinterpret_cast<uintptr_t>(a.wpk) & 15) == 0);
+    const bool vecw = (a.Cout % bm == 0) && ((reinterpret_cast<uintptr_t>(a.wpk) & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
     if (d->ks == 3) {
-        if (d->mode == IDIFF_CONV_NORMAL) return dispatch_tw<3, 8, IDIFF_CONV_NORMAL>(a, twl, vecw, st);
-        return dispatch_tw<3, 8, IDIFF_CONV_UPSAMPLE2>(a, twl, vecw, st);
+        if (d->mode == IDIFF_CONV_NORMAL) return dispatch_mb<3, 8, IDIFF_CONV_NORMAL>(a, twl, mb, vecw, st);
+        return dispatch_mb<3, 8, IDIFF_CONV_UPSAMPLE2>(a, twl, mb, vecw, st);
     }
     if (d->ks == 1) {
         IDIFF_CHECK_ARG(d->mode != IDIFF_CONV_UPSAMPLE2, "conv2d: upsample mode needs ks=3");
-        if (d->mode == IDIFF_CONV_NORMAL) return dispatch_tw<1, 16, IDIFF_CONV_NORMAL>(a, twl, vecw, st);
-        return dispatch_tw<1, 16, IDIFF_CONV_UNSHUFFLE2>(a, twl, vecw, st);
+        if (d->mode == IDIFF_CONV_NORMAL) return dispatch_mb<1, 16, IDIFF_CONV_NORMAL>(a, twl, mb, vecw, st);
+        return dispatch_mb<1, 16, IDIFF_CONV_UNSHUFFLE2>(a, twl, mb, vecw, st);
     }
     IDIFF_CHECK_ARG(d->mode == IDIFF_CONV_NORMAL, "conv2d: ks=7 needs normal mode");
-    return dispatch_tw<7, 2, IDIFF_CONV_NORMAL>(a, twl, vecw, st);
+    return dispatch_mb<7, 2, IDIFF_CONV_NORMAL>(a, twl, mb, vecw, st);
 }
 
 static int pack_common(const float* w, float* wpk, int Cout, int Cin, int ks, int tr, idiff_stream_t stream) {
