@@ -113,6 +113,17 @@ int idiff_affine_silu_add(const float* h, int64_t h_bstride, const float* a, con
 int idiff_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* res,
                      int64_t ldr, const float* gscale, float* out, int64_t ldo, int R, int K, int N, int act_in,
                      int act_out, idiff_stream_t stream);
+/* same contract with a PRE-TRANSPOSED weight wT [K, N] (row stride ldw): lane = output feature, unit-stride weight
+ * reads, no cross-lane reduction -- the low-latency form used for the ScoreMapModule token chain. */
+int idiff_linear_t_fwd(const float* x, int64_t ldx, const float* wT, int64_t ldw, const float* bias, const float* res,
+                       int64_t ldr, const float* gscale, float* out, int64_t ldo, int R, int K, int N, int act_in,
+                       int act_out, idiff_stream_t stream);
+/* ScoreMapModule memory projection fused in one pass (ContextDecoder.memory_proj, _modified_BiomedCLIP.py:1205-1209):
+ * out[b,:,p] = LayerNorm_256( wpk^T . LayerNorm_C(feat[b,:,p]) + bias );  feat [B,C,N] (feat_bstride), wpk [C][256]
+ * (idiff_pack_conv_weight of the [256,C,1,1] view), out [B,256,N]. */
+int idiff_smm_memproj_fwd(const float* feat, int64_t feat_bstride, const float* ln1_g, const float* ln1_b,
+                          const float* wpk, const float* bias, const float* ln2_g, const float* ln2_b, float* out, int B,
+                          int C, int N, float eps, idiff_stream_t stream);
 int idiff_layernorm_rows_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out,
                              int64_t ldo, int R, int C, float eps, float* mean_rstd, idiff_stream_t stream);
 /* sinusoidal embedding, [sin | cos] halves; freqs [dim/2] = host-built table exp(-ln(1e4) * i/(half-1))
@@ -135,9 +146,10 @@ int idiff_attn_self_fwd(const float* qkv, float* out, float* lse, int B, int C, 
 /* pixels attend to M context tokens: q [B,C,N] channel-major, k,v [B,M,C] token-major, out [B,C,N]; M <= 32 */
 int idiff_attn_ctx_fwd(const float* q, const float* k, const float* v, float* out, int B, int C, int N, int M,
                        int heads, float scale, idiff_stream_t stream);
-/* tiny token-major attention (ScoreMapModule decoder self-attention): q [B,Nq,C], k,v [B,M,C]; Nq,M <= 64 */
+/* tiny token-major attention (ScoreMapModule decoder self-attention): q [B,Nq,C] (row stride ldq), k,v [B,M,C]
+ * (row stride ldkv) -- strides let q/k/v be slices of one packed qkv projection; out [B,Nq,C] dense; Nq,M <= 64 */
 int idiff_attn_tokens_fwd(const float* q, const float* k, const float* v, float* out, int B, int Nq, int M, int C,
-                          int heads, float scale, idiff_stream_t stream);
+                          int heads, float scale, int64_t ldq, int64_t ldkv, idiff_stream_t stream);
 /* ScoreMapModule cross-attention, K/V projections folded onto the query side:
  *   S[b,h,q,n] = scale * sum_c qf[b,q,h,c] * mem[b,c,n];  P = softmax_n(S);  o[b,q,h,c] = sum_n P * mem[b,c,n]
  * qf, o: [B, Nq, heads, Cm];  mem: [B, Cm, N] channel-major;  Nq*heads <= 32, Cm % 32 == 0.

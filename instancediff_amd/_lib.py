@@ -46,12 +46,14 @@ SIGNATURES = {
     "idiff_gn_finalize": (I, [P, I, I, I, I, I, P, P, P, I64, F, P, P, P, c_stream]),
     "idiff_affine_silu_add": (I, [P, I64, P, P, P, I64, P, P, I64, I, I, I, c_stream]),
     "idiff_linear_fwd": (I, [P, I64, P, I64, P, P, I64, P, P, I64, I, I, I, I, I, c_stream]),
+    "idiff_linear_t_fwd": (I, [P, I64, P, I64, P, P, I64, P, P, I64, I, I, I, I, I, c_stream]),
+    "idiff_smm_memproj_fwd": (I, [P, I64, P, P, P, P, P, P, P, I, I, I, F, c_stream]),
     "idiff_layernorm_rows_fwd": (I, [P, I64, P, P, P, I64, I, I, F, P, c_stream]),
     "idiff_time_embed_fwd": (I, [P, P, I, I, P, c_stream]),
     "idiff_chan_layernorm_fwd": (I, [P, I64, P, P, P, I64, I, I, I, F, P, c_stream]),
     "idiff_attn_self_fwd": (I, [P, P, P, I, I, I, I, F, c_stream]),
     "idiff_attn_ctx_fwd": (I, [P, P, P, P, I, I, I, I, I, F, c_stream]),
-    "idiff_attn_tokens_fwd": (I, [P, P, P, P, I, I, I, I, I, F, c_stream]),
+    "idiff_attn_tokens_fwd": (I, [P, P, P, P, I, I, I, I, I, F, I64, I64, c_stream]),
     "idiff_smm_xattn_ws_floats": (I64, [I, I, I, I, I]),
     "idiff_smm_xattn_fwd": (I, [P, P, P, P, I, I, I, I, I, F, c_stream]),
     "idiff_scoremap_fwd": (I, [P, I64, P, P, P, P, I, I, I, I, c_stream]),

@@ -188,14 +188,15 @@ __global__ __launch_bounds__(256) void attn_ctx_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------------
 // one wave per (b, head, query); lanes = keys
 __global__ __launch_bounds__(64) void attn_tokens_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-                                                         float* __restrict__ out, int Nq, int M, int C, int heads, float scale) {
+                                                         float* __restrict__ out, int Nq, int M, int C, int heads, float scale, long long ldq,
+                                                         long long ldkv) {
     const int dh = C / heads;
     const int n = blockIdx.x % Nq, h = (blockIdx.x / Nq) % heads, b = blockIdx.x / (Nq * heads);
     const int lane = threadIdx.x;
-    const float* qp = q + ((long long)b * Nq + n) * C + h * dh;
+    const float* qp = q + ((long long)b * Nq + n) * ldq + h * dh;
     float s = -INFINITY;
     if (lane < M) {
-        const float* kp = k + ((long long)b * M + lane) * C + h * dh;
+        const float* kp = k + ((long long)b * M + lane) * ldkv + h * dh;
         float acc = 0.f;
         for (int d = 0; d < dh; ++d) acc += qp[d] * kp[d];
         s = acc * scale;
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(64) void attn_tokens_kernel(const float* __restrict
     const float pn = p / l;
     float* op = out + ((long long)b * Nq + n) * C + h * dh;
     for (int d = 0; d < dh; ++d) {
-        const float t = wave_sum(lane < M ? pn * v[((long long)b * M + lane) * C + h * dh + d] : 0.f);
+        const float t = wave_sum(lane < M ? pn * v[((long long)b * M + lane) * ldkv + h * dh + d] : 0.f);
         if (lane == 0) op[d] = t;
     }
 }
@@ -398,10 +399,12 @@ extern "C" int idiff_attn_ctx_fwd(const float* q, const float* k, const float* v
 }
 
 extern "C" int idiff_attn_tokens_fwd(const float* q, const float* k, const float* v, float* out, int B, int Nq, int M, int C, int heads,
-                                     float scale, idiff_stream_t stream) {
+                                     float scale, int64_t ldq, int64_t ldkv, idiff_stream_t stream) {
     IDIFF_CHECK_ARG(q && k && v && out && B > 0 && Nq > 0 && C > 0 && heads > 0 && C % heads == 0, "attn_tokens: bad args");
     IDIFF_CHECK_ARG(M >= 1 && M <= 64, "attn_tokens: M must be in 1..64 (got %d)", M);
-    hipLaunchKernelGGL(attn_tokens_kernel, dim3(B * heads * Nq), dim3(64), 0, (hipStream_t)stream, q, k, v, out, Nq, M, C, heads, scale);
+    IDIFF_CHECK_ARG(ldq >= C && ldkv >= C, "attn_tokens: row strides must be >= C");
+    hipLaunchKernelGGL(attn_tokens_kernel, dim3(B * heads * Nq), dim3(64), 0, (hipStream_t)stream, q, k, v, out, Nq, M, C, heads, scale,
+                       (long long)ldq, (long long)ldkv);
     IDIFF_CHECK_LAUNCH("attn_tokens_fwd");
     return IDIFF_OK;
 }

@@ -16,6 +16,8 @@
 //
 // f32 MFMA is an exact k-ordered fp32 fma chain (MI355X_MICROARCH.md), i.e. same numerics class as the
 // reference's fp32 cuDNN/ATen convs; roofline for this kernel = 157.3 TFLOP/s (f32 matrix peak).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -262,6 +264,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                 acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[m], b0, acc[m][0], 0, 0, 0);
                 acc[m][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[m], b1, acc[m][1], 0, 0, 0);
             }
+            // pin the software pipeline: the LDS reads of k-step s+1 issue ahead of the MFMAs of k-step s, so
+            // their latency hides under 2*MB*64 cycles of matrix work (hipcc otherwise sinks each read to its use).
+            __builtin_amdgcn_sched_group_barrier(0x100, MB + 2, 0);   // DS reads (next step)
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * MB, 0);   // MFMAs (this step)
         }
         if (cc + 1 < nchunks) write_lds(cc + 1, buf ^ 1);
         __syncthreads();

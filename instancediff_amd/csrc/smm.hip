@@ -1,0 +1,253 @@
+// ScoreMapModule memory projection, fused:  mem = LayerNorm_256( Linear_{C->256}( LayerNorm_C(feature tokens) ) )
+// (ContextDecoder.memory_proj, models/_modified_BiomedCLIP.py:1205-1209) on a channel-major feature map.
+//
+// One workgroup = 64 pixels x all 256 output channels.  The [C][64] input tile is loaded once into LDS
+// (coalesced 256-byte rows), normalised in place (per-pixel two-pass statistics, lanes = pixels), multiplied by
+// the packed weight [C][256] on v_mfma_f32_32x32x2_f32 (wave w owns output channels 64w..64w+63, A operand
+// streamed from L2 with unit stride along co, B operand from LDS with unit stride along pixels), then the
+// second LayerNorm runs on the accumulators (per-pixel sums across the 4 waves through LDS).
+// HBM traffic = read C*4 B + write 1 KB per pixel (the unfused chain made 3 extra passes over the 1 KB/pixel map).
+#include "common.h"
+
+namespace {
+
+constexpr int MP_W = 256;   // decoder width
+constexpr int MP_PX = 64;   // pixels per workgroup
+
+__global__ __launch_bounds__(256) void smm_memproj_kernel(const float* __restrict__ feat, long long fbs, const float* __restrict__ g1,
+                                                          const float* __restrict__ b1, const float* __restrict__ wpk,
+                                                          const float* __restrict__ bias, const float* __restrict__ g2,
+                                                          const float* __restrict__ b2, float* __restrict__ out, int C, int N, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xt = smem;                 // [C][64]
+    float* part = smem + C * MP_PX;   // [4][64]
+    float* stat = part + 4 * MP_PX;   // [2][64] mean, rstd
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * MP_PX;
+    const float* fb = feat + (long long)b * fbs;
+
+    // ---- load the [C][64] tile ------------------------------------------------------------------
+    const int nf4 = C * (MP_PX / 4);
+    for (int f = tid; f < nf4; f += 256) {
+        const int c = f >> 4, j4 = (f & 15) * 4;
+        floatx4 v = {0.f, 0.f, 0.f, 0.f};
+        if (p0 + j4 + 3 < N)
+            v = *reinterpret_cast<const floatx4*>(fb + (long long)c * N + p0 + j4);
+        else
+            for (int e = 0; e < 4; ++e)
+                if (p0 + j4 + e < N) v[e] = fb[(long long)c * N + p0 + j4 + e];
+        *reinterpret_cast<floatx4*>(xt + c * MP_PX + j4) = v;
+    }
+    __syncthreads();
+    // ---- LayerNorm over C per pixel: wave q covers channels q, q+4, ... ; lane = pixel -----------
+    float s = 0.f;
+    for (int c = wave; c < C; c += 4) s += xt[c * MP_PX + lane];
+    part[wave * MP_PX + lane] = s;
+    __syncthreads();
+    const float mean1 = (part[lane] + part[MP_PX + lane] + part[2 * MP_PX + lane] + part[3 * MP_PX + lane]) / (float)C;
+    __syncthreads();
+    float q = 0.f;
+    for (int c = wave; c < C; c += 4) {
+        const float d = xt[c * MP_PX + lane] - mean1;
+        q += d * d;
+    }
+    part[wave * MP_PX + lane] = q;
+    __syncthreads();
+    const float rstd1 = rsqrtf((part[lane] + part[MP_PX + lane] + part[2 * MP_PX + lane] + part[3 * MP_PX + lane]) / (float)C + eps);
+    for (int c = wave; c < C; c += 4) xt[c * MP_PX + lane] = (xt[c * MP_PX + lane] - mean1) * rstd1 * g1[c] + b1[c];
+    __syncthreads();
+
+    // ---- GEMM: out[co][p] = sum_c W[c][co] * xhat[c][p] -----------------------------------------------
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    const float* wl = wpk + (long long)half * MP_W + wave * 64 + l31;
+    const float* xl = xt + half * MP_PX + l31;
+    const int nsteps = C / 2;
+#pragma unroll 4
+    for (int st = 0; st < nsteps; ++st) {
+        const float a0 = wl[(long long)(2 * st) * MP_W];
+        const float a1 = wl[(long long)(2 * st) * MP_W + 32];
+        const float x0 = xl[2 * st * MP_PX];
+        const float x1 = xl[2 * st * MP_PX + 32];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, x0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, x1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, x0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, x1, acc[1][1], 0, 0, 0);
+    }
+    // ---- + bias, LayerNorm over the 256 output channels per pixel ------------------------------------
+    float bv[2][16], gv[2][16], ov[2][16];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = wave * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            bv[m][r] = bias[co];
+            gv[m][r] = g2[co];
+            ov[m][r] = b2[co];
+        }
+    float ps[2] = {0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[m][n][r] += bv[m][r];
+                ps[n] += acc[m][n][r];
+            }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        ps[n] += __shfl_xor(ps[n], 32, 64);
+        if (half == 0) part[wave * MP_PX + n * 32 + l31] = ps[n];
+    }
+    __syncthreads();
+    float mean2[2], rstd2[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int p = n * 32 + l31;
+        mean2[n] = (part[p] + part[MP_PX + p] + part[2 * MP_PX + p] + part[3 * MP_PX + p]) / (float)MP_W;
+    }
+    __syncthreads();
+    float pq[2] = {0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float d = acc[m][n][r] - mean2[n];
+                pq[n] += d * d;
+            }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        pq[n] += __shfl_xor(pq[n], 32, 64);
+        if (half == 0) part[wave * MP_PX + n * 32 + l31] = pq[n];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int p = n * 32 + l31;
+        rstd2[n] = rsqrtf((part[p] + part[MP_PX + p] + part[2 * MP_PX + p] + part[3 * MP_PX + p]) / (float)MP_W + eps);
+    }
+    float* ob = out + (long long)b * MP_W * N;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int p = p0 + n * 32 + l31;
+        if (p < N) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = wave * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    ob[(long long)co * N + p] = (acc[m][n][r] - mean2[n]) * rstd2[n] * gv[m][r] + ov[m][r];
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Token-side Linear with a pre-transposed weight wT [K][N]: lane = output feature (unit-stride weight reads, no
+// cross-lane reduction), 8 rows per workgroup, the 4 waves split K and combine through LDS.
+// out[r,n] = res[r,n] + gscale[n] * (sum_k act_in(x[r,k]) * wT[k,n] + bias[n]), then act_out.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_apply_t(float v, int act) {
+    if (act == IDIFF_ACT_SILU) return silu_f(v);
+    if (act == IDIFF_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    return v;
+}
+
+constexpr int LT_ROWS = 8;
+__global__ __launch_bounds__(256) void linear_t_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ wT, long long ldw,
+                                                       const float* __restrict__ bias, const float* __restrict__ res, long long ldr,
+                                                       const float* __restrict__ gscale, float* __restrict__ out, long long ldo, int R, int K,
+                                                       int N, int act_in, int act_out) {
+    extern __shared__ __attribute__((aligned(16))) float lt_smem[];
+    float* xs = lt_smem;                                             // [LT_ROWS][K] activated input rows
+    float(*red)[LT_ROWS][64] = reinterpret_cast<float(*)[LT_ROWS][64]>(lt_smem + LT_ROWS * K);  // [4][8][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * LT_ROWS;
+    for (int i = threadIdx.x; i < LT_ROWS * K; i += 256) {
+        const int r = i / K, k = i - r * K;
+        const int rr = r0 + r < R ? r0 + r : R - 1;
+        xs[i] = act_apply_t(x[(long long)rr * ldx + k], act_in);
+    }
+    __syncthreads();
+    const int kq = (K + 3) / 4;
+    const int k0 = wave * kq, k1 = min(K, k0 + kq);
+    float acc[LT_ROWS];
+#pragma unroll
+    for (int r = 0; r < LT_ROWS; ++r) acc[r] = 0.f;
+    const int nn = n < N ? n : N - 1;
+    const float* wp = wT + nn;
+#pragma unroll 8
+    for (int k = k0; k < k1; ++k) {
+        const float wv = wp[(long long)k * ldw];
+#pragma unroll
+        for (int r = 0; r < LT_ROWS; ++r) acc[r] += xs[r * K + k] * wv;  // LDS broadcast read
+    }
+#pragma unroll
+    for (int r = 0; r < LT_ROWS; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    // 8 rows x 64 features = 512 outputs, 2 per thread
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int o = threadIdx.x + i * 256;
+        const int r = o >> 6, l = o & 63;
+        const int nn2 = blockIdx.x * 64 + l;
+        if (r0 + r < R && nn2 < N) {
+            float v = red[0][r][l] + red[1][r][l] + red[2][r][l] + red[3][r][l];
+            v = (gscale ? gscale[nn2] : 1.f) * (v + (bias ? bias[nn2] : 0.f));
+            if (res) v += res[(long long)(r0 + r) * ldr + nn2];
+            out[(long long)(r0 + r) * ldo + nn2] = act_apply_t(v, act_out);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int idiff_smm_memproj_fwd(const float* feat, int64_t feat_bstride, const float* ln1_g, const float* ln1_b, const float* wpk,
+                                     const float* bias, const float* ln2_g, const float* ln2_b, float* out, int B, int C, int N, float eps,
+                                     idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(feat && ln1_g && ln1_b && wpk && bias && ln2_g && ln2_b && out, "smm_memproj: null pointer");
+    IDIFF_CHECK_ARG(B > 0 && N > 0 && C >= 2 && C % 2 == 0 && C <= 512, "smm_memproj: C must be even and <= 512 (got %d)", C);
+    IDIFF_CHECK_ARG(N % 4 == 0 && feat_bstride % 4 == 0, "smm_memproj: N and feat_bstride must be multiples of 4");
+    const size_t lds = (size_t)(C * MP_PX + 4 * MP_PX + 2 * MP_PX) * sizeof(float);
+    static size_t attr = 0;
+    if (lds > attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(smm_memproj_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "smm_memproj: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr = lds;
+    }
+    hipLaunchKernelGGL(smm_memproj_kernel, dim3((N + MP_PX - 1) / MP_PX, B), dim3(256), lds, (hipStream_t)stream, feat, (long long)feat_bstride,
+                       ln1_g, ln1_b, wpk, bias, ln2_g, ln2_b, out, C, N, eps);
+    IDIFF_CHECK_LAUNCH("smm_memproj_fwd");
+    return IDIFF_OK;
+}
+
+extern "C" int idiff_linear_t_fwd(const float* x, int64_t ldx, const float* wT, int64_t ldw, const float* bias, const float* res, int64_t ldr,
+                                  const float* gscale, float* out, int64_t ldo, int R, int K, int N, int act_in, int act_out,
+                                  idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(x && wT && out && R > 0 && K > 0 && N > 0, "linear_t_fwd: bad args");
+    IDIFF_CHECK_ARG(ldx >= K && ldw >= N && ldo >= N, "linear_t_fwd: bad leading dims");
+    IDIFF_CHECK_ARG(K <= 8192, "linear_t_fwd: K must be <= 8192 (got %d)", K);
+    dim3 grid((N + 63) / 64, (R + LT_ROWS - 1) / LT_ROWS);
+    const size_t lds = ((size_t)LT_ROWS * K + 4 * LT_ROWS * 64) * sizeof(float);
+    static size_t attr = 0;
+    if (lds > 64 * 1024 && lds > attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_t_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "linear_t_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr = lds;
+    }
+    hipLaunchKernelGGL(linear_t_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, (long long)ldx, wT, (long long)ldw, bias, res,
+                       (long long)ldr, gscale, out, (long long)ldo, R, K, N, act_in, act_out);
+    IDIFF_CHECK_LAUNCH("linear_t_fwd");
+    return IDIFF_OK;
+}

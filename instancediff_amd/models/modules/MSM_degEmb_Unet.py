@@ -61,6 +61,11 @@ def packed(conv):
     return _PREP.get(("pk", conv), (conv.weight,), lambda: ops.pack_conv_weight(conv.weight.detach().contiguous()))
 
 
+def wT(lin):
+    """cached transposed weight [K, N] of an nn.Linear (the low-latency token-side linear reads it unit-stride)."""
+    return _PREP.get(("wT", lin), (lin.weight,), lambda: lin.weight.detach().t().contiguous())
+
+
 # ---------------------------------------------------------------------------------------------------
 # parameter containers (attribute names == oracle/unet_ref.py)
 # ---------------------------------------------------------------------------------------------------
@@ -163,42 +168,40 @@ class ScoreMapModule(nn.Module):
         dh = Wd // heads
         text = self.text_embeddings(text_encoder, B)  # [B,K,text_dim]
         t2d = text.reshape(B * K, self.text_dim)
-        # memory = LN(Linear(LN(feature tokens)))  (channel-major: [B, Wd, h*w])
+        # memory = LN(Linear(LN(feature tokens))), one fused pass (channel-major: [B, Wd, h*w])
         mp = dec.memory_proj
-        fn = ops.chan_layernorm(feat, mp[0].weight, mp[0].bias)
         wmp = _PREP.get(("mp", mp[1]), (mp[1].weight,),
                         lambda: ops.pack_conv_weight(mp[1].weight.detach().reshape(Wd, C, 1, 1).contiguous()))
-        m1 = ops.conv2d(fn, wmp, mp[1].bias, 1, Wd)
-        mem = ops.chan_layernorm(m1, mp[2].weight, mp[2].bias).reshape(B, Wd, H * W)
+        mem = ops.smm_memproj(feat, mp[0].weight, mp[0].bias, wmp, mp[1].bias, mp[2].weight, mp[2].bias, eps=mp[0].eps)
         tp = dec.text_proj
-        x = ops.linear(ops.layernorm_rows(t2d, tp[0].weight, tp[0].bias), tp[1].weight, tp[1].bias)  # [B*K, Wd]
+        x = ops.linear_t(ops.layernorm_rows(t2d, tp[0].weight, tp[0].bias), wT(tp[1]), tp[1].bias)  # [B*K, Wd]
         for li, layer in enumerate(dec.decoder):
             sa, ca = layer.self_attn, layer.cross_attn
-            wqkv = _PREP.get(("qkv", sa), (sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight),
-                             lambda: torch.cat([sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight], 0).detach().contiguous())
+            wqkvT = _PREP.get(("qkvT", sa), (sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight),
+                              lambda: torch.cat([sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight], 0).detach().t().contiguous())
             n1 = ops.layernorm_rows(x, layer.norm1.weight, layer.norm1.bias)
-            qkv = ops.linear(n1, wqkv).reshape(B, K, 3, Wd)
-            a = ops.attn_tokens(qkv[:, :, 0].contiguous(), qkv[:, :, 1].contiguous(), qkv[:, :, 2].contiguous(), heads, sa.scale)
-            x = ops.linear(a.reshape(B * K, Wd), sa.proj.weight, sa.proj.bias, res=x)
-            # cross attention, k/v projections folded onto the (few) queries
+            qkv = ops.linear_t(n1, wqkvT).reshape(B, K, 3 * Wd)
+            a = ops.attn_tokens_packed(qkv, heads, sa.scale)
+            x = ops.linear_t(a.reshape(B * K, Wd), wT(sa.proj), sa.proj.bias, res=x)
+            # cross attention, k/v projections folded onto the (few) queries:
+            #   qf[:, h, :] = q_h @ Wk[h*dh:(h+1)*dh, :]   (Wk's row block IS the transposed-weight form [K=dh][N=Wd])
             n2 = ops.layernorm_rows(x, layer.norm2.weight, layer.norm2.bias)
-            qc = ops.linear(n2, ca.q_proj.weight)
-            wkT = _PREP.get(("wkT", ca), (ca.k_proj.weight,),
-                            lambda: [ca.k_proj.weight[h * dh:(h + 1) * dh].detach().t().contiguous() for h in range(heads)])
+            qc = ops.linear_t(n2, wT(ca.q_proj))
             qf = torch.empty((B * K, heads * Wd), device=feat.device, dtype=torch.float32)
             for h in range(heads):
-                ops.linear(qc[:, h * dh:(h + 1) * dh], wkT[h], out=qf[:, h * Wd:(h + 1) * Wd])
+                ops.linear_t(qc[:, h * dh:(h + 1) * dh], ca.k_proj.weight[h * dh:(h + 1) * dh], out=qf[:, h * Wd:(h + 1) * Wd])
             o = ops.smm_xattn(qf.reshape(B, K, heads, Wd), mem, ca.scale).reshape(B * K, heads * Wd)
+            wvT = wT(ca.v_proj)  # [Wd (c), Wd (n)]
             av = torch.empty((B * K, Wd), device=feat.device, dtype=torch.float32)
             for h in range(heads):
-                ops.linear(o[:, h * Wd:(h + 1) * Wd], ca.v_proj.weight[h * dh:(h + 1) * dh], out=av[:, h * dh:(h + 1) * dh])
-            x = ops.linear(av, ca.proj.weight, ca.proj.bias, res=x)
+                ops.linear_t(o[:, h * Wd:(h + 1) * Wd], wvT[:, h * dh:(h + 1) * dh], out=av[:, h * dh:(h + 1) * dh])
+            x = ops.linear_t(av, wT(ca.proj), ca.proj.bias, res=x)
             n3 = ops.layernorm_rows(x, layer.norm3.weight, layer.norm3.bias)
-            hm = ops.linear(n3, layer.mlp[0].weight, layer.mlp[0].bias, act_out=ops.ACT_GELU)
-            x = ops.linear(hm, layer.mlp[3].weight, layer.mlp[3].bias, res=x)
+            hm = ops.linear_t(n3, wT(layer.mlp[0]), layer.mlp[0].bias, act_out=ops.ACT_GELU)
+            x = ops.linear_t(hm, wT(layer.mlp[3]), layer.mlp[3].bias, res=x)
         op = dec.out_proj
-        t2v = ops.linear(t2d, self.text_to_visual.weight, self.text_to_visual.bias)
-        tv = ops.linear(ops.layernorm_rows(x, op[0].weight, op[0].bias), op[1].weight, op[1].bias, res=t2v, gscale=self.gamma)
+        t2v = ops.linear_t(t2d, wT(self.text_to_visual), self.text_to_visual.bias)
+        tv = ops.linear_t(ops.layernorm_rows(x, op[0].weight, op[0].bias), wT(op[1]), op[1].bias, res=t2v, gscale=self.gamma)
         return ops.scoremap(feat, tv.reshape(B, K, C), idx)
 
 

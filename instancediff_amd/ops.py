@@ -170,6 +170,33 @@ def linear(x, w, bias=None, res=None, gscale=None, act_in=ACT_NONE, act_out=ACT_
     return out
 
 
+def linear_t(x, wT, bias=None, res=None, gscale=None, act_in=ACT_NONE, act_out=ACT_NONE, out=None):
+    """x [R,K] (row-strided ok), wT [K,N] PRE-TRANSPOSED weight (row-strided ok) -> [R,N]."""
+    lib = _lib.load()
+    _chk(x, "x"), _chk(wT, "wT")
+    assert x.dim() == 2 and wT.dim() == 2 and x.stride(1) == 1 and wT.stride(1) == 1 and x.shape[1] == wT.shape[0]
+    R, K = x.shape
+    N = wT.shape[1]
+    if out is None:
+        out = torch.empty((R, N), device=x.device, dtype=torch.float32)
+    assert out.stride(1) == 1 and tuple(out.shape) == (R, N)
+    if res is not None:
+        assert res.stride(1) == 1 and tuple(res.shape) == (R, N)
+    check(lib.idiff_linear_t_fwd(_p(x), x.stride(0), _p(wT), wT.stride(0), _p(_c(bias)), _p(res), res.stride(0) if res is not None else 0,
+                                 _p(_c(gscale)), _p(out), out.stride(0), R, K, N, act_in, act_out, _stream()), "linear_t_fwd")
+    return out
+
+
+def smm_memproj(feat, ln1_g, ln1_b, wpk, bias, ln2_g, ln2_b, eps=1e-5):
+    """feat [B,C,H,W] -> mem [B,256,H*W] = LN(Linear(LN(tokens)))"""
+    lib = _lib.load()
+    B, Cc, H, W = feat.shape
+    out = torch.empty((B, 256, H * W), device=feat.device, dtype=torch.float32)
+    check(lib.idiff_smm_memproj_fwd(_p(feat), _bs(feat, "feat"), _p(_c(ln1_g)), _p(_c(ln1_b)), _p(_c(wpk)), _p(_c(bias)), _p(_c(ln2_g)),
+                                    _p(_c(ln2_b)), _p(out), B, Cc, H * W, eps, _stream()), "smm_memproj_fwd")
+    return out
+
+
 def layernorm_rows(x, gamma, beta, eps=1e-5, want_mean_rstd=False):
     lib = _lib.load()
     _chk(x, "x")
@@ -231,7 +258,20 @@ def attn_tokens(q, k, v, heads, scale):
     B, Nq, Cc = q.shape
     M = k.shape[1]
     out = torch.empty_like(q)
-    check(lib.idiff_attn_tokens_fwd(_p(q), _p(k), _p(v), _p(out), B, Nq, M, Cc, heads, scale, _stream()), "attn_tokens_fwd")
+    check(lib.idiff_attn_tokens_fwd(_p(q), _p(k), _p(v), _p(out), B, Nq, M, Cc, heads, scale, Cc, Cc, _stream()), "attn_tokens_fwd")
+    return out
+
+
+def attn_tokens_packed(qkv, heads, scale):
+    """self-attention on a packed projection qkv [B,N,3C] (q | k | v along the last dim) -> [B,N,C]; no copies."""
+    lib = _lib.load()
+    _c(qkv, "qkv")
+    B, Nq, C3 = qkv.shape
+    Cc = C3 // 3
+    out = torch.empty((B, Nq, Cc), device=qkv.device, dtype=torch.float32)
+    base = qkv.data_ptr()
+    check(lib.idiff_attn_tokens_fwd(C.c_void_p(base), C.c_void_p(base + 4 * Cc), C.c_void_p(base + 8 * Cc), _p(out), B, Nq, Nq, Cc, heads, scale,
+                                    C3, C3, _stream()), "attn_tokens_fwd")
     return out
 
 

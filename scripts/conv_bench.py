@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--only", type=str, default="")
     args = ap.parse_args()
     dev = "cuda"
     B = args.batch
@@ -38,6 +39,8 @@ def main():
         ("init 7x7 2->64", 1, 1, 64, 256, 7, 0, False, False),
     ]
     cases = []
+    if args.only:
+        shapes = [s for s in shapes if args.only in s[0]]
     for name, C0, C1, Co, H, ks, mode, stats, pro in shapes:
         x0 = torch.randn(B, C0, H, H, device=dev)
         x1 = torch.randn(B, C1, H, H, device=dev) if C1 else None

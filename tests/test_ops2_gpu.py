@@ -1,0 +1,82 @@
+"""Op-level parity, part 2: fused ScoreMapModule memory projection, transposed-weight linear, packed token
+attention (GPU box only)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from instancediff_amd import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def _close(got, ref, tol, what=""):
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    scale = max(float(ref.abs().max()), 1e-6)
+    err = float((got - ref).abs().max())
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (tol {tol})"
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 32, 32), (1, 128, 16, 16), (2, 256, 8, 8), (1, 64, 12, 20)])
+def test_smm_memproj(B, C, H, W):
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, C + 16, H, W, generator=g) * 2 + 0.3
+    g1, b1 = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    w = torch.randn(256, C, generator=g) / math.sqrt(C)
+    bias = torch.randn(256, generator=g)
+    g2, b2 = torch.randn(256, generator=g), torch.randn(256, generator=g)
+    feat = x[:, :C]  # channel slice of a bigger buffer (as the UNet skip produces it)
+    tok = feat.double().reshape(B, C, H * W).permute(0, 2, 1)
+    ref = F.layer_norm(F.linear(F.layer_norm(tok, (C,), g1.double(), b1.double(), 1e-5), w.double(), bias.double()), (256,),
+                       g2.double(), b2.double(), 1e-5).permute(0, 2, 1)
+    wpk = ops.pack_conv_weight(w.reshape(256, C, 1, 1).contiguous().to(DEV))
+    out = ops.smm_memproj(x.to(DEV)[:, :C], g1.to(DEV), b1.to(DEV), wpk, bias.to(DEV), g2.to(DEV), b2.to(DEV))
+    assert out.shape == (B, 256, H * W)
+    _close(out, ref, 5e-6, "smm_memproj")
+
+
+@pytest.mark.parametrize("R,K,N", [(80, 256, 256), (21, 300, 77), (5, 64, 256), (16, 256, 8448), (80, 1024, 256)])
+def test_linear_t(R, K, N):
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(R, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    res = torch.randn(R, N, generator=g)
+    gs = torch.randn(N, generator=g)
+    ref = F.gelu(res.double() + gs.double() * (F.silu(x.double()) @ w.double().T + b.double()))
+    out = ops.linear_t(x.to(DEV), w.t().contiguous().to(DEV), b.to(DEV), res=res.to(DEV), gscale=gs.to(DEV), act_in=ops.ACT_SILU,
+                       act_out=ops.ACT_GELU)
+    _close(out, ref, 3e-6, "linear_t")
+    _close(ops.linear_t(x.to(DEV), w.t().contiguous().to(DEV)), x.double() @ w.double().T, 3e-6, "linear_t plain")
+
+
+def test_linear_t_strided_views():
+    g = torch.Generator().manual_seed(23)
+    R = 15
+    x = torch.randn(R, 4 * 64, generator=g)
+    wk = torch.randn(256, 256, generator=g)  # [out, in] like nn.Linear
+    # fold form: q_h @ Wk[h*64:(h+1)*64, :]  -> rows of Wk are the transposed weight [K=64][N=256]
+    out = torch.empty(R, 4 * 256, device=DEV)
+    for h in range(4):
+        ops.linear_t(x.to(DEV)[:, h * 64:(h + 1) * 64], wk.to(DEV)[h * 64:(h + 1) * 64], out=out[:, h * 256:(h + 1) * 256])
+        _close(out[:, h * 256:(h + 1) * 256], x.double()[:, h * 64:(h + 1) * 64] @ wk.double()[h * 64:(h + 1) * 64], 3e-6, "fold")
+    # column slice of a transposed weight (row stride > N)
+    wvT = wk.t().contiguous().to(DEV)
+    o = torch.randn(R, 256, generator=g)
+    got = ops.linear_t(o.to(DEV), wvT[:, 64:128])
+    _close(got, o.double() @ wk.double()[64:128].T, 3e-6, "v-proj slice")
+
+
+def test_attn_tokens_packed():
+    g = torch.Generator().manual_seed(24)
+    B, N, C, heads = 3, 5, 256, 4
+    qkv = torch.randn(B, N, 3 * C, generator=g)
+    q, k, v = qkv.double().split(C, dim=-1)
+    dh = C // heads
+    s = torch.einsum('bnhd,bmhd->bhnm', q.reshape(B, N, heads, dh), k.reshape(B, N, heads, dh)) * dh ** -0.5
+    ref = torch.einsum('bhnm,bmhd->bnhd', s.softmax(-1), v.reshape(B, N, heads, dh)).reshape(B, N, C)
+    _close(ops.attn_tokens_packed(qkv.to(DEV), heads, dh ** -0.5), ref, 5e-6, "attn_tokens_packed")
