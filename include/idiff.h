@@ -193,6 +193,79 @@ int idiff_axpby(const float* x, const float* y, float* out, int64_t n, float alp
 int idiff_mix3_per_sample(const float* x0, const float* cond, const float* eps, const float* c0, const float* c1,
                           const float* c2, float* out, int B, int64_t per_sample, idiff_stream_t stream);
 
+/* ================================================================================================
+ * TRAINING PATH (models/drift_noise_model.py:242-312: loss.backward() + Adam).  The reference gets its
+ * backward from ATen autograd; here every gradient kernel is explicit.
+ * ============================================================================================== */
+
+/* Weight gradient of idiff_conv2d_fwd for the SAME descriptor (sources, mode, ks, prologue are re-gathered the
+ * way the forward gathered them; wpk/bias/out/epilogue fields are ignored):
+ *   dw[co][ci][ky][kx] (torch layout) (+)= sum_{b,y,x} dy[b,co,y,x] * X[b,ci,y+ky-p,x+kx-p]
+ * ws: workspace of idiff_conv2d_wgrad_ws_floats(d) floats (per-split partials, reduced in a fixed order). */
+int64_t idiff_conv2d_wgrad_ws_floats(const idiff_conv_desc* d);
+int idiff_conv2d_wgrad(const idiff_conv_desc* d, const float* dy, int64_t dy_bstride, float* dw, int accumulate, float* ws,
+                       idiff_stream_t stream);
+/* data-gradient helpers: the data gradient itself is idiff_conv2d_fwd on dy with idiff_pack_conv_weight_T weights */
+int idiff_sumpool2x2(const float* x, float* out, int64_t planes, int h, int w, idiff_stream_t stream);     /* upsample^T   */
+int idiff_pixel_shuffle2(const float* x, float* out, int B, int C, int h, int w, idiff_stream_t stream);    /* unshuffle^T  */
+/* out_bc[b*C+c] = sum_p x[b,c,p];  out_c[c] (+)= sum_b in_bc[b*C+c]   (bias / per-(b,c) vector gradients) */
+int idiff_plane_sum(const float* x, int64_t x_bstride, float* out_bc, int B, int C, int HW, idiff_stream_t stream);
+int idiff_batch_sum(const float* in_bc, float* out_c, int B, int C, int accumulate, idiff_stream_t stream);
+
+/* Backward of y = silu(a[b,c]*h + b[b,c]) with (a,b) = idiff_gn_finalize(stats(h), gamma, beta, film): gradient
+ * w.r.t. h THROUGH the GroupNorm statistics, dgamma/dbeta [C], dfilm [B,2C] (scale | shift).  a, b, mean_rstd as
+ * produced by idiff_gn_finalize.  ws: idiff_gn_silu_bwd_ws_floats(B,C,groups) floats. */
+int64_t idiff_gn_silu_bwd_ws_floats(int B, int C, int groups);
+int idiff_gn_silu_bwd(const float* dy, int64_t dy_bstride, const float* h, int64_t h_bstride, const float* a, const float* b,
+                      const float* mean_rstd, const float* gamma, const float* beta, const float* film, int64_t film_ld,
+                      float* dh, int64_t dh_bstride, float* dgamma, float* dbeta, float* dfilm, int64_t dfilm_ld, float* ws,
+                      int B, int C, int groups, int HW, int accumulate, idiff_stream_t stream);
+
+/* elementwise activations (token side) and their gradients: dx = dy * act'(x) */
+int idiff_act_fwd(const float* x, float* y, int64_t n, int act, idiff_stream_t stream);
+int idiff_act_bwd(const float* dy, const float* x, float* dx, int64_t n, int act, idiff_stream_t stream);
+/* out[n] (+)= sum_r x[r,n]  (Linear bias gradient) */
+int idiff_colsum(const float* x, int64_t ldx, float* out, int R, int N, int accumulate, idiff_stream_t stream);
+/* out[r,n] = x[r,n]*g[n]  and  out[n] = sum_r x[r,n]*y[r,n]  (dense [R,N]; ScoreMapModule gamma and its gradient) */
+int idiff_scale_cols(const float* x, const float* g, float* out, int R, int N, idiff_stream_t stream);
+int idiff_colsum_prod(const float* x, const float* y, float* out, int R, int N, idiff_stream_t stream);
+int idiff_layernorm_rows_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                             const float* mean_rstd, float* dx, int64_t lddx, float* dgamma, float* dbeta, int R, int C,
+                             int accumulate, idiff_stream_t stream);
+/* ws: 2*B*C floats */
+int idiff_chan_layernorm_bwd(const float* dy, int64_t dy_bstride, const float* x, int64_t x_bstride, const float* gamma,
+                             const float* mean_rstd, float* dx, int64_t dx_bstride, float* dgamma, float* dbeta, float* ws,
+                             int B, int C, int HW, int accumulate, idiff_stream_t stream);
+/* y = x / max(|x|_2 over channels, 1e-12) per pixel (F.normalize(dim=1)); nrm [B,HW] */
+int idiff_chan_normalize_fwd(const float* x, int64_t x_bstride, float* y, float* nrm, int B, int C, int HW,
+                             idiff_stream_t stream);
+int idiff_chan_normalize_bwd(const float* dy, const float* y, const float* nrm, float* dx, int64_t dx_bstride, int B, int C,
+                             int HW, idiff_stream_t stream);
+/* out[b, idx[b], p] = x[b,0,p], zeros elsewhere (gradient of idiff_gather_channel) */
+int idiff_scatter_channel(const float* x, const int32_t* idx, float* out, int B, int C, int HW, idiff_stream_t stream);
+
+/* generic batched GEMM on the f32 matrix cores:  C[b] = alpha * op(A[b]) (MxK) . op(B[b]) (KxN) + beta * C[b]
+ * (row-major; transX != 0 -> the matrix is stored transposed); sA/sB/sC = batch strides in elements */
+int idiff_bgemm(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                int transA, int transB, int64_t sA, int64_t sB, int64_t sC, int batch, float alpha, float beta,
+                idiff_stream_t stream);
+/* out = softmax(scale * x) over each row;  ds = scale * p * (dp - <p, dp>) */
+int idiff_softmax_rows_fwd(const float* x, int64_t ldx, float* out, int64_t ldo, int R, int N, float scale,
+                           idiff_stream_t stream);
+int idiff_softmax_rows_bwd(const float* p, int64_t ldp, const float* dp, int64_t lddp, float* ds, int64_t ldds, int R, int N,
+                           float scale, idiff_stream_t stream);
+
+/* losses (drift_noise_model.py:234-240,270,279): bilinear resize of the label (align_corners=False, no antialias;
+ * torchvision Resize is unpinned in the reference) and mean squared error with its gradient
+ * grad = grad_scale * 2 (a-b) / n  (grad may be NULL); ws: 256 floats; loss: 1 float on the device */
+int idiff_resize_bilinear(const float* x, float* out, int64_t planes, int H, int W, int oh, int ow, idiff_stream_t stream);
+int idiff_mse_loss(const float* a, const float* b, float* loss, float* grad, float* ws, int64_t n, float grad_scale,
+                   idiff_stream_t stream);
+/* torch.optim.Adam semantics (L2-in-gradient weight decay, config.yml:138-143), grad pre-scaled by grad_scale
+ * (1/world after the flat RCCL all-reduce); step >= 1 */
+int idiff_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, float grad_scale, int step, idiff_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

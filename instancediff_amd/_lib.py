@@ -64,6 +64,31 @@ SIGNATURES = {
     "idiff_philox_raw": (I, [P, I64, U64, U64, c_stream]),
     "idiff_axpby": (I, [P, P, P, I64, F, F, c_stream]),
     "idiff_mix3_per_sample": (I, [P, P, P, P, P, P, P, I, I64, c_stream]),
+    # ---- training path ----
+    "idiff_conv2d_wgrad_ws_floats": (I64, [C.POINTER(ConvDesc)]),
+    "idiff_conv2d_wgrad": (I, [C.POINTER(ConvDesc), P, I64, P, I, P, c_stream]),
+    "idiff_sumpool2x2": (I, [P, P, I64, I, I, c_stream]),
+    "idiff_pixel_shuffle2": (I, [P, P, I, I, I, I, c_stream]),
+    "idiff_plane_sum": (I, [P, I64, P, I, I, I, c_stream]),
+    "idiff_batch_sum": (I, [P, P, I, I, I, c_stream]),
+    "idiff_gn_silu_bwd_ws_floats": (I64, [I, I, I]),
+    "idiff_gn_silu_bwd": (I, [P, I64, P, I64, P, P, P, P, P, P, I64, P, I64, P, P, P, I64, P, I, I, I, I, I, c_stream]),
+    "idiff_act_fwd": (I, [P, P, I64, I, c_stream]),
+    "idiff_act_bwd": (I, [P, P, P, I64, I, c_stream]),
+    "idiff_colsum": (I, [P, I64, P, I, I, I, c_stream]),
+    "idiff_scale_cols": (I, [P, P, P, I, I, c_stream]),
+    "idiff_colsum_prod": (I, [P, P, P, I, I, c_stream]),
+    "idiff_layernorm_rows_bwd": (I, [P, I64, P, I64, P, P, P, I64, P, P, I, I, I, c_stream]),
+    "idiff_chan_layernorm_bwd": (I, [P, I64, P, I64, P, P, P, I64, P, P, P, I, I, I, I, c_stream]),
+    "idiff_chan_normalize_fwd": (I, [P, I64, P, P, I, I, I, c_stream]),
+    "idiff_chan_normalize_bwd": (I, [P, P, P, P, I64, I, I, I, c_stream]),
+    "idiff_scatter_channel": (I, [P, P, P, I, I, I, c_stream]),
+    "idiff_bgemm": (I, [P, P, P, I, I, I, I64, I64, I64, I, I, I64, I64, I64, I, F, F, c_stream]),
+    "idiff_softmax_rows_fwd": (I, [P, I64, P, I64, I, I, F, c_stream]),
+    "idiff_softmax_rows_bwd": (I, [P, I64, P, I64, P, I64, I, I, F, c_stream]),
+    "idiff_resize_bilinear": (I, [P, P, I64, I, I, I, I, c_stream]),
+    "idiff_mse_loss": (I, [P, P, P, P, P, I64, F, c_stream]),
+    "idiff_adam_step": (I, [P, P, P, P, I64, F, F, F, F, F, F, I, c_stream]),
 }
 
 

@@ -1,0 +1,572 @@
+// HBM-bound kernels of the TRAINING path (models/drift_noise_model.py:242-312): data-gradient reshapes,
+// GroupNorm/FiLM/SiLU backward, LayerNorm backward, activation gradients, reductions, score-map backward,
+// losses (MSE + bilinear-resize pyramid), fused Adam.  gfx950, fp32, deterministic (no atomics).
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+inline int bgrid(long long n, int per = 256, int cap = 4096) {
+    long long g = (n + per - 1) / per;
+    if (g < 1) g = 1;
+    return (int)(g > cap ? cap : g);
+}
+
+// out[b,c,y,x] = sum of the 2x2 block of x (data gradient of nearest x2 upsampling)
+__global__ void sumpool2x2_kernel(const float* __restrict__ x, float* __restrict__ out, long long planes, int h, int w) {
+    const long long n = planes * h * w;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int xx = i % w, yy = (i / w) % h;
+        const long long pl = i / ((long long)w * h);
+        const float* p = x + pl * 4 * h * w + (long long)(2 * yy) * (2 * w) + 2 * xx;
+        out[i] = (p[0] + p[1]) + (p[2 * w] + p[2 * w + 1]);
+    }
+}
+
+// out[b,c,2y+p1,2x+p2] = x[b, c*4+p1*2+p2, y, x]   (data gradient of pixel_unshuffle(2))
+__global__ void pixel_shuffle2_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int C, int h, int w) {
+    const long long n = (long long)B * C * 4 * h * w;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int ox = i % (2 * w), oy = (i / (2 * w)) % (2 * h);
+        const long long bc = i / ((long long)4 * h * w);
+        const int c = bc % C;
+        const long long b = bc / C;
+        out[i] = x[((b * C + c) * 4 + (oy & 1) * 2 + (ox & 1)) * (long long)h * w + (long long)(oy >> 1) * w + (ox >> 1)];
+    }
+}
+
+// per-plane sums: out[b*C+c] = sum_p x[b,c,p]  (one workgroup per plane, fixed order)
+__global__ __launch_bounds__(256) void plane_sum_kernel(const float* __restrict__ x, long long xbs, float* __restrict__ out, int C, int HW) {
+    __shared__ float red[4];
+    const int b = blockIdx.x / C, c = blockIdx.x % C;
+    const float* p = x + (long long)b * xbs + (long long)c * HW;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) s += p[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// out[c] (+)= sum_b in[b*C+c]
+__global__ void batch_sum_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += in[(long long)b * C + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+__device__ __forceinline__ float silu_grad(float z) {
+    const float sg = 1.0f / (1.0f + __expf(-z));
+    return sg * (1.0f + z * (1.0f - sg));
+}
+
+// GroupNorm(+FiLM)+SiLU backward, pass 1: per (b,c)  S1 = sum dz,  S2 = sum dz*xhat,  dz = dy*silu'(a*h+b)
+__global__ __launch_bounds__(256) void gn_silu_bwd_reduce_kernel(const float* __restrict__ dy, long long dybs, const float* __restrict__ h,
+                                                                 long long hbs, const float* __restrict__ a, const float* __restrict__ bc,
+                                                                 const float* __restrict__ mean_rstd, float* __restrict__ s12, int C, int groups,
+                                                                 int HW) {
+    __shared__ float red[2][4];
+    const int b = blockIdx.x / C, c = blockIdx.x % C;
+    const int g = c / (C / groups);
+    const float mean = mean_rstd[((long long)b * groups + g) * 2], rstd = mean_rstd[((long long)b * groups + g) * 2 + 1];
+    const float aa = a[blockIdx.x], bb = bc[blockIdx.x];
+    const float* dp = dy + (long long)b * dybs + (long long)c * HW;
+    const float* hp = h + (long long)b * hbs + (long long)c * HW;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const float hv = hp[i];
+        const float dz = dp[i] * silu_grad(aa * hv + bb);
+        s1 += dz;
+        s2 += dz * (hv - mean) * rstd;
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = s1;
+        red[1][threadIdx.x >> 6] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s12[blockIdx.x * 2] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        s12[blockIdx.x * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+// pass 2 (tiny): group means A, Bq per (b,g); dgamma/dbeta (sum over b, fixed order); dfilm [B,2C]
+__global__ void gn_bwd_finalize_kernel(const float* __restrict__ s12, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       const float* __restrict__ film, long long film_ld, float* __restrict__ ab, float* __restrict__ gbc,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dfilm, long long dfilm_ld, int B,
+                                       int C, int groups, int HW, int accumulate) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int cpg = C / groups;
+    if (tid < B * groups) {  // group means
+        const int b = tid / groups, g = tid % groups;
+        float sa = 0.f, sb = 0.f;
+        for (int i = 0; i < cpg; ++i) {
+            const int c = g * cpg + i;
+            const float sc = film ? 1.f + film[(long long)b * film_ld + c] : 1.f;
+            const float gg = sc * (gamma ? gamma[c] : 1.f);
+            sa += gg * s12[((long long)b * C + c) * 2];
+            sb += gg * s12[((long long)b * C + c) * 2 + 1];
+        }
+        const float inv = 1.0f / ((float)cpg * (float)HW);
+        ab[tid * 2] = sa * inv;
+        ab[tid * 2 + 1] = sb * inv;
+    }
+    if (tid < C) {  // parameter gradients
+        float dg = 0.f, db = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float sc = film ? 1.f + film[(long long)b * film_ld + tid] : 1.f;
+            dg += sc * s12[((long long)b * C + tid) * 2 + 1];
+            db += sc * s12[((long long)b * C + tid) * 2];
+        }
+        if (dgamma) dgamma[tid] = accumulate ? dgamma[tid] + dg : dg;
+        if (dbeta) dbeta[tid] = accumulate ? dbeta[tid] + db : db;
+    }
+    if (tid < B * C) {  // per-(b,c) scale used by the apply pass, and FiLM gradients
+        const int b = tid / C, c = tid % C;
+        const float sc = film ? 1.f + film[(long long)b * film_ld + c] : 1.f;
+        const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+        gbc[tid] = sc * ga;
+        if (dfilm) {
+            dfilm[(long long)b * dfilm_ld + c] = ga * s12[tid * 2 + 1] + be * s12[tid * 2];  // d scale
+            dfilm[(long long)b * dfilm_ld + C + c] = s12[tid * 2];                           // d shift
+        }
+    }
+}
+
+// pass 3: dh = rstd * (dz*g - A - xhat*Bq)
+__global__ __launch_bounds__(256) void gn_silu_bwd_apply_kernel(const float* __restrict__ dy, long long dybs, const float* __restrict__ h,
+                                                                long long hbs, const float* __restrict__ a, const float* __restrict__ bc,
+                                                                const float* __restrict__ mean_rstd, const float* __restrict__ ab,
+                                                                const float* __restrict__ gbc, float* __restrict__ dh, long long dhbs, int C,
+                                                                int groups, int HW) {
+    const int b = blockIdx.y / C, c = blockIdx.y % C;
+    const int g = c / (C / groups);
+    const float mean = mean_rstd[((long long)b * groups + g) * 2], rstd = mean_rstd[((long long)b * groups + g) * 2 + 1];
+    const float A = ab[((long long)b * groups + g) * 2], Bq = ab[((long long)b * groups + g) * 2 + 1];
+    const float aa = a[blockIdx.y], bb = bc[blockIdx.y], gg = gbc[blockIdx.y];
+    const float* dp = dy + (long long)b * dybs + (long long)c * HW;
+    const float* hp = h + (long long)b * hbs + (long long)c * HW;
+    float* op = dh + (long long)b * dhbs + (long long)c * HW;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+        const float hv = hp[i];
+        const float dz = dp[i] * silu_grad(aa * hv + bb);
+        op[i] = rstd * (dz * gg - A - (hv - mean) * rstd * Bq);
+    }
+}
+
+// dx = dy * act'(x)   (act: SILU or GELU)
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, long long n, int act) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        float g;
+        if (act == IDIFF_ACT_SILU) {
+            g = silu_grad(v);
+        } else {
+            const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+            g = cdf + v * 0.3989422804014327f * __expf(-0.5f * v * v);
+        }
+        dx[i] = dy[i] * g;
+    }
+}
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, int act) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        y[i] = act == IDIFF_ACT_SILU ? silu_f(v) : 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    }
+}
+
+// out[n] (+)= sum_r x[r, n]
+__global__ void colsum_kernel(const float* __restrict__ x, long long ldx, float* __restrict__ out, int R, int N, int accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += x[(long long)r * ldx + n];
+    out[n] = accumulate ? out[n] + s : s;
+}
+
+// out[r,n] = x[r,n] * g[n]
+__global__ void scale_cols_kernel(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ out, int R, int N) {
+    const long long n = (long long)R * N;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = x[i] * g[i % N];
+}
+// out[n] = sum_r x[r,n] * y[r,n]
+__global__ void colsum_prod_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, int R, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += x[(long long)r * N + n] * y[(long long)r * N + n];
+    out[n] = s;
+}
+
+// LayerNorm rows backward: dx (wave per row) ; dgamma/dbeta by a column pass
+__global__ __launch_bounds__(256) void ln_rows_bwd_dx_kernel(const float* __restrict__ dy, long long lddy, const float* __restrict__ x,
+                                                             long long ldx, const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
+                                                             float* __restrict__ dx, long long lddx, int R, int C) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float mean = mean_rstd[2 * r], rstd = mean_rstd[2 * r + 1];
+    const float* dyr = dy + (long long)r * lddy;
+    const float* xr = x + (long long)r * ldx;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float g = dyr[c] * gamma[c];
+        s1 += g;
+        s2 += g * (xr[c] - mean) * rstd;
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+    for (int c = lane; c < C; c += 64) {
+        const float xh = (xr[c] - mean) * rstd;
+        dx[(long long)r * lddx + c] = rstd * (dyr[c] * gamma[c] - s1 - xh * s2);
+    }
+}
+__global__ void ln_rows_bwd_param_kernel(const float* __restrict__ dy, long long lddy, const float* __restrict__ x, long long ldx,
+                                         const float* __restrict__ mean_rstd, float* __restrict__ dgamma, float* __restrict__ dbeta, int R, int C,
+                                         int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float dg = 0.f, db = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const float d = dy[(long long)r * lddy + c];
+        dg += d * (x[(long long)r * ldx + c] - mean_rstd[2 * r]) * mean_rstd[2 * r + 1];
+        db += d;
+    }
+    dgamma[c] = accumulate ? dgamma[c] + dg : dg;
+    dbeta[c] = accumulate ? dbeta[c] + db : db;
+}
+
+// channel LayerNorm backward (thread = pixel) ; writes dx and per-(b,c) partial sums are done by plane kernels
+__global__ __launch_bounds__(256) void chan_ln_bwd_dx_kernel(const float* __restrict__ dy, long long dybs, const float* __restrict__ x, long long xbs,
+                                                             const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
+                                                             float* __restrict__ dx, long long dxbs, int C, int HW) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const float mean = mean_rstd[((long long)b * HW + p) * 2], rstd = mean_rstd[((long long)b * HW + p) * 2 + 1];
+    const float* dp = dy + (long long)b * dybs + p;
+    const float* xp = x + (long long)b * xbs + p;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float g = dp[(long long)c * HW] * gamma[c];
+        s1 += g;
+        s2 += g * (xp[(long long)c * HW] - mean) * rstd;
+    }
+    s1 /= (float)C;
+    s2 /= (float)C;
+    float* op = dx + (long long)b * dxbs + p;
+    for (int c = 0; c < C; ++c) {
+        const float xh = (xp[(long long)c * HW] - mean) * rstd;
+        op[(long long)c * HW] = rstd * (dp[(long long)c * HW] * gamma[c] - s1 - xh * s2);
+    }
+}
+// per plane: out[(b*C+c)*2] = sum_p dy*xhat, [..+1] = sum_p dy   (xhat from per-pixel mean/rstd)
+__global__ __launch_bounds__(256) void chan_ln_bwd_param_kernel(const float* __restrict__ dy, long long dybs, const float* __restrict__ x,
+                                                                long long xbs, const float* __restrict__ mean_rstd, float* __restrict__ out, int C,
+                                                                int HW) {
+    __shared__ float red[2][4];
+    const int b = blockIdx.x / C, c = blockIdx.x % C;
+    const float* dp = dy + (long long)b * dybs + (long long)c * HW;
+    const float* xp = x + (long long)b * xbs + (long long)c * HW;
+    const float* mr = mean_rstd + (long long)b * HW * 2;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const float d = dp[i];
+        s1 += d * (xp[i] - mr[2 * i]) * mr[2 * i + 1];
+        s2 += d;
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = s1;
+        red[1][threadIdx.x >> 6] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[blockIdx.x * 2] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        out[blockIdx.x * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+// dgamma[c] (+)= sum_b in[(b*C+c)*2], dbeta[c] (+)= sum_b in[(b*C+c)*2+1]
+__global__ void pair_batch_sum_kernel(const float* __restrict__ in, float* __restrict__ o0, float* __restrict__ o1, int B, int C, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, b2 = 0.f;
+    for (int b = 0; b < B; ++b) {
+        a += in[((long long)b * C + c) * 2];
+        b2 += in[((long long)b * C + c) * 2 + 1];
+    }
+    o0[c] = accumulate ? o0[c] + a : a;
+    o1[c] = accumulate ? o1[c] + b2 : b2;
+}
+
+// L2 normalisation along channels of a map (thread = pixel): y = x / max(|x|, eps); also the norm
+__global__ __launch_bounds__(256) void chan_normalize_fwd_kernel(const float* __restrict__ x, long long xbs, float* __restrict__ y,
+                                                                 float* __restrict__ nrm, int C, int HW) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const float* xp = x + (long long)b * xbs + p;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += xp[(long long)c * HW] * xp[(long long)c * HW];
+    const float n = fmaxf(sqrtf(s), 1e-12f);
+    nrm[(long long)b * HW + p] = n;
+    float* yp = y + (long long)b * C * HW + p;
+    for (int c = 0; c < C; ++c) yp[(long long)c * HW] = xp[(long long)c * HW] / n;
+}
+// dx = (dy - y * <y, dy>) / n
+__global__ __launch_bounds__(256) void chan_normalize_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                 const float* __restrict__ nrm, float* __restrict__ dx, long long dxbs, int C,
+                                                                 int HW) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const float* dp = dy + (long long)b * C * HW + p;
+    const float* yp = y + (long long)b * C * HW + p;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += dp[(long long)c * HW] * yp[(long long)c * HW];
+    const float inv = 1.0f / nrm[(long long)b * HW + p];
+    float* op = dx + (long long)b * dxbs + p;
+    for (int c = 0; c < C; ++c) op[(long long)c * HW] = (dp[(long long)c * HW] - yp[(long long)c * HW] * s) * inv;
+}
+
+// out[b, idx[b], p] = x[b, 0, p], other channels zero
+__global__ void scatter_channel_kernel(const float* __restrict__ x, const int* __restrict__ idx, float* __restrict__ out, int B, int C, int HW) {
+    const long long n = (long long)B * C * HW;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int p = i % HW, c = (i / HW) % C;
+        const long long b = i / ((long long)C * HW);
+        out[i] = c == idx[b] ? x[b * HW + p] : 0.f;
+    }
+}
+
+// ---- losses ---------------------------------------------------------------------------------------------
+// bilinear resize, align_corners=False, antialias=False (torchvision Resize on tensors with antialias off)
+__device__ __forceinline__ void bil_coef(int o, int in_size, float scale, int* i0, int* i1, float* w1) {
+    float s = ((float)o + 0.5f) * scale - 0.5f;
+    if (s < 0.f) s = 0.f;
+    int a = (int)s;
+    if (a > in_size - 1) a = in_size - 1;
+    *i0 = a;
+    *i1 = a < in_size - 1 ? a + 1 : a;
+    *w1 = s - (float)a;
+}
+__global__ void resize_bilinear_kernel(const float* __restrict__ x, float* __restrict__ out, long long planes, int H, int W, int oh, int ow) {
+    const long long n = planes * oh * ow;
+    const float sy = (float)H / (float)oh, sx = (float)W / (float)ow;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int ox = i % ow, oy = (i / ow) % oh;
+        const long long pl = i / ((long long)oh * ow);
+        int y0, y1, x0, x1;
+        float wy, wx;
+        bil_coef(oy, H, sy, &y0, &y1, &wy);
+        bil_coef(ox, W, sx, &x0, &x1, &wx);
+        const float* p = x + pl * H * W;
+        const float top = p[(long long)y0 * W + x0] * (1.f - wx) + p[(long long)y0 * W + x1] * wx;
+        const float bot = p[(long long)y1 * W + x0] * (1.f - wx) + p[(long long)y1 * W + x1] * wx;
+        out[i] = top * (1.f - wy) + bot * wy;
+    }
+}
+// sum of squared differences, one partial per workgroup (fixed grid -> deterministic); d = 2*scale*(a-b) optional
+__global__ __launch_bounds__(256) void sqdiff_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ part,
+                                                             float* __restrict__ grad, long long n, float gscale) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float d = a[i] - b[i];
+        s += d * d;
+        if (grad) grad[i] = gscale * d;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void sum_small_kernel(const float* __restrict__ part, int n, float scale, float* __restrict__ out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += part[i];
+        *out = s * scale;
+    }
+}
+
+// Adam with L2-in-gradient weight decay (torch.optim.Adam, not AdamW), grad pre-scale (1/world for the flat
+// all-reduce), bias corrections folded into step_size / bc2_sqrt on the host
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
+                            float lr, float beta1, float beta2, float eps, float wd, float gscale, float bc1, float bc2_sqrt) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float gr = g[i] * gscale;
+        const float pv = p[i];
+        gr += wd * pv;
+        const float mm = beta1 * m[i] + (1.f - beta1) * gr;
+        const float vv = beta2 * v[i] + (1.f - beta2) * gr * gr;
+        m[i] = mm;
+        v[i] = vv;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        p[i] = pv - (lr / bc1) * (mm / denom);
+    }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int idiff_sumpool2x2(const float* x, float* out, int64_t planes, int h, int w, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(x && out && planes > 0 && h > 0 && w > 0, "sumpool2x2: bad args");
+    hipLaunchKernelGGL(sumpool2x2_kernel, dim3(bgrid(planes * h * w)), dim3(256), 0, ST, x, out, (long long)planes, h, w);
+    IDIFF_CHECK_LAUNCH("sumpool2x2");
+    return IDIFF_OK;
+}
+extern "C" int idiff_pixel_shuffle2(const float* x, float* out, int B, int C, int h, int w, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(x && out && B > 0 && C > 0 && h > 0 && w > 0, "pixel_shuffle2: bad args");
+    hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3(bgrid((long long)B * C * 4 * h * w)), dim3(256), 0, ST, x, out, B, C, h, w);
+    IDIFF_CHECK_LAUNCH("pixel_shuffle2");
+    return IDIFF_OK;
+}
+extern "C" int idiff_plane_sum(const float* x, int64_t x_bstride, float* out_bc, int B, int C, int HW, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(x && out_bc && B > 0 && C > 0 && HW > 0, "plane_sum: bad args");
+    hipLaunchKernelGGL(plane_sum_kernel, dim3(B * C), dim3(256), 0, ST, x, (long long)x_bstride, out_bc, C, HW);
+    IDIFF_CHECK_LAUNCH("plane_sum");
+    return IDIFF_OK;
+}
+extern "C" int idiff_batch_sum(const float* in_bc, float* out_c, int B, int C, int accumulate, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(in_bc && out_c && B > 0 && C > 0, "batch_sum: bad args");
+    hipLaunchKernelGGL(batch_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, in_bc, out_c, B, C, accumulate);
+    IDIFF_CHECK_LAUNCH("batch_sum");
+    return IDIFF_OK;
+}
+extern "C" int idiff_gn_silu_bwd(const float* dy, int64_t dy_bstride, const float* h, int64_t h_bstride, const float* a, const float* b,
+                                 const float* mean_rstd, const float* gamma, const float* beta, const float* film, int64_t film_ld, float* dh,
+                                 int64_t dh_bstride, float* dgamma, float* dbeta, float* dfilm, int64_t dfilm_ld, float* ws, int B, int C,
+                                 int groups, int HW, int accumulate, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(dy && h && a && b && mean_rstd && dh && ws, "gn_silu_bwd: null pointer");
+    IDIFF_CHECK_ARG(B > 0 && C > 0 && groups > 0 && C % groups == 0 && HW > 0, "gn_silu_bwd: bad dims");
+    float* s12 = ws;                       // [B*C*2]
+    float* ab = ws + (size_t)B * C * 2;    // [B*groups*2]
+    float* gbc = ab + (size_t)B * groups * 2;  // [B*C]
+    hipLaunchKernelGGL(gn_silu_bwd_reduce_kernel, dim3(B * C), dim3(256), 0, ST, dy, (long long)dy_bstride, h, (long long)h_bstride, a, b,
+                       mean_rstd, s12, C, groups, HW);
+    IDIFF_CHECK_LAUNCH("gn_silu_bwd_reduce");
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, ST, s12, gamma, beta, film, (long long)film_ld, ab, gbc,
+                       dgamma, dbeta, dfilm, (long long)dfilm_ld, B, C, groups, HW, accumulate);
+    IDIFF_CHECK_LAUNCH("gn_bwd_finalize");
+    int gx = (HW + 1023) / 1024;
+    if (gx < 1) gx = 1;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(gn_silu_bwd_apply_kernel, dim3(gx, B * C), dim3(256), 0, ST, dy, (long long)dy_bstride, h, (long long)h_bstride, a, b,
+                       mean_rstd, ab, gbc, dh, (long long)dh_bstride, C, groups, HW);
+    IDIFF_CHECK_LAUNCH("gn_silu_bwd_apply");
+    return IDIFF_OK;
+}
+extern "C" int64_t idiff_gn_silu_bwd_ws_floats(int B, int C, int groups) { return (int64_t)B * C * 3 + (int64_t)B * groups * 2; }
+
+extern "C" int idiff_act_fwd(const float* x, float* y, int64_t n, int act, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(x && y && n > 0 && (act == IDIFF_ACT_SILU || act == IDIFF_ACT_GELU), "act_fwd: bad args");
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(bgrid(n)), dim3(256), 0, ST, x, y, (long long)n, act);
+    IDIFF_CHECK_LAUNCH("act_fwd");
+    return IDIFF_OK;
+}
+extern "C" int idiff_act_bwd(const float* dy, const float* x, float* dx, int64_t n, int act, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(dy && x && dx && n > 0 && (act == IDIFF_ACT_SILU || act == IDIFF_ACT_GELU), "act_bwd: bad args");
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(bgrid(n)), dim3(256), 0, ST, dy, x, dx, (long long)n, act);
+    IDIFF_CHECK_LAUNCH("act_bwd");
+    return IDIFF_OK;
+}
+extern "C" int idiff_colsum(const float* x, int64_t ldx, float* out, int R, int N, int accumulate, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(x && out && R > 0 && N > 0 && ldx >= N, "colsum: bad args");
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256), dim3(256), 0, ST, x, (long long)ldx, out, R, N, accumulate);
+    IDIFF_CHECK_LAUNCH("colsum");
+    return IDIFF_OK;
+}
+extern "C" int idiff_scale_cols(const float* x, const float* g, float* out, int R, int N, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(x && g && out && R > 0 && N > 0, "scale_cols: bad args");
+    hipLaunchKernelGGL(scale_cols_kernel, dim3(bgrid((long long)R * N)), dim3(256), 0, ST, x, g, out, R, N);
+    IDIFF_CHECK_LAUNCH("scale_cols");
+    return IDIFF_OK;
+}
+extern "C" int idiff_colsum_prod(const float* x, const float* y, float* out, int R, int N, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(x && y && out && R > 0 && N > 0, "colsum_prod: bad args");
+    hipLaunchKernelGGL(colsum_prod_kernel, dim3((N + 255) / 256), dim3(256), 0, ST, x, y, out, R, N);
+    IDIFF_CHECK_LAUNCH("colsum_prod");
+    return IDIFF_OK;
+}
+extern "C" int idiff_layernorm_rows_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean_rstd,
+                                        float* dx, int64_t lddx, float* dgamma, float* dbeta, int R, int C, int accumulate,
+                                        idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(dy && x && gamma && mean_rstd && dx && R > 0 && C > 0, "layernorm_rows_bwd: bad args");
+    hipLaunchKernelGGL(ln_rows_bwd_dx_kernel, dim3((R + 3) / 4), dim3(256), 0, ST, dy, (long long)lddy, x, (long long)ldx, gamma, mean_rstd, dx,
+                       (long long)lddx, R, C);
+    IDIFF_CHECK_LAUNCH("layernorm_rows_bwd_dx");
+    if (dgamma && dbeta) {
+        hipLaunchKernelGGL(ln_rows_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, dy, (long long)lddy, x, (long long)ldx, mean_rstd,
+                           dgamma, dbeta, R, C, accumulate);
+        IDIFF_CHECK_LAUNCH("layernorm_rows_bwd_param");
+    }
+    return IDIFF_OK;
+}
+extern "C" int idiff_chan_layernorm_bwd(const float* dy, int64_t dy_bstride, const float* x, int64_t x_bstride, const float* gamma,
+                                        const float* mean_rstd, float* dx, int64_t dx_bstride, float* dgamma, float* dbeta, float* ws, int B, int C,
+                                        int HW, int accumulate, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(dy && x && gamma && mean_rstd && dx && ws && B > 0 && C > 0 && HW > 0, "chan_layernorm_bwd: bad args");
+    hipLaunchKernelGGL(chan_ln_bwd_dx_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, ST, dy, (long long)dy_bstride, x, (long long)x_bstride,
+                       gamma, mean_rstd, dx, (long long)dx_bstride, C, HW);
+    IDIFF_CHECK_LAUNCH("chan_layernorm_bwd_dx");
+    if (dgamma && dbeta) {
+        hipLaunchKernelGGL(chan_ln_bwd_param_kernel, dim3(B * C), dim3(256), 0, ST, dy, (long long)dy_bstride, x, (long long)x_bstride, mean_rstd,
+                           ws, C, HW);
+        IDIFF_CHECK_LAUNCH("chan_layernorm_bwd_param");
+        hipLaunchKernelGGL(pair_batch_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, ws, dgamma, dbeta, B, C, accumulate);
+        IDIFF_CHECK_LAUNCH("chan_layernorm_bwd_param_sum");
+    }
+    return IDIFF_OK;
+}
+extern "C" int idiff_chan_normalize_fwd(const float* x, int64_t x_bstride, float* y, float* nrm, int B, int C, int HW, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(x && y && nrm && B > 0 && C > 0 && HW > 0, "chan_normalize_fwd: bad args");
+    hipLaunchKernelGGL(chan_normalize_fwd_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, ST, x, (long long)x_bstride, y, nrm, C, HW);
+    IDIFF_CHECK_LAUNCH("chan_normalize_fwd");
+    return IDIFF_OK;
+}
+extern "C" int idiff_chan_normalize_bwd(const float* dy, const float* y, const float* nrm, float* dx, int64_t dx_bstride, int B, int C, int HW,
+                                        idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(dy && y && nrm && dx && B > 0 && C > 0 && HW > 0, "chan_normalize_bwd: bad args");
+    hipLaunchKernelGGL(chan_normalize_bwd_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, ST, dy, y, nrm, dx, (long long)dx_bstride, C, HW);
+    IDIFF_CHECK_LAUNCH("chan_normalize_bwd");
+    return IDIFF_OK;
+}
+extern "C" int idiff_scatter_channel(const float* x, const int32_t* idx, float* out, int B, int C, int HW, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(x && idx && out && B > 0 && C > 0 && HW > 0, "scatter_channel: bad args");
+    hipLaunchKernelGGL(scatter_channel_kernel, dim3(bgrid((long long)B * C * HW)), dim3(256), 0, ST, x, idx, out, B, C, HW);
+    IDIFF_CHECK_LAUNCH("scatter_channel");
+    return IDIFF_OK;
+}
+extern "C" int idiff_resize_bilinear(const float* x, float* out, int64_t planes, int H, int W, int oh, int ow, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(x && out && planes > 0 && H > 0 && W > 0 && oh > 0 && ow > 0, "resize_bilinear: bad args");
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(bgrid(planes * oh * ow)), dim3(256), 0, ST, x, out, (long long)planes, H, W, oh, ow);
+    IDIFF_CHECK_LAUNCH("resize_bilinear");
+    return IDIFF_OK;
+}
+#define IDIFF_MSE_PARTS 256
+extern "C" int idiff_mse_loss(const float* a, const float* b, float* loss, float* grad, float* ws, int64_t n, float grad_scale,
+                              idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(a && b && loss && ws && n > 0, "mse_loss: bad args");
+    hipLaunchKernelGGL(sqdiff_partial_kernel, dim3(IDIFF_MSE_PARTS), dim3(256), 0, ST, a, b, ws, grad, (long long)n, 2.0f * grad_scale / (float)n);
+    IDIFF_CHECK_LAUNCH("mse_loss_partial");
+    hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(64), 0, ST, ws, IDIFF_MSE_PARTS, 1.0f / (float)n, loss);
+    IDIFF_CHECK_LAUNCH("mse_loss_sum");
+    return IDIFF_OK;
+}
+extern "C" int idiff_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, float grad_scale, int step, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adam_step: bad args");
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(bgrid(n, 256, 8192)), dim3(256), 0, ST, p, g, m, v, (long long)n, lr, beta1, beta2, eps, weight_decay,
+                       grad_scale, bc1, bc2_sqrt);
+    IDIFF_CHECK_LAUNCH("adam_step");
+    return IDIFF_OK;
+}

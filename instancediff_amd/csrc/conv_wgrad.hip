@@ -1,0 +1,291 @@
+// Weight gradient of the implicit-GEMM convolution on the f32 matrix cores (v_mfma_f32_16x16x4_f32).
+//
+//   dW[co][ci][tap] = sum_{b,y,x} dY[b,co,y,x] * X[b,ci,y+ky-pad,x+kx-pad]
+//   GEMM view: M = co (64 per workgroup = 4 waves x 16), N = (ci, tap) pairs of one CK-channel chunk
+//   (CK*taps = 144 for 3x3 with CK=16: nine 16-wide N blocks, no padding waste), K = pixels.
+//   A workgroup owns one (channel chunk, co block, split) and walks its share of the (sample, 128-pixel tile)
+//   list with the accumulators resident in registers; X is gathered exactly like the forward kernel gathers it
+//   (virtual concat, nearest x2 upsample, pixel-unshuffle, producer's GroupNorm/FiLM affine + SiLU, zero
+//   padding), so the same fused forward needs no materialised im2col / activated tensor for its backward.
+//   Results go to a per-split partial buffer (plain coalesced stores, co fastest); a second kernel reduces the
+//   splits in a fixed order and writes torch layout [co][ci][ky][kx] -> bitwise reproducible (no atomics).
+#include "common.h"
+
+namespace {
+
+struct WgArgs {
+    const float* src0;
+    const float* src1;
+    long long bs0, bs1;
+    int C0v, C1v, C0r, Cin;
+    int B, Hin, Win, Hout, Wout;
+    int Cout;
+    const float* pro_a;
+    const float* pro_b;
+    const float* dy;
+    long long dybs;
+    float* ws;  // [nsplit][taps][Cin][Cout]
+    int tiles_x, ntiles, ncob, nchunks, nsplit;
+};
+
+template <int KS, int CK, int TWL, int MODE>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
+    constexpr int TW = 1 << TWL;
+    constexpr int TH = 128 / TW;
+    constexpr int PAD = KS / 2;
+    constexpr int TRH = TH + KS - 1;
+    constexpr int RS = TW + KS - 1;
+    constexpr int PS = TRH * RS;
+    constexpr int TAPS = KS * KS;
+    constexpr int NN = CK * TAPS;             // (ci, tap) pairs per chunk
+    constexpr int NB = (NN + 15) / 16;        // 16-wide N blocks
+    constexpr int XT = CK * PS + 4;           // + a zero slot
+    constexpr int DYLD = 129;
+    constexpr int NL = (CK * PS + 255) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xt = smem;                 // [CK][TRH][RS] (+ zero slot at CK*PS)
+    float* dyt = smem + XT;           // [64][129]
+    float* protab = dyt + 64 * DYLD;  // [2][C0r] when pro
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int cc = blockIdx.x % a.nchunks;
+    const int cob = (blockIdx.x / a.nchunks) % a.ncob;
+    const int sp = blockIdx.x / (a.nchunks * a.ncob);
+    const int cb = cc * CK, co0 = cob * 64;
+    const int HWin = a.Hin * a.Win, HWo = a.Hout * a.Wout;
+    const bool has_pro = a.pro_a != nullptr;
+
+    // per-lane B-operand bases: n = nb*16 + l15 -> (ci, tap)
+    int bbase[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int n = nb * 16 + l15;
+        const int ci = n / TAPS, tap = n - ci * TAPS;
+        bbase[nb] = n < NN ? ci * PS + (tap / KS) * RS + (tap % KS) : -1;
+    }
+    floatx4 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = floatx4{0.f, 0.f, 0.f, 0.f};
+    if (tid < 4) xt[CK * PS + tid] = 0.f;
+
+    const int total_tiles = a.B * a.ntiles;
+    int cur_b = -1;
+    for (int t = sp; t < total_tiles; t += a.nsplit) {
+        const int b = t / a.ntiles, tile = t - b * a.ntiles;
+        const int y0 = (tile / a.tiles_x) * TH, x0 = (tile % a.tiles_x) * TW;
+        __syncthreads();  // previous tile's LDS reads are done
+        if (has_pro && b != cur_b) {
+            for (int i = tid; i < a.C0r; i += 256) {
+                protab[i] = a.pro_a[(long long)b * a.C0r + i];
+                protab[a.C0r + i] = a.pro_b[(long long)b * a.C0r + i];
+            }
+            cur_b = b;
+            __syncthreads();
+        }
+        // ---- gather the X tile (same semantics as the forward kernel) --------------------------------
+        const float* sample0 = a.src0 + (long long)b * a.bs0;
+        const float* base0 = sample0 + (long long)(MODE == IDIFF_CONV_UNSHUFFLE2 ? (cb >> 2) : cb) * HWin;
+        const float* base1 = a.src1 ? a.src1 + (long long)b * a.bs1 + (long long)(cb - a.C0v) * HWin : sample0;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int e = tid + i * 256;
+            if (e < CK * PS) {
+                const int ci = e / PS;
+                const int rem = e - ci * PS;
+                const int r = rem / RS, c = rem - r * RS;
+                const int oy = y0 - PAD + r, ox = x0 - PAD + c;
+                const int ch = cb + ci;
+                float x = 0.f;
+                if (oy >= 0 && oy < a.Hout && ox >= 0 && ox < a.Wout && ch < a.Cin) {
+                    int off;
+                    if (MODE == IDIFF_CONV_UPSAMPLE2)
+                        off = ci * HWin + (oy >> 1) * a.Win + (ox >> 1);
+                    else if (MODE == IDIFF_CONV_UNSHUFFLE2)
+                        off = (ci >> 2) * HWin + (2 * oy + ((ci >> 1) & 1)) * a.Win + 2 * ox + (ci & 1);
+                    else
+                        off = ci * HWin + oy * a.Win + ox;
+                    x = (ch < a.C0v ? base0 : base1)[off];
+                    if (has_pro) {
+                        const int chr = MODE == IDIFF_CONV_UNSHUFFLE2 ? (ch >> 2) : ch;
+                        x = silu_fast(protab[chr] * x + protab[a.C0r + chr]);
+                    }
+                }
+                xt[e] = x;
+            }
+        }
+        // ---- dY tile [64 co][128 px] --------------------------------------------------------------------
+        const float* dyb = a.dy + (long long)b * a.dybs;
+        for (int e = tid; e < 64 * 128; e += 256) {
+            const int co = e >> 7, p = e & 127;
+            const int oy = y0 + (p >> TWL), ox = x0 + (p & (TW - 1));
+            float v = 0.f;
+            if (co0 + co < a.Cout && oy < a.Hout && ox < a.Wout) v = dyb[(long long)(co0 + co) * HWo + oy * a.Wout + ox];
+            dyt[co * DYLD + p] = v;
+        }
+        __syncthreads();
+        // ---- K loop over the 128 pixels, 4 per MFMA ------------------------------------------------------
+        const float* ar = dyt + (wave * 16 + l15) * DYLD + kq;
+#pragma unroll 4
+        for (int s = 0; s < 32; ++s) {
+            const int p = 4 * s + kq;
+            const int pixoff = (p >> TWL) * RS + (p & (TW - 1));
+            const float av = ar[4 * s];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const float bv = xt[bbase[nb] >= 0 ? bbase[nb] + pixoff : CK * PS];
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[nb], 0, 0, 0);
+            }
+        }
+    }
+    // ---- stage the [NN][64] result through LDS and store it co-fastest into this split's partial --------
+    __syncthreads();
+    float* ot = smem;  // [NB*16][65]
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ot[(nb * 16 + l15) * 65 + wave * 16 + kq * 4 + r] = acc[nb][r];
+    __syncthreads();
+    float* wsp = a.ws + (long long)sp * TAPS * a.Cin * a.Cout;
+    for (int e = tid; e < NN * 64; e += 256) {
+        const int n = e >> 6, co = e & 63;
+        const int ci = n / TAPS, tap = n - ci * TAPS;
+        if (cb + ci < a.Cin && co0 + co < a.Cout) wsp[((long long)tap * a.Cin + cb + ci) * a.Cout + co0 + co] = ot[n * 65 + co];
+    }
+}
+
+// dW[co][ci][tap] (+)= sum_s ws[s][tap][ci][co]   (fixed order -> deterministic)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int taps, int Cin, int Cout, int accumulate) {
+    const long long n = (long long)taps * Cin * Cout;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int co = i % Cout;
+        const int ci = (i / Cout) % Cin;
+        const int tap = i / ((long long)Cout * Cin);
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += ws[(long long)k * n + i];
+        const long long o = ((long long)co * Cin + ci) * taps + tap;
+        dw[o] = accumulate ? dw[o] + s : s;
+    }
+}
+
+inline int wg_pick_twl(int Wout) { return Wout >= 32 ? 5 : (Wout >= 16 ? 4 : 3); }
+
+inline void wg_geometry(int ks, int Cin, int Cout, int B, int Hout, int Wout, int* ck, int* nchunks, int* ncob, int* ntiles, int* tiles_x, int* nsplit) {
+    *ck = ks == 3 ? 16 : (ks == 1 ? 64 : 2);
+    *nchunks = (Cin + *ck - 1) / *ck;
+    *ncob = (Cout + 63) / 64;
+    const int twl = wg_pick_twl(Wout);
+    const int TW = 1 << twl, TH = 128 / TW;
+    *tiles_x = (Wout + TW - 1) / TW;
+    *ntiles = *tiles_x * ((Hout + TH - 1) / TH);
+    const int total_tiles = B * *ntiles;
+    int s = 1536 / (*nchunks * *ncob);
+    if (s < 1) s = 1;
+    if (s > total_tiles) s = total_tiles;
+    *nsplit = s;
+}
+
+template <int KS, int CK, int MODE>
+int launch_wg(const WgArgs& a, int twl, hipStream_t st) {
+    const int TW = 1 << twl, TH = 128 / TW;
+    const int PS = (TH + KS - 1) * (TW + KS - 1);
+    const int NB = (CK * KS * KS + 15) / 16;
+    size_t fl = (size_t)CK * PS + 4 + 64 * 129 + (a.pro_a ? 2 * (size_t)a.C0r : 0);
+    const size_t ot = (size_t)NB * 16 * 65;
+    if (ot > fl) fl = ot;
+    const size_t lds = fl * sizeof(float);
+    if (lds > 160 * 1024) IDIFF_FAIL(IDIFF_E_UNSUPPORTED, "conv2d_wgrad: LDS budget exceeded");
+    dim3 grid(a.nchunks * a.ncob * a.nsplit);
+#define IDIFF_WG_LAUNCH(TWL)                                                                                             \
+    {                                                                                                                    \
+        static size_t attr = 0;                                                                                          \
+        auto kern = conv_wgrad_kernel<KS, CK, TWL, MODE>;                                                                 \
+        if (lds > attr) {                                                                                                \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "conv2d_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e)); \
+            attr = lds;                                                                                                  \
+        }                                                                                                                \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);                                                           \
+    }
+    if (twl == 5) IDIFF_WG_LAUNCH(5) else if (twl == 4) IDIFF_WG_LAUNCH(4) else IDIFF_WG_LAUNCH(3)
+#undef IDIFF_WG_LAUNCH
+    IDIFF_CHECK_LAUNCH("conv2d_wgrad");
+    return IDIFF_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t idiff_conv2d_wgrad_ws_floats(const idiff_conv_desc* d) {
+    if (!d) return -1;
+    const int Cin = (d->mode == IDIFF_CONV_UNSHUFFLE2 ? d->C0 * 4 : d->C0) + d->C1;
+    const int Hout = d->mode == IDIFF_CONV_UPSAMPLE2 ? d->Hin * 2 : (d->mode == IDIFF_CONV_UNSHUFFLE2 ? d->Hin / 2 : d->Hin);
+    const int Wout = d->mode == IDIFF_CONV_UPSAMPLE2 ? d->Win * 2 : (d->mode == IDIFF_CONV_UNSHUFFLE2 ? d->Win / 2 : d->Win);
+    int ck, nch, ncob, nt, tx, ns;
+    wg_geometry(d->ks, Cin, d->Cout, d->B, Hout, Wout, &ck, &nch, &ncob, &nt, &tx, &ns);
+    return (int64_t)ns * d->ks * d->ks * Cin * d->Cout;
+}
+
+extern "C" int idiff_conv2d_wgrad(const idiff_conv_desc* d, const float* dy, int64_t dy_bstride, float* dw, int accumulate, float* ws,
+                                  idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(d && d->src0 && dy && dw && ws, "conv2d_wgrad: null pointer");
+    IDIFF_CHECK_ARG(d->B > 0 && d->C0 > 0 && d->Cout > 0 && d->Hin > 0 && d->Win > 0, "conv2d_wgrad: bad dims");
+    IDIFF_CHECK_ARG(d->ks == 1 || d->ks == 3 || d->ks == 7, "conv2d_wgrad: ks must be 1, 3 or 7");
+    IDIFF_CHECK_ARG((d->C1 > 0) == (d->src1 != nullptr), "conv2d_wgrad: src1/C1 mismatch");
+    IDIFF_CHECK_ARG(!(d->pro_a && d->C1 > 0), "conv2d_wgrad: prologue needs a single source");
+    WgArgs a;
+    a.src0 = d->src0;
+    a.src1 = d->src1;
+    a.bs0 = d->src0_bstride;
+    a.bs1 = d->src1_bstride;
+    a.B = d->B;
+    a.C0r = d->C0;
+    a.Hin = d->Hin;
+    a.Win = d->Win;
+    a.Cout = d->Cout;
+    a.pro_a = d->pro_a;
+    a.pro_b = d->pro_b;
+    a.dy = dy;
+    a.dybs = dy_bstride;
+    a.ws = ws;
+    if (d->mode == IDIFF_CONV_UNSHUFFLE2) {
+        IDIFF_CHECK_ARG(d->ks == 1 && d->C1 == 0, "conv2d_wgrad: unshuffle mode needs ks=1 and a single source");
+        a.C0v = d->C0 * 4;
+        a.C1v = 0;
+        a.Hout = d->Hin / 2;
+        a.Wout = d->Win / 2;
+    } else if (d->mode == IDIFF_CONV_UPSAMPLE2) {
+        a.C0v = d->C0;
+        a.C1v = d->C1;
+        a.Hout = d->Hin * 2;
+        a.Wout = d->Win * 2;
+    } else {
+        a.C0v = d->C0;
+        a.C1v = d->C1;
+        a.Hout = d->Hin;
+        a.Wout = d->Win;
+    }
+    a.Cin = a.C0v + a.C1v;
+    IDIFF_CHECK_ARG(dy_bstride >= (long long)d->Cout * a.Hout * a.Wout, "conv2d_wgrad: dy_bstride too small");
+    int ck;
+    wg_geometry(d->ks, a.Cin, a.Cout, a.B, a.Hout, a.Wout, &ck, &a.nchunks, &a.ncob, &a.ntiles, &a.tiles_x, &a.nsplit);
+    const int twl = wg_pick_twl(a.Wout);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (d->ks == 3) {
+        IDIFF_CHECK_ARG(d->mode != IDIFF_CONV_UNSHUFFLE2, "conv2d_wgrad: unshuffle needs ks=1");
+        rc = d->mode == IDIFF_CONV_NORMAL ? launch_wg<3, 16, IDIFF_CONV_NORMAL>(a, twl, st) : launch_wg<3, 16, IDIFF_CONV_UPSAMPLE2>(a, twl, st);
+    } else if (d->ks == 1) {
+        IDIFF_CHECK_ARG(d->mode != IDIFF_CONV_UPSAMPLE2, "conv2d_wgrad: upsample needs ks=3");
+        rc = d->mode == IDIFF_CONV_NORMAL ? launch_wg<1, 64, IDIFF_CONV_NORMAL>(a, twl, st) : launch_wg<1, 64, IDIFF_CONV_UNSHUFFLE2>(a, twl, st);
+    } else {
+        IDIFF_CHECK_ARG(d->mode == IDIFF_CONV_NORMAL, "conv2d_wgrad: ks=7 needs normal mode");
+        rc = launch_wg<7, 2, IDIFF_CONV_NORMAL>(a, twl, st);
+    }
+    if (rc != IDIFF_OK) return rc;
+    const long long n = (long long)d->ks * d->ks * a.Cin * a.Cout;
+    const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, ws, dw, a.nsplit, d->ks * d->ks, a.Cin, a.Cout, accumulate);
+    IDIFF_CHECK_LAUNCH("conv2d_wgrad_reduce");
+    return IDIFF_OK;
+}

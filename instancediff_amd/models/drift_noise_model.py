@@ -104,9 +104,9 @@ class CLIPDriftModel():
         self.dn_ema = self.nn_ema = None  # created lazily: a deep copy of both nets doubles weight memory (reference :151-152)
         self.grad_sync = None
         if dist and torch.distributed.is_available() and torch.distributed.is_initialized():
-            from ..parallel import FlatGradAllReduce
-            self.grad_sync = FlatGradAllReduce(list(self.drift_net.parameters()) + list(self.noise_net.parameters()))
-            self.grad_sync.broadcast_parameters()
+            from ..parallel import GradSync
+            self.grad_sync = GradSync()
+            self.grad_sync.broadcast_parameters(list(self.drift_net.parameters()) + list(self.noise_net.parameters()))
         if if_train:
             from ..train_ops import FusedAdam
             self.drift_optimizer = FusedAdam(self.drift_net.parameters(), lr=drift_net_lr, weight_decay=weight_decay_drift, betas=(beta1, beta2))

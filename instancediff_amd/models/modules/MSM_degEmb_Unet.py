@@ -32,6 +32,11 @@ def _trunc_normal_(t, std=0.02):
 # prepared-weight cache: packed conv weights, concatenated / transposed linear weights.  Keyed on the
 # parameters' (data_ptr, _version) so optimizer steps and load_state_dict invalidate it.
 # ---------------------------------------------------------------------------------------------------
+def _weight_epoch():
+    from ... import train_ops
+    return train_ops.WEIGHT_EPOCH[0]
+
+
 class _Prepared:
     """per-owner-module cache (weakly keyed, so it dies with the module and ids can never alias)."""
 
@@ -40,7 +45,8 @@ class _Prepared:
 
     def get(self, key, params, build):
         owner, name = key[1], key[0]
-        sig = tuple((p.data_ptr(), p._version) for p in params)
+        # WEIGHT_EPOCH: the fused Adam kernel rewrites parameters through raw pointers (no _version bump)
+        sig = (_weight_epoch(),) + tuple((p.data_ptr(), p._version) for p in params)
         slot = self.store.setdefault(owner, {})
         hit = slot.get(name)
         if hit is not None and hit[0] == sig:
@@ -149,7 +155,7 @@ class ScoreMapModule(nn.Module):
     # ---- text branch (frozen encoder: out of the accelerated scope, cached at inference) ---------
     def text_embeddings(self, text_encoder, B):
         if not torch.is_grad_enabled() or not self.contexts.requires_grad:
-            key = (B, self.contexts.data_ptr(), self.contexts._version)
+            key = (B, self.contexts.data_ptr(), self.contexts._version, _weight_epoch())
             c = self._text_cache
             if c is not None and c[0] == key and c[2]() is text_encoder:
                 return c[1]
@@ -430,7 +436,7 @@ class LearnableForwardUNet_MultiScoreMap(nn.Module):
     def _ctx_vecs(self, ctx):
         """single-token image context: per-block vectors, cached across denoising steps (ctx is constant)."""
         cas = self.cross_attns()
-        key = (ctx._version, tuple(ctx.shape)) + tuple((p.data_ptr(), p._version) for ca in cas
+        key = (ctx._version, tuple(ctx.shape), _weight_epoch()) + tuple((p.data_ptr(), p._version) for ca in cas
                                                         for p in (ca.v_proj.weight, ca.proj.weight, ca.proj.bias))
         c = self._ctx_cache
         if c is not None and c[0] == key and c[2]() is ctx:

@@ -1,0 +1,195 @@
+"""Training-mode forward of `LearnableForwardUNet_MultiScoreMap`: the same network as forward_infer, composed of
+autograd Functions (instancediff_amd/train_ops.py) whose forward and backward are the HIP kernels.  ResBlocks keep
+the inference fusion (one Function, hand-written backward); attention / ScoreMapModule chains are expressed with
+batched-GEMM + softmax + LayerNorm Functions so that autograd derives their backward from those primitives."""
+import torch
+
+from ... import ops
+from ...train_ops import (ActFn, AddFn, AddVecFn, BgemmFn, ChanLayerNormFn, ChanNormalizeFn, ConvFn, GatherChannelFn, LayerNormRowsFn,
+                          LinearFn, ResBlockFn, ScaleColsFn, SoftmaxRowsFn)
+
+
+def _resblock(rb, src0, src1, temb_act, vec=None):
+    import torch.nn as nn
+    film = LinearFn.apply(temb_act, rb.mlp.weight, rb.mlp.bias)
+    ident = isinstance(rb.res_conv, nn.Identity)
+    return ResBlockFn.apply(src0, src1, film, vec, rb.conv1.weight, rb.conv1.bias, rb.norm1.weight, rb.norm1.bias, rb.conv2.weight,
+                            rb.conv2.bias, rb.norm2.weight, rb.norm2.bias, None if ident else rb.res_conv.weight,
+                            None if ident else rb.res_conv.bias, rb.groups, rb.norm1.eps)
+
+
+def _heads_attention(q3, k3, v3, heads, scale):
+    """token-major attention from batched GEMMs: q3 [B,Nq,C], k3/v3 [B,M,C] -> [B,Nq,C]"""
+    C = q3.shape[-1]
+    dh = C // heads
+    outs = []
+    for h in range(heads):
+        sl = slice(h * dh, (h + 1) * dh)
+        s = BgemmFn.apply(q3[:, :, sl], k3[:, :, sl], False, True)  # [B,Nq,M]
+        p = SoftmaxRowsFn.apply(s, scale)
+        outs.append(BgemmFn.apply(p, v3[:, :, sl], False, False))   # [B,Nq,dh]
+    return torch.cat(outs, dim=-1)
+
+
+def _ca_vec(ca, ctx):
+    """single-token image context: proj(v_proj(ctx)) as a per-(sample, channel) vector"""
+    B = ctx.shape[0]
+    v = LinearFn.apply(ctx.reshape(B, -1), ca.v_proj.weight, None)
+    return LinearFn.apply(v, ca.proj.weight.reshape(ca.dim, ca.dim), ca.proj.bias)
+
+
+def _ca_general(ca, x, ctx):
+    """x + proj(attention(q_proj(norm(x)), k_proj(ctx), v_proj(ctx))) for M > 1 context tokens (channel-major maps)"""
+    B, C, H, W = x.shape
+    M, N, heads = ctx.shape[1], H * W, ca.num_heads
+    dh = C // heads
+    xn = ChanLayerNormFn.apply(x, ca.norm.weight, ca.norm.bias, 1e-5)
+    q = ConvFn.apply(xn, None, ca.q_proj.weight, None, 1, ops.CONV_NORMAL).reshape(B, C, N)
+    c2 = ctx.reshape(B * M, -1)
+    k = LinearFn.apply(c2, ca.k_proj.weight, None).reshape(B, M, C)
+    v = LinearFn.apply(c2, ca.v_proj.weight, None).reshape(B, M, C)
+    outs = []
+    for h in range(heads):
+        sl = slice(h * dh, (h + 1) * dh)
+        s = BgemmFn.apply(q[:, sl, :], k[:, :, sl], True, True)        # q_h stored [dh][N] -> [N,dh] . [dh,M]
+        p = SoftmaxRowsFn.apply(s, ca.scale)                             # [B,N,M]
+        outs.append(BgemmFn.apply(v[:, :, sl], p, True, True))           # [dh,M] . [M,N] -> [B,dh,N]
+    o = torch.cat(outs, dim=1).reshape(B, C, H, W)
+    return AddFn.apply(x, ConvFn.apply(o, None, ca.proj.weight, ca.proj.bias, 1, ops.CONV_NORMAL), 1.0)
+
+
+def _self_attention(sa, x, vec=None):
+    B, C, H, W = x.shape
+    N, heads = H * W, sa.num_heads
+    dh = C // heads
+    xn = ChanLayerNormFn.apply(x, sa.norm.weight, sa.norm.bias, 1e-5)
+    qkv = ConvFn.apply(xn, None, sa.qkv.weight, None, 1, ops.CONV_NORMAL).reshape(B, 3, heads, dh, N)
+    q = qkv[:, 0].reshape(B * heads, dh, N)
+    k = qkv[:, 1].reshape(B * heads, dh, N)
+    v = qkv[:, 2].reshape(B * heads, dh, N)
+    s = BgemmFn.apply(q, k, True, False)            # [N_q, dh] . [dh, N_k]
+    p = SoftmaxRowsFn.apply(s, sa.scale)            # [BH, N_q, N_k]
+    o = BgemmFn.apply(v, p, False, True)            # [dh, N_k] . [N_k, N_q] -> channel-major [BH, dh, N_q]
+    o = o.reshape(B, C, H, W)
+    y = AddFn.apply(x, ConvFn.apply(o, None, sa.proj.weight, sa.proj.bias, 1, ops.CONV_NORMAL), 1.0)
+    return AddVecFn.apply(y, vec) if vec is not None else y
+
+
+def _smm(smm, feat, text_encoder, idx):
+    """ScoreMapModule forward in Function form -> (score [B,K,h,w], sel [B,1,h,w])"""
+    B, C, H, W = feat.shape
+    K, N = smm.n_cls, H * W
+    dec = smm.context_decoder
+    Wd, heads = dec.width, dec.heads
+    dh = Wd // heads
+    text = smm.text_embeddings(text_encoder, B)
+    t2d = text.reshape(B * K, smm.text_dim)
+    mp = dec.memory_proj
+    fn = ChanLayerNormFn.apply(feat, mp[0].weight, mp[0].bias, mp[0].eps)
+    m1 = ConvFn.apply(fn, None, mp[1].weight.reshape(Wd, C, 1, 1), mp[1].bias, 1, ops.CONV_NORMAL)
+    mem = ChanLayerNormFn.apply(m1, mp[2].weight, mp[2].bias, mp[2].eps).reshape(B, Wd, N)
+    tp = dec.text_proj
+    x = LinearFn.apply(LayerNormRowsFn.apply(t2d, tp[0].weight, tp[0].bias, tp[0].eps), tp[1].weight, tp[1].bias)
+    R = B * K
+    for layer in dec.decoder:
+        sa, ca = layer.self_attn, layer.cross_attn
+        n1 = LayerNormRowsFn.apply(x, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
+        q = LinearFn.apply(n1, sa.q_proj.weight, None).reshape(B, K, Wd)
+        k = LinearFn.apply(n1, sa.k_proj.weight, None).reshape(B, K, Wd)
+        v = LinearFn.apply(n1, sa.v_proj.weight, None).reshape(B, K, Wd)
+        a = _heads_attention(q, k, v, heads, sa.scale).reshape(R, Wd)
+        x = AddFn.apply(x, LinearFn.apply(a, sa.proj.weight, sa.proj.bias), 1.0)
+        n2 = LayerNormRowsFn.apply(x, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
+        qc = LinearFn.apply(n2, ca.q_proj.weight, None)  # [R, Wd]
+        avs = []
+        for h in range(heads):
+            sl = slice(h * dh, (h + 1) * dh)
+            # k/v projections folded onto the queries: qf = q_h Wk_h ; S = qf mem ; o = P mem^T ; av_h = o Wv_h^T
+            qf = BgemmFn.apply(qc[:, sl].unsqueeze(0), ca.k_proj.weight[sl].unsqueeze(0), False, False).reshape(B, K, Wd)
+            s = BgemmFn.apply(qf, mem, False, False)               # [B,K,N]
+            p = SoftmaxRowsFn.apply(s, ca.scale)
+            o = BgemmFn.apply(p, mem, False, True).reshape(1, R, Wd)  # [B,K,Wd]
+            avs.append(BgemmFn.apply(o, ca.v_proj.weight[sl].unsqueeze(0), False, True).reshape(R, dh))
+        av = torch.cat(avs, dim=-1)
+        x = AddFn.apply(x, LinearFn.apply(av, ca.proj.weight, ca.proj.bias), 1.0)
+        n3 = LayerNormRowsFn.apply(x, layer.norm3.weight, layer.norm3.bias, layer.norm3.eps)
+        hm = ActFn.apply(LinearFn.apply(n3, layer.mlp[0].weight, layer.mlp[0].bias), ops.ACT_GELU)
+        x = AddFn.apply(x, LinearFn.apply(hm, layer.mlp[3].weight, layer.mlp[3].bias), 1.0)
+    op = dec.out_proj
+    diff = LinearFn.apply(LayerNormRowsFn.apply(x, op[0].weight, op[0].bias, op[0].eps), op[1].weight, op[1].bias)  # [R, C]
+    t2v = LinearFn.apply(t2d, smm.text_to_visual.weight, smm.text_to_visual.bias)
+    tv = AddFn.apply(t2v, ScaleColsFn.apply(diff, smm.gamma), 1.0)
+    tvn = ChanNormalizeFn.apply(tv.reshape(R, C, 1)).reshape(B, K, C)
+    fnm = ChanNormalizeFn.apply(feat).reshape(B, C, N)
+    score = BgemmFn.apply(tvn, fnm, False, False).reshape(B, K, H, W)
+    sel = GatherChannelFn.apply(score, idx)
+    return score, sel
+
+
+def forward_train(net, x_a, x_b, t, names, text_encoder, image_context=None):
+    dev = x_a.device
+    B, _, H, W = x_a.shape
+    if not torch.is_tensor(t):
+        t = torch.full((B,), float(t), dtype=torch.float32, device=dev)
+    t = t.reshape(-1).to(device=dev, dtype=torch.float32)
+    if t.numel() == 1 and B > 1:
+        t = t.expand(B)
+    t = t.contiguous()
+    idx = net.class_index(names, dev)
+    ctx = image_context.contiguous() if (net.use_image_context and image_context is not None) else None
+    single = ctx is not None and ctx.shape[1] == 1
+    general = ctx is not None and not single
+
+    def vec_of(holder, name):
+        return _ca_vec(getattr(holder, name), ctx) if single else None
+
+    temb0 = ops.time_embed(t, net.nf, net.time_freqs)
+    hmid = ActFn.apply(LinearFn.apply(temb0, net.time_mlp[0].weight, net.time_mlp[0].bias), ops.ACT_GELU)
+    temb = LinearFn.apply(hmid, net.time_mlp[2].weight, net.time_mlp[2].bias)
+    tact = ActFn.apply(temb, ops.ACT_SILU)
+
+    x = ConvFn.apply(x_a.contiguous(), x_b.contiguous(), net.init_conv.weight, net.init_conv.bias, 7, ops.CONV_NORMAL)
+    x_ = x
+    hs, sms = [], []
+    use_sm = net.CLIP_ScoreMapModule is not None
+    for i, lv in enumerate(net.downs):
+        x = _resblock(lv.res1, x, None, tact, vec_of(lv, "ca1"))
+        if general:
+            x = _ca_general(lv.ca1, x, ctx)
+        hs.append(x)
+        x = _resblock(lv.res2, x, None, tact, vec_of(lv, "ca2"))
+        if general:
+            x = _ca_general(lv.ca2, x, ctx)
+        if use_sm:
+            score, sel = _smm(net.CLIP_ScoreMapModule[i], x, text_encoder, idx)
+            sms.append(sel)
+            emb = ConvFn.apply(score, None, net.sm_embed[i].weight, net.sm_embed[i].bias, 3, ops.CONV_NORMAL)
+            hs.append(("cat", x, emb))
+        else:
+            hs.append(x)
+        down = lv.down
+        mode = ops.CONV_UNSHUFFLE2 if type(down).__name__ == "Downsample" else ops.CONV_NORMAL
+        x = ConvFn.apply(x, None, down.conv.weight, down.conv.bias, 1 if mode == ops.CONV_UNSHUFFLE2 else 3, mode)
+    x = _resblock(net.mid_res1, x, None, tact)
+    x = _self_attention(net.mid_attn, x, vec_of(net, "mid_ca"))
+    if general:
+        x = _ca_general(net.mid_ca, x, ctx)
+    x = _resblock(net.mid_res2, x, None, tact)
+    for up in net.ups:
+        skip = hs.pop()
+        skip = torch.cat([skip[1], skip[2]], dim=1) if isinstance(skip, tuple) else skip
+        x = _resblock(up.res1, x, skip, tact, vec_of(up, "ca1"))
+        if general:
+            x = _ca_general(up.ca1, x, ctx)
+        x = _resblock(up.res2, x, hs.pop(), tact, vec_of(up, "ca2"))
+        if general:
+            x = _ca_general(up.ca2, x, ctx)
+        u = up.up
+        mode = ops.CONV_UPSAMPLE2 if type(u).__name__ == "Upsample" else ops.CONV_NORMAL
+        x = ConvFn.apply(x, None, u.conv.weight, u.conv.bias, 3, mode)
+    x = _resblock(net.final_res, x, x_, tact)
+    out = ConvFn.apply(x, None, net.final_conv.weight, net.final_conv.bias, 3, ops.CONV_NORMAL)
+    pred = GatherChannelFn.apply(out, idx)
+    if net.text_module == "scoremap":
+        return pred, sms
+    return pred

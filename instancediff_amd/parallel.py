@@ -41,6 +41,31 @@ def shard_indices(n, rank, world):
     return list(range(n))[rank::world]
 
 
+class GradSync:
+    """Data-parallel exchange for optimizers that already own flat gradient buffers (train_ops.FusedAdam):
+    one all-reduce(SUM) per flat buffer per step; the 1/world average is folded into the fused Adam kernel."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    @torch.no_grad()
+    def broadcast_parameters(self, params, src=0):
+        if self.world <= 1:
+            return
+        for p in params:
+            dist.broadcast(p.data, src=src, group=self.group)
+
+    @torch.no_grad()
+    def all_reduce_flat(self, flats):
+        """SUM every flat gradient buffer over the ranks; returns the scale (1/world) still to be applied."""
+        if self.world <= 1:
+            return 1.0
+        for f in flats:
+            dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group)
+        return 1.0 / self.world
+
+
 class FlatGradAllReduce:
     """Owns one flat gradient buffer; every parameter's .grad is a view into it."""
 

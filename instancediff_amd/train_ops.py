@@ -1,0 +1,608 @@
+"""Training path: autograd Functions whose forward AND backward are the hand-written HIP kernels of
+include/idiff.h, the fused Adam optimizer and the `optimize_parameters_inputRes` train step
+(models/drift_noise_model.py:242-312).  torch.autograd only routes gradients between these Functions; no
+gradient arithmetic runs in ATen except autograd's own accumulation of fan-in gradients."""
+import ctypes as C
+
+import torch
+
+from . import _lib, ops
+from ._lib import ConvDesc, check
+from .ops import _bs, _c, _chk, _p, _stream
+
+# bumped whenever weights are modified behind torch's back (fused Adam writes parameters in place through raw
+# pointers, which does not bump tensor._version); prepared-weight caches include it in their signature
+WEIGHT_EPOCH = [0]
+
+
+# =====================================================================================================
+# raw wrappers of the training kernels
+# =====================================================================================================
+def _conv_desc(src0, src1, mode, ks, Cout, pro=None):
+    B, C0, Hin, Win = src0.shape
+    d = ConvDesc()
+    d.src0, d.src0_bstride, d.C0 = src0.data_ptr(), _bs(src0, "src0"), C0
+    if src1 is not None:
+        d.src1, d.src1_bstride, d.C1 = src1.data_ptr(), _bs(src1, "src1"), src1.shape[1]
+    d.B, d.Hin, d.Win, d.mode, d.ks, d.Cout = B, Hin, Win, mode, ks, Cout
+    if pro is not None:
+        d.pro_a, d.pro_b = _c(pro[0]).data_ptr(), _c(pro[1]).data_ptr()
+    return d
+
+
+def conv2d_wgrad(src0, src1, mode, ks, dy, Cin, pro=None, dw=None, accumulate=False):
+    """dW [Cout, Cin, ks, ks] of conv2d(src0 (+src1), mode, ks, pro) given dy."""
+    lib = _lib.load()
+    Cout = dy.shape[1]
+    d = _conv_desc(src0, src1, mode, ks, Cout, pro)
+    nws = lib.idiff_conv2d_wgrad_ws_floats(C.byref(d))
+    ws = torch.empty((nws,), device=dy.device, dtype=torch.float32)
+    if dw is None:
+        dw = torch.empty((Cout, Cin, ks, ks), device=dy.device, dtype=torch.float32)
+        accumulate = False
+    check(lib.idiff_conv2d_wgrad(C.byref(d), _p(dy), _bs(dy, "dy"), _p(_c(dw)), 1 if accumulate else 0, _p(ws), _stream()), "conv2d_wgrad")
+    return dw
+
+
+def conv2d_dgrad(dy, weight, ks, mode, Cin_virtual, res=None):
+    """data gradient w.r.t. the (virtual) conv input: [B, Cin_v, Hout, Wout]; the caller undoes upsample/unshuffle."""
+    wT = ops.pack_conv_weight(weight.detach().contiguous(), transpose=True)
+    return ops.conv2d(dy, wT, None, ks, Cin_virtual, res=res)
+
+
+def channel_sums(x, per_sample=False):
+    """sum over pixels (and batch unless per_sample): [C] or [B,C]"""
+    lib = _lib.load()
+    B, Cc, H, W = x.shape
+    bc = torch.empty((B, Cc), device=x.device, dtype=torch.float32)
+    check(lib.idiff_plane_sum(_p(x), _bs(x, "x"), _p(bc), B, Cc, H * W, _stream()), "plane_sum")
+    if per_sample:
+        return bc
+    out = torch.empty((Cc,), device=x.device, dtype=torch.float32)
+    check(lib.idiff_batch_sum(_p(bc), _p(out), B, Cc, 0, _stream()), "batch_sum")
+    return out
+
+
+def sumpool2x2(x):
+    lib = _lib.load()
+    _c(x)
+    B, Cc, H2, W2 = x.shape
+    out = torch.empty((B, Cc, H2 // 2, W2 // 2), device=x.device, dtype=torch.float32)
+    check(lib.idiff_sumpool2x2(_p(x), _p(out), B * Cc, H2 // 2, W2 // 2, _stream()), "sumpool2x2")
+    return out
+
+
+def pixel_shuffle2(x):
+    lib = _lib.load()
+    _c(x)
+    B, C4, h, w = x.shape
+    out = torch.empty((B, C4 // 4, 2 * h, 2 * w), device=x.device, dtype=torch.float32)
+    check(lib.idiff_pixel_shuffle2(_p(x), _p(out), B, C4 // 4, h, w, _stream()), "pixel_shuffle2")
+    return out
+
+
+def gn_silu_bwd(dy, h, a, b, mean_rstd, gamma, beta, film, groups):
+    """-> dh, dgamma, dbeta, dfilm (or None)"""
+    lib = _lib.load()
+    B, Cc, H, W = h.shape
+    dh = torch.empty((B, Cc, H, W), device=h.device, dtype=torch.float32)
+    dgamma = torch.empty((Cc,), device=h.device, dtype=torch.float32)
+    dbeta = torch.empty_like(dgamma)
+    dfilm = torch.empty((B, 2 * Cc), device=h.device, dtype=torch.float32) if film is not None else None
+    ws = torch.empty((lib.idiff_gn_silu_bwd_ws_floats(B, Cc, groups),), device=h.device, dtype=torch.float32)
+    check(lib.idiff_gn_silu_bwd(_p(dy), _bs(dy, "dy"), _p(h), _bs(h, "h"), _p(_c(a)), _p(_c(b)), _p(_c(mean_rstd)), _p(_c(gamma)), _p(_c(beta)),
+                                _p(film), film.stride(0) if film is not None else 0, _p(dh), _bs(dh), _p(dgamma), _p(dbeta), _p(dfilm),
+                                2 * Cc, _p(ws), B, Cc, groups, H * W, 0, _stream()), "gn_silu_bwd")
+    return dh, dgamma, dbeta, dfilm
+
+
+def bgemm(A, B, M, N, K, lda, ldb, transA, transB, sA, sB, batch, out=None, alpha=1.0, beta=0.0):
+    lib = _lib.load()
+    _chk(A), _chk(B)
+    if out is None:
+        out = torch.empty((batch, M, N), device=A.device, dtype=torch.float32)
+    check(lib.idiff_bgemm(_p(A), _p(B), _p(out), M, N, K, lda, ldb, N, 1 if transA else 0, 1 if transB else 0, sA, sB, M * N, batch, alpha, beta,
+                          _stream()), "bgemm")
+    return out
+
+
+# =====================================================================================================
+# autograd Functions
+# =====================================================================================================
+def _packed(w):
+    return ops.pack_conv_weight(w.detach().contiguous())
+
+
+class ConvFn(torch.autograd.Function):
+    """plain conv (virtual concat / upsample / unshuffle gather modes), bias; no fused prologue/epilogue."""
+
+    @staticmethod
+    def forward(ctx, src0, src1, weight, bias, ks, mode):
+        Cout = weight.shape[0]
+        out = ops.conv2d(src0, _packed(weight), bias, ks, Cout, src1=src1, mode=mode)
+        ctx.save_for_backward(src0, src1, weight)
+        ctx.ks, ctx.mode, ctx.has_bias = ks, mode, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        src0, src1, weight = ctx.saved_tensors
+        dout = dout.contiguous()
+        ks, mode = ctx.ks, ctx.mode
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        C0 = src0.shape[1]
+        d0 = d1 = None
+        if ctx.needs_input_grad[0] or (src1 is not None and ctx.needs_input_grad[1]):
+            dxv = conv2d_dgrad(dout, weight, ks, mode, Cin)
+            if mode == ops.CONV_UPSAMPLE2:
+                dxv = sumpool2x2(dxv)
+            elif mode == ops.CONV_UNSHUFFLE2:
+                dxv = pixel_shuffle2(dxv)
+            d0 = dxv[:, :C0] if src1 is not None else dxv
+            d1 = dxv[:, C0:] if src1 is not None else None
+        dw = conv2d_wgrad(src0, src1, mode, ks, dout, Cin) if ctx.needs_input_grad[2] else None
+        db = channel_sums(dout) if ctx.has_bias and ctx.needs_input_grad[3] else None
+        return d0, d1, dw, db, None, None
+
+
+class ResBlockFn(torch.autograd.Function):
+    """conv3x3 -> GN -> FiLM -> SiLU -> conv3x3 -> GN -> SiLU, + res(cat(src0,src1)) + vec, fused exactly like the
+    inference path (GN statistics in the conv epilogue, normalise+SiLU in the next conv's gather)."""
+
+    @staticmethod
+    def forward(ctx, src0, src1, film, vec, w1, b1, g1, be1, w2, b2, g2, be2, wr, br, groups, eps):
+        B, _, H, W = src0.shape
+        Co, HW = w1.shape[0], H * W
+        h1, st1 = ops.conv2d(src0, _packed(w1), b1, 3, Co, src1=src1, want_stats=True)
+        a1, c1, mr1 = ops.gn_finalize(st1, groups, HW, g1, be1, film=film, eps=eps, want_mean_rstd=True)
+        h2, st2 = ops.conv2d(h1, _packed(w2), b2, 3, Co, pro=(a1, c1), want_stats=True)
+        a2, c2, mr2 = ops.gn_finalize(st2, groups, HW, g2, be2, eps=eps, want_mean_rstd=True)
+        if wr is None:
+            out = ops.affine_silu_add(h2, (a2, c2), res=src0, vec=vec)
+        else:
+            out = ops.conv2d(src0, _packed(wr), br, 1, Co, src1=src1, aux=(h2, a2, c2), vec=vec)
+        ctx.save_for_backward(src0, src1, film, w1, g1, be1, w2, g2, be2, wr, h1, h2, a1, c1, mr1, a2, c2, mr2)
+        ctx.groups, ctx.has_vec = groups, vec is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        src0, src1, film, w1, g1, be1, w2, g2, be2, wr, h1, h2, a1, c1, mr1, a2, c2, mr2 = ctx.saved_tensors
+        G = ctx.groups
+        dout = dout.contiguous()
+        Co = w1.shape[0]
+        C0 = src0.shape[1]
+        Cin = w1.shape[1]
+        dvec = channel_sums(dout, per_sample=True) if ctx.has_vec else None
+        # tail: out = silu(a2*h2+c2) + res(x) + vec
+        dh2, dg2, dbe2, _ = gn_silu_bwd(dout, h2, a2, c2, mr2, g2, be2, None, G)
+        db2 = channel_sums(dh2)
+        dw2 = conv2d_wgrad(h1, None, ops.CONV_NORMAL, 3, dh2, Co, pro=(a1, c1))
+        dact1 = conv2d_dgrad(dh2, w2, 3, ops.CONV_NORMAL, Co)
+        dh1, dg1, dbe1, dfilm = gn_silu_bwd(dact1, h1, a1, c1, mr1, g1, be1, film, G)
+        db1 = channel_sums(dh1)
+        dw1 = conv2d_wgrad(src0, src1, ops.CONV_NORMAL, 3, dh1, Cin)
+        if wr is None:
+            dres = dout  # identity residual (single source)
+            dwr = dbr = None
+        else:
+            dres = conv2d_dgrad(dout, wr, 1, ops.CONV_NORMAL, Cin)
+            dwr = conv2d_wgrad(src0, src1, ops.CONV_NORMAL, 1, dout, Cin)
+            dbr = channel_sums(dout)
+        dx = conv2d_dgrad(dh1, w1, 3, ops.CONV_NORMAL, Cin, res=dres)
+        d0 = dx[:, :C0] if src1 is not None else dx
+        d1 = dx[:, C0:] if src1 is not None else None
+        return d0, d1, dfilm, dvec, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, dwr, dbr, None, None
+
+
+class BgemmFn(torch.autograd.Function):
+    """C[b] = op(A[b]) . op(B[b]); A, B are 3-D [batch, rows, cols] row-major (possibly strided views with unit
+    inner stride); transX -> the stored matrix is the transpose of the operand."""
+
+    @staticmethod
+    def forward(ctx, A, B, transA, transB):
+        batch = A.shape[0]
+        M, K = (A.shape[2], A.shape[1]) if transA else (A.shape[1], A.shape[2])
+        N = B.shape[1] if transB else B.shape[2]
+        assert A.stride(2) == 1 and B.stride(2) == 1 and B.shape[0] == batch
+        out = bgemm(A, B, M, N, K, A.stride(1), B.stride(1), transA, transB, A.stride(0), B.stride(0), batch)
+        ctx.save_for_backward(A, B)
+        ctx.tA, ctx.tB, ctx.dims = transA, transB, (M, N, K, batch)
+        return out
+
+    @staticmethod
+    def backward(ctx, dC):
+        A, B = ctx.saved_tensors
+        tA, tB = ctx.tA, ctx.tB
+        M, N, K, batch = ctx.dims
+        dC = dC.contiguous()
+        dA = dB = None
+        if ctx.needs_input_grad[0]:
+            if not tA:  # dA [M,K] = dC [M,N] . op(B)^T [N,K]
+                dA = bgemm(dC, B, M, K, N, N, B.stride(1), False, not tB, M * N, B.stride(0), batch)
+            else:       # dA stored [K,M] = op(B) [K,N] . dC^T [N,M]
+                dA = bgemm(B, dC, K, M, N, B.stride(1), N, tB, True, B.stride(0), M * N, batch)
+        if ctx.needs_input_grad[1]:
+            if not tB:  # dB [K,N] = op(A)^T [K,M] . dC [M,N]
+                dB = bgemm(A, dC, K, N, M, A.stride(1), N, not tA, False, A.stride(0), M * N, batch)
+            else:       # dB stored [N,K] = dC^T [N,M] . op(A) [M,K]
+                dB = bgemm(dC, A, N, K, M, N, A.stride(1), True, tA, M * N, A.stride(0), batch)
+        return dA, dB, None, None
+
+
+class SoftmaxRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        lib = _lib.load()
+        _c(x)
+        N = x.shape[-1]
+        R = x.numel() // N
+        p = torch.empty_like(x)
+        check(lib.idiff_softmax_rows_fwd(_p(x), N, _p(p), N, R, N, scale, _stream()), "softmax_rows_fwd")
+        ctx.save_for_backward(p)
+        ctx.scale = scale
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        lib = _lib.load()
+        (p,) = ctx.saved_tensors
+        dp = dp.contiguous()
+        N = p.shape[-1]
+        R = p.numel() // N
+        ds = torch.empty_like(p)
+        check(lib.idiff_softmax_rows_bwd(_p(p), N, _p(dp), N, _p(ds), N, R, N, ctx.scale, _stream()), "softmax_rows_bwd")
+        return ds, None
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b on token rows ([R,K] x [N,K]); x may be a column slice (row-strided)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        y = ops.linear(x, w, b)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous() if dy.stride(-1) != 1 else dy
+        R, K = x.shape
+        N = w.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear_t(dy, w)  # w [N,K] is the transposed-weight form of the map dy -> dx
+        if ctx.needs_input_grad[1]:
+            dw = bgemm(dy, x, N, K, R, dy.stride(0), x.stride(0), True, False, 0, 0, 1).reshape(N, K)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty((N,), device=dy.device, dtype=torch.float32)
+            check(lib.idiff_colsum(_p(dy), dy.stride(0), _p(db), R, N, 0, _stream()), "colsum")
+        return dx, dw, db
+
+
+class LayerNormRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = x if x.stride(-1) == 1 else x.contiguous()
+        y, mr = ops.layernorm_rows(x, gamma, beta, eps, want_mean_rstd=True)
+        ctx.save_for_backward(x, gamma, mr)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, gamma, mr = ctx.saved_tensors
+        dy = dy.contiguous()
+        R, Cc = x.shape
+        dx = torch.empty((R, Cc), device=x.device, dtype=torch.float32)
+        dg = torch.empty((Cc,), device=x.device, dtype=torch.float32)
+        db = torch.empty_like(dg)
+        check(lib.idiff_layernorm_rows_bwd(_p(dy), Cc, _p(x), x.stride(0), _p(_c(gamma)), _p(mr), _p(dx), Cc, _p(dg), _p(db), R, Cc, 0, _stream()),
+              "layernorm_rows_bwd")
+        return dx, dg, db, None
+
+
+class ChanLayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        y, mr = ops.chan_layernorm(x, gamma, beta, eps, want_mean_rstd=True)
+        ctx.save_for_backward(x, gamma, mr)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, gamma, mr = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, Cc, H, W = x.shape
+        dx = torch.empty((B, Cc, H, W), device=x.device, dtype=torch.float32)
+        dg = torch.empty((Cc,), device=x.device, dtype=torch.float32)
+        db = torch.empty_like(dg)
+        ws = torch.empty((2 * B * Cc,), device=x.device, dtype=torch.float32)
+        check(lib.idiff_chan_layernorm_bwd(_p(dy), _bs(dy), _p(x), _bs(x, "x"), _p(_c(gamma)), _p(mr), _p(dx), _bs(dx), _p(dg), _p(db), _p(ws), B,
+                                           Cc, H * W, 0, _stream()), "chan_layernorm_bwd")
+        return dx, dg, db, None
+
+
+class ChanNormalizeFn(torch.autograd.Function):
+    """F.normalize(x, dim=1) on [B,C,*] maps (thread = pixel); also used for token rows viewed as [R,C,1]."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        B, Cc = x.shape[:2]
+        HW = x.numel() // (B * Cc)
+        y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+        nrm = torch.empty((B, HW), device=x.device, dtype=torch.float32)
+        check(lib.idiff_chan_normalize_fwd(_p(x), _bs(x, "x") if x.dim() == 4 else Cc * HW, _p(y), _p(nrm), B, Cc, HW, _stream()),
+              "chan_normalize_fwd")
+        ctx.save_for_backward(y, nrm)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        y, nrm = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, Cc = y.shape[:2]
+        HW = y.numel() // (B * Cc)
+        dx = torch.empty(y.shape, device=y.device, dtype=torch.float32)
+        check(lib.idiff_chan_normalize_bwd(_p(dy), _p(y), _p(nrm), _p(dx), Cc * HW, B, Cc, HW, _stream()), "chan_normalize_bwd")
+        return dx
+
+
+class ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        lib = _lib.load()
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        check(lib.idiff_act_fwd(_p(x), _p(y), x.numel(), act, _stream()), "act_fwd")
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        check(lib.idiff_act_bwd(_p(dy), _p(x), _p(dx), x.numel(), ctx.act, _stream()), "act_bwd")
+        return dx, None
+
+
+class AddFn(torch.autograd.Function):
+    """a + alpha*b (same shape, contiguous)"""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        ctx.alpha = alpha
+        return ops.axpby(a.contiguous(), b.contiguous(), 1.0, alpha)
+
+    @staticmethod
+    def backward(ctx, d):
+        d = d.contiguous()
+        db = d if ctx.alpha == 1.0 else ops.axpby(d, d, ctx.alpha, 0.0)
+        return d, db, None
+
+
+class AddVecFn(torch.autograd.Function):
+    """x[b,c,:,:] + vec[b,c]"""
+
+    @staticmethod
+    def forward(ctx, x, vec):
+        return ops.affine_silu_add(x, None, vec=vec.contiguous())
+
+    @staticmethod
+    def backward(ctx, d):
+        d = d.contiguous()
+        return d, channel_sums(d, per_sample=True)
+
+
+class ScaleColsFn(torch.autograd.Function):
+    """y[r, n] = g[n] * x[r, n]  (ScoreMapModule gamma)"""
+
+    @staticmethod
+    def forward(ctx, x, g):
+        lib = _lib.load()
+        x = x.contiguous()
+        ctx.save_for_backward(x, g)
+        R, N = x.shape
+        y = torch.empty_like(x)
+        check(lib.idiff_scale_cols(_p(x), _p(_c(g)), _p(y), R, N, _stream()), "scale_cols")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, g = ctx.saved_tensors
+        dy = dy.contiguous()
+        R, N = x.shape
+        dx = torch.empty_like(x)
+        check(lib.idiff_scale_cols(_p(dy), _p(g), _p(dx), R, N, _stream()), "scale_cols")
+        dg = torch.empty((N,), device=x.device, dtype=torch.float32)
+        check(lib.idiff_colsum_prod(_p(dy), _p(x), _p(dg), R, N, _stream()), "colsum_prod")
+        return dx, dg
+
+
+class GatherChannelFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.save_for_backward(idx)
+        ctx.C = x.shape[1]
+        return ops.gather_channel(x.contiguous(), idx)
+
+    @staticmethod
+    def backward(ctx, d):
+        lib = _lib.load()
+        (idx,) = ctx.saved_tensors
+        d = d.contiguous()
+        B, _, H, W = d.shape
+        out = torch.empty((B, ctx.C, H, W), device=d.device, dtype=torch.float32)
+        check(lib.idiff_scatter_channel(_p(d), _p(idx), _p(out), B, ctx.C, H * W, _stream()), "scatter_channel")
+        return out, None
+
+
+# =====================================================================================================
+# losses, optimizer, train step
+# =====================================================================================================
+def resize_bilinear(x, oh, ow):
+    lib = _lib.load()
+    _c(x)
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, Cc, oh, ow), device=x.device, dtype=torch.float32)
+    check(lib.idiff_resize_bilinear(_p(x), _p(out), B * Cc, H, W, oh, ow, _stream()), "resize_bilinear")
+    return out
+
+
+def mse_loss_and_grad(pred, target, loss_slot, weight=1.0, want_grad=True):
+    """writes mean((pred-target)^2) into loss_slot (1-element device view); returns weight * d loss / d pred."""
+    lib = _lib.load()
+    pred, target = pred.contiguous(), target.contiguous()
+    assert pred.shape == target.shape, (pred.shape, target.shape)
+    grad = torch.empty_like(pred) if want_grad else None
+    ws = torch.empty((256,), device=pred.device, dtype=torch.float32)
+    check(lib.idiff_mse_loss(_p(pred), _p(target), _p(loss_slot), _p(grad), _p(ws), pred.numel(), weight, _stream()), "mse_loss")
+    return grad
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (L2 weight decay added to the gradient; config.yml:138-143) in ONE kernel launch per
+    parameter group: parameters, gradients and both moments live in flat buffers (the parameters' .data / .grad are
+    views into them), so the flat RCCL all-reduce buffer, the Adam update and the 1/world gradient scale fuse."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._flat = []
+        for group in self.param_groups:
+            ps = [p for p in group['params'] if p.requires_grad]
+            if not ps:
+                self._flat.append(None)
+                continue
+            dev = ps[0].device
+            total = sum(p.numel() for p in ps)
+            fp = torch.empty(total, device=dev, dtype=torch.float32)
+            fg = torch.zeros(total, device=dev, dtype=torch.float32)
+            o = 0
+            for p in ps:
+                n = p.numel()
+                fp[o:o + n].copy_(p.data.reshape(-1))
+                p.data = fp[o:o + n].view_as(p)
+                p.grad = fg[o:o + n].view_as(p)
+                o += n
+            self._flat.append(dict(p=fp, g=fg, m=torch.zeros_like(fp), v=torch.zeros_like(fp), step=0, params=ps))
+        self.grad_scale = 1.0
+        WEIGHT_EPOCH[0] += 1
+
+    def flat_grads(self):
+        return [f['g'] for f in self._flat if f is not None]
+
+    def zero_grad(self, set_to_none=False):
+        for f in self._flat:
+            if f is None:
+                continue
+            f['g'].zero_()
+            o = 0
+            for p in f['params']:  # keep .grad bound to the flat buffer (autograd accumulates in place)
+                n = p.numel()
+                if p.grad is None or p.grad.data_ptr() != f['g'].data_ptr() + 4 * o:
+                    p.grad = f['g'][o:o + n].view_as(p)
+                o += n
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        lib = _lib.load()
+        for group, f in zip(self.param_groups, self._flat):
+            if f is None:
+                continue
+            o = 0
+            for p in f['params']:  # a .grad that autograd replaced (first accumulation) is copied back into the flat buffer
+                n = p.numel()
+                if p.grad is not None and p.grad.data_ptr() != f['g'].data_ptr() + 4 * o:
+                    f['g'][o:o + n].copy_(p.grad.reshape(-1))
+                    p.grad = f['g'][o:o + n].view_as(p)
+                o += n
+            f['step'] += 1
+            b1, b2 = group['betas']
+            check(lib.idiff_adam_step(_p(f['p']), _p(f['g']), _p(f['m']), _p(f['v']), f['p'].numel(), group['lr'], b1, b2, group['eps'],
+                                      group['weight_decay'], self.grad_scale, f['step'], _stream()), "adam_step")
+        WEIGHT_EPOCH[0] += 1
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd['flat'] = [None if f is None else dict(m=f['m'].cpu(), v=f['v'].cpu(), step=f['step']) for f in self._flat]
+        return sd
+
+    def load_state_dict(self, sd):
+        flat = sd.pop('flat', None)
+        super().load_state_dict(sd)
+        if flat:
+            for f, s in zip(self._flat, flat):
+                if f is not None and s is not None:
+                    f['m'].copy_(s['m'])
+                    f['v'].copy_(s['v'])
+                    f['step'] = s['step']
+
+
+def score_map_losses(score_maps, label, loss_rec, slot0, mult=(1, 2, 4, 8)):
+    """optimize_score_map (drift_noise_model.py:234-240): sum_i MSE(sm_i, resize(label, H//m_i)) / 2 with the
+    hard-coded 224 replaced by the label's own size.  Returns the per-map gradients; loss values go to loss_rec."""
+    H, W = label.shape[-2:]
+    grads = []
+    for i, sm in enumerate(score_maps):
+        tgt = label if mult[i] == 1 else resize_bilinear(label, H // mult[i], W // mult[i])
+        grads.append(mse_loss_and_grad(sm, tgt, loss_rec[slot0 + i:slot0 + i + 1], weight=0.5))
+    return grads
+
+
+def train_step_inputRes(model):
+    """One optimisation step with the reference's active objective (drift_noise_model.py:242-312):
+       pred_drift, dsm = drift_net(x_t - LQ, LQ, t, ...) ; pred_noise, nsm = noise_net(x_t - LQ, x_t, t, ...)
+       loss = MSE(pred_drift, LQ-GT) + MSE(pred_noise, std_noise) + pyramid(dsm, LQ-GT) + pyramid(nsm, std_noise)
+    Losses and their gradients come from the HIP loss kernel; autograd is entered with explicit output gradients."""
+    import time
+    st = time.time()
+    m = model
+    xa = ops.axpby(m.drift_noised_x, m.input, 1.0, -1.0)
+    tgt_d = ops.axpby(m.input, m.target, 1.0, -1.0)
+    t = m.t.reshape(-1).to(torch.float32)
+    use_dsm = m.dnet_settings.get("use_dsm", True) and m.dnet_settings["text_module"] == "scoremap"
+    use_nsm = m.nnet_settings.get("use_nsm", True) and m.nnet_settings["text_module"] == "scoremap"
+    with torch.enable_grad():
+        outd = m.drift_net(xa, m.input, t, m.names, m.text_encoder, image_context=m.A_emb)
+        outn = m.noise_net(xa, m.drift_noised_x, t, m.names, m.text_encoder, image_context=m.A_emb)
+    pred_d, dsm = outd if isinstance(outd, tuple) else (outd, [])
+    pred_n, nsm = outn if isinstance(outn, tuple) else (outn, [])
+    iter_time = time.time() - st  # the reference times the forward only (:246,290)
+    rec = torch.zeros(10, device=m.device, dtype=torch.float32)  # dl, nl, dsm x4, nsm x4
+    outs, grads = [pred_d, pred_n], [mse_loss_and_grad(pred_d, tgt_d, rec[0:1]), mse_loss_and_grad(pred_n, m.std_noise, rec[1:2])]
+    if use_dsm:
+        outs += list(dsm)
+        grads += score_map_losses(dsm, tgt_d, rec, 2)
+    if use_nsm:
+        outs += list(nsm)
+        grads += score_map_losses(nsm, m.std_noise, rec, 6)
+    m.noise_optimizer.zero_grad()
+    m.drift_optimizer.zero_grad()
+    torch.autograd.backward(outs, grads)
+    scale = 1.0
+    if m.grad_sync is not None:
+        scale = m.grad_sync.all_reduce_flat(m.drift_optimizer.flat_grads() + m.noise_optimizer.flat_grads())
+    m.noise_optimizer.grad_scale = m.drift_optimizer.grad_scale = scale
+    m.noise_optimizer.step()
+    m.drift_optimizer.step()
+    r = rec.cpu()  # the step's single device->host synchronisation (the reference does nine .item() calls)
+    dl, nl = float(r[0]), float(r[1])
+    dsml = float(r[2:6].sum()) / 2.0 if use_dsm else 0.0
+    nsml = float(r[6:10].sum()) / 2.0 if use_nsm else 0.0
+    loss = dl + nl + dsml + nsml
+    li = m.loss_info
+    li['latest'].update(l=loss, nsml=nsml, dsml=dsml, nl=nl, dl=dl)
+    for k, v in (('l', loss), ('dl', dl), ('nl', nl), ('dsml', dsml), ('nsml', nsml)):
+        li['avg'][k] += v
+    li['num'] += 1
+    return loss, iter_time

@@ -1,0 +1,289 @@
+"""Training-path parity on the GPU: every autograd Function's backward (HIP kernels) against torch autograd of the
+plain-PyTorch formula on the CPU, then whole-UNet parameter gradients and two Adam steps against the oracle."""
+import math
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from instancediff_amd import ops, pipeline, train_ops as T  # noqa: E402
+from instancediff_amd.utils.synthetic import make_batch  # noqa: E402
+from oracle import sde_ref, unet_ref  # noqa: E402
+
+DEV = "cuda"
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def _leaf(t):
+    return t.clone().to(DEV).requires_grad_(True)
+
+
+@pytest.mark.parametrize("C0,C1,Cout,H,W,ks,mode", [
+    (24, 0, 64, 16, 16, 3, 0), (16, 24, 40, 32, 32, 3, 0), (32, 0, 64, 8, 8, 3, 1), (16, 0, 64, 16, 32, 1, 2),
+    (40, 8, 64, 16, 16, 1, 0), (2, 0, 64, 32, 32, 7, 0), (64, 0, 5, 32, 32, 3, 0), (5, 0, 16, 16, 16, 3, 0)])
+def test_conv_fn_backward(C0, C1, Cout, H, W, ks, mode):
+    g = _g(1)
+    B = 2
+    x0 = torch.randn(B, C0, H, W, generator=g)
+    x1 = torch.randn(B, C1, H, W, generator=g) if C1 else None
+    cin = (C0 * 4 if mode == 2 else C0) + C1
+    w = torch.randn(Cout, cin, ks, ks, generator=g) / math.sqrt(cin * ks * ks)
+    b = torch.randn(Cout, generator=g)
+    # reference
+    r0, r1, rw, rb = x0.double().requires_grad_(True), (x1.double().requires_grad_(True) if C1 else None), w.double().requires_grad_(True), \
+        b.double().requires_grad_(True)
+    xin = torch.cat([r0, r1], 1) if C1 else r0
+    if mode == 1:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    elif mode == 2:
+        xin = F.pixel_unshuffle(xin, 2)
+    ref = F.conv2d(xin, rw, rb, padding=ks // 2)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy.double())
+    p0, p1, pw, pb = _leaf(x0), (_leaf(x1) if C1 else None), _leaf(w), _leaf(b)
+    out = T.ConvFn.apply(p0, p1, pw, pb, ks, mode)
+    out.backward(dy.to(DEV))
+    assert _rel(out, ref) < 3e-6
+    assert _rel(p0.grad, r0.grad) < 5e-6, "d src0"
+    if C1:
+        assert _rel(p1.grad, r1.grad) < 5e-6, "d src1"
+    assert _rel(pw.grad, rw.grad) < 5e-6, "d weight"
+    assert _rel(pb.grad, rb.grad) < 5e-6, "d bias"
+
+
+@pytest.mark.parametrize("C0,C1,Co,H", [(64, 0, 64, 16), (64, 48, 64, 32), (32, 0, 64, 8)])
+def test_resblock_fn_backward(C0, C1, Co, H):
+    g = _g(2)
+    B, G = 2, 8
+    rb = unet_ref.ResBlock(C0 + C1, Co, 32, G).double()
+    with torch.no_grad():
+        for p in rb.parameters():
+            p.copy_(torch.randn(p.shape, generator=g).double() * (0.3 if p.dim() == 1 else 1.0 / math.sqrt(p[0].numel())))
+        rb.norm1.weight.add_(1.0), rb.norm2.weight.add_(1.0)
+    x0 = torch.randn(B, C0, H, H, generator=g)
+    x1 = torch.randn(B, C1, H, H, generator=g) if C1 else None
+    temb = torch.randn(B, 32, generator=g)
+    vec = torch.randn(B, Co, generator=g)
+    r0 = x0.double().requires_grad_(True)
+    r1 = x1.double().requires_grad_(True) if C1 else None
+    rt = temb.double().requires_grad_(True)
+    rv = vec.double().requires_grad_(True)
+    ref = rb(torch.cat([r0, r1], 1) if C1 else r0, rt) + rv[:, :, None, None]
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy.double())
+    # product: film = Linear(SiLU(temb)) is formed outside the Function
+    P = {k: _leaf(v.float()) for k, v in rb.state_dict().items()}
+    p0, p1, pt, pv = _leaf(x0), (_leaf(x1) if C1 else None), _leaf(temb), _leaf(vec)
+    film = T.LinearFn.apply(T.ActFn.apply(pt, ops.ACT_SILU), P["mlp.weight"], P["mlp.bias"])
+    ident = (C0 + C1) == Co
+    out = T.ResBlockFn.apply(p0, p1, film, pv, P["conv1.weight"], P["conv1.bias"], P["norm1.weight"], P["norm1.bias"], P["conv2.weight"],
+                             P["conv2.bias"], P["norm2.weight"], P["norm2.bias"], None if ident else P["res_conv.weight"],
+                             None if ident else P["res_conv.bias"], G, 1e-5)
+    out.backward(dy.to(DEV))
+    assert _rel(out, ref) < 1e-5
+    assert _rel(p0.grad, r0.grad) < 2e-5
+    if C1:
+        assert _rel(p1.grad, r1.grad) < 2e-5
+    assert _rel(pt.grad, rt.grad) < 2e-5, "d temb (through FiLM)"
+    assert _rel(pv.grad, rv.grad) < 2e-5
+    for k, p in rb.named_parameters():
+        assert _rel(P[k].grad, p.grad) < 3e-5, k
+
+
+@pytest.mark.parametrize("tA,tB", [(False, False), (True, False), (False, True), (True, True)])
+def test_bgemm_softmax_fn(tA, tB):
+    g = _g(3)
+    bt, M, N, K = 3, 37, 50, 29
+    A = torch.randn((bt, K, M) if tA else (bt, M, K), generator=g)
+    Bm = torch.randn((bt, N, K) if tB else (bt, K, N), generator=g)
+    ra, rb = A.double().requires_grad_(True), Bm.double().requires_grad_(True)
+    ref = ((ra.transpose(1, 2) if tA else ra) @ (rb.transpose(1, 2) if tB else rb) * 0.3).softmax(-1)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy.double())
+    pa, pb = _leaf(A), _leaf(Bm)
+    out = T.SoftmaxRowsFn.apply(T.BgemmFn.apply(pa, pb, tA, tB), 0.3)
+    out.backward(dy.to(DEV))
+    assert _rel(out, ref) < 5e-6 and _rel(pa.grad, ra.grad) < 1e-5 and _rel(pb.grad, rb.grad) < 1e-5
+
+
+def test_token_side_fns():
+    g = _g(4)
+    R, K, N = 15, 48, 40
+    x = torch.randn(R, K, generator=g)
+    w, b = torch.randn(N, K, generator=g) / 7, torch.randn(N, generator=g)
+    ga, be = torch.randn(K, generator=g), torch.randn(K, generator=g)
+    gm = torch.randn(N, generator=g)
+    rx, rw, rbb, rga, rbe, rgm = [t.double().requires_grad_(True) for t in (x, w, b, ga, be, gm)]
+    ref = F.gelu(F.linear(F.layer_norm(rx, (K,), rga, rbe, 1e-5), rw, rbb)) * rgm
+    ref = ref + F.silu(ref)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy.double())
+    px, pw, pb, pga, pbe, pgm = [_leaf(t) for t in (x, w, b, ga, be, gm)]
+    y = T.ScaleColsFn.apply(T.ActFn.apply(T.LinearFn.apply(T.LayerNormRowsFn.apply(px, pga, pbe, 1e-5), pw, pb), ops.ACT_GELU), pgm)
+    out = T.AddFn.apply(y, T.ActFn.apply(y, ops.ACT_SILU), 1.0)
+    out.backward(dy.to(DEV))
+    assert _rel(out, ref) < 5e-6
+    for p, r in ((px, rx), (pw, rw), (pb, rbb), (pga, rga), (pbe, rbe), (pgm, rgm)):
+        assert _rel(p.grad, r.grad) < 2e-5
+
+
+def test_map_side_fns():
+    g = _g(5)
+    B, C, H, W = 2, 32, 8, 12
+    x = torch.randn(B, C, H, W, generator=g)
+    ga, be = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    vec = torch.randn(B, C, generator=g)
+    idx = torch.tensor([3, 7], dtype=torch.int32)
+    rx, rga, rbe, rv = [t.double().requires_grad_(True) for t in (x, ga, be, vec)]
+    y = F.layer_norm(rx.permute(0, 2, 3, 1), (C,), rga, rbe, 1e-5).permute(0, 3, 1, 2)
+    y = F.normalize(y, dim=1) + rv[:, :, None, None]
+    ref = y[torch.arange(B), idx.long()][:, None]
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy.double())
+    px, pga, pbe, pv = [_leaf(t) for t in (x, ga, be, vec)]
+    out = T.GatherChannelFn.apply(T.AddVecFn.apply(T.ChanNormalizeFn.apply(T.ChanLayerNormFn.apply(px, pga, pbe, 1e-5)), pv), idx.to(DEV))
+    out.backward(dy.to(DEV))
+    assert _rel(out, ref) < 5e-6
+    for p, r in ((px, rx), (pga, rga), (pbe, rbe), (pv, rv)):
+        assert _rel(p.grad, r.grad) < 2e-5
+
+
+def test_losses_and_adam():
+    g = _g(6)
+    a, b = torch.randn(3, 1, 20, 24, generator=g), torch.randn(3, 1, 20, 24, generator=g)
+    slot = torch.zeros(2, device=DEV)
+    grad = T.mse_loss_and_grad(a.to(DEV), b.to(DEV), slot[0:1], weight=0.5)
+    ra = a.double().requires_grad_(True)
+    l = F.mse_loss(ra, b.double())
+    (0.5 * l).backward()
+    assert abs(float(slot[0]) - float(l)) < 1e-6 * float(l) + 1e-9 and _rel(grad, ra.grad) < 1e-6
+    lab = torch.randn(2, 1, 32, 48, generator=g)
+    for oh, ow in ((16, 24), (8, 12), (4, 6)):
+        ref = F.interpolate(lab.double(), size=(oh, ow), mode="bilinear", align_corners=False, antialias=False)
+        assert _rel(T.resize_bilinear(lab.to(DEV), oh, ow), ref) < 2e-6
+    # Adam == torch.optim.Adam (L2-in-grad weight decay)
+    p0 = torch.randn(1000, generator=g)
+    ref_p = p0.clone().requires_grad_(True)
+    ropt = torch.optim.Adam([ref_p], lr=2e-3, betas=(0.9, 0.99), weight_decay=1e-2)
+    pp = nn.Parameter(p0.clone().to(DEV))
+    opt = T.FusedAdam([pp], lr=2e-3, betas=(0.9, 0.99), weight_decay=1e-2)
+    for it in range(3):
+        gr = torch.randn(1000, generator=g)
+        ref_p.grad = gr.clone()
+        ropt.step()
+        opt.zero_grad()
+        pp.grad.copy_(gr.to(DEV))
+        opt.step()
+    assert _rel(pp.data, ref_p.data) < 1e-6
+
+
+def _oracle_pair(model):
+    opt = pipeline.load_options()
+    mo = opt['models']['DriftNoise']
+    refs = []
+    for key, net in (('dnet_settings', model.drift_net), ('nnet_settings', model.noise_net)):
+        s = {k: v for k, v in dict(mo[key]).items() if k not in ("module_name", "class_name")}
+        smm = nn.ModuleList([unet_ref.ScoreMapModule(visual_dim=mo['score_map_ngf'] * m) for m in mo['score_map_ch_mult']])
+        r = unet_ref.LearnableForwardUNet_MultiScoreMap(CLIP_ScoreMapModule=smm, use_image_context=True, **s)
+        r.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()})
+        refs.append(r)
+    return refs
+
+
+def test_unet_param_gradients_and_train_steps_vs_oracle():
+    B, H, T_ = 2, 32, 20
+    model, sde = pipeline.build(phase="train", device=torch.device(DEV), T=T_, seed=0)
+    model.set_train()
+    with torch.no_grad():  # make the tiny-gamma / zero-bias paths carry signal
+        for net in (model.drift_net, model.noise_net):
+            for m in net.CLIP_ScoreMapModule:
+                m.gamma.fill_(0.3)
+    rd, rn = _oracle_pair(model)
+    te = unet_ref.StubTextEncoder()
+    batch = make_batch(B, H, seed=3)
+    g = _g(7)
+    t = torch.tensor([[[[5]]], [[[17]]]])
+    eps = torch.randn(batch['input'].shape, generator=g)
+    # ---- oracle step (torch autograd + torch Adam on the CPU) ----
+    osde = sde_ref.DriftSDERef(T_, rd, rn, max_sigma=0.4)
+    _, x_t, _, std_noise, _ = osde.forward_diffusion(batch['target'], batch['input'], t, eps)
+    opt_d = torch.optim.Adam(rd.parameters(), lr=2e-5, betas=(0.9, 0.99), weight_decay=1e-4)
+    opt_n = torch.optim.Adam(rn.parameters(), lr=2e-5, betas=(0.9, 0.99), weight_decay=1e-4)
+
+    def oracle_loss():
+        tt = t.reshape(-1)
+        pd, dsm = rd(x_t - batch['input'], batch['input'], tt, batch['names'], te, image_context=batch['A_emb'])
+        pn, nsm = rn(x_t - batch['input'], x_t, tt, batch['names'], te, image_context=batch['A_emb'])
+        tgt = batch['input'] - batch['target']
+
+        def pyr(sms, lab):
+            tot = 0
+            for i, sm in enumerate(sms):
+                lb = lab if i == 0 else F.interpolate(lab, size=(H >> i, H >> i), mode="bilinear", align_corners=False, antialias=False)
+                tot = tot + F.mse_loss(sm, lb)
+            return tot / 2.0
+        return F.mse_loss(pd, tgt) + F.mse_loss(pn, std_noise) + pyr(dsm, tgt) + pyr(nsm, std_noise)
+
+    opt_d.zero_grad(), opt_n.zero_grad()
+    l0 = oracle_loss()
+    l0.backward()
+    ref_grads = {("d", k): p.grad.clone() for k, p in rd.named_parameters()}
+    ref_grads.update({("n", k): p.grad.clone() for k, p in rn.named_parameters()})
+    opt_d.step(), opt_n.step()
+    # ---- product step ----
+    model.input = batch['input'].to(DEV)
+    model.target = batch['target'].to(DEV)
+    model.names = batch['names']
+    model.A_emb = batch['A_emb'].to(DEV)
+    model.t, model.drift_noised_x, _, model.std_noise, _ = sde.forward_diffusion(model.target, model.input, t=t, eps=eps.to(DEV))
+    assert _rel(model.drift_noised_x, x_t) < 1e-6
+    loss, _ = model.optimize_parameters()
+    assert abs(loss - float(l0)) < 2e-5 * abs(float(l0)), (loss, float(l0))
+    # gradients live in the optimizers' flat buffers, still intact after step()
+    worst = 0.0
+    for tag, net in (("d", model.drift_net), ("n", model.noise_net)):
+        for k, p in net.named_parameters():
+            r = ref_grads[(tag, k)]
+            scale = float(r.abs().max())
+            if scale < 1e-12:
+                assert float(p.grad.abs().max()) < 1e-9, (tag, k)
+                continue
+            e = float((p.grad.cpu() - r).abs().max()) / scale
+            worst = max(worst, e)
+            assert e < 2e-3, (tag, k, e)
+    print("worst relative parameter-gradient error", worst)
+    # parameters after one Adam step
+    # (the first Adam step is -lr*g/(|g|+eps) ~ -lr*sign(g): elements whose gradient is ~0 may legitimately differ by up
+    #  to 2*lr, so the check is on the bulk: >= 99 % of all elements within 0.1*lr, none beyond 2.5*lr)
+    lr, n_all, n_bad = 2e-5, 0, 0
+    for net, ref in ((model.drift_net, rd), (model.noise_net, rn)):
+        for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+            d = (p.detach().cpu() - q.detach()).abs()
+            assert float(d.max()) < 2.5 * lr, k
+            n_all += d.numel()
+            n_bad += int((d > 0.1 * lr).sum())
+    assert n_bad < 0.01 * n_all, (n_bad, n_all)
+    # second step: loss is finite and the inference path sees the updated weights (prepared-weight cache invalidated)
+    loss2, _ = model.optimize_parameters()
+    assert math.isfinite(loss2)
+    model.set_eval()
+    with torch.no_grad():
+        p_inf = model.drift_net(model.drift_noised_x - model.input, model.input, t.reshape(-1).to(DEV), model.names, model.text_encoder,
+                                image_context=model.A_emb)[0]
+    opt_d.zero_grad(), opt_n.zero_grad()
+    oracle_loss().backward()
+    opt_d.step(), opt_n.step()
+    with torch.no_grad():
+        p_ref = rd.eval()(x_t - batch['input'], batch['input'], t.reshape(-1), batch['names'], te, image_context=batch['A_emb'])[0]
+    assert _rel(p_inf, p_ref) < 1e-3
