@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=1)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--mode", choices=["sample", "train"], default="sample",
+                    help="sample = headline denoising-steps/s metric; train = secondary training-iterations/s line")
     return ap.parse_args()
 
 
@@ -157,6 +159,56 @@ def log(msg):
 _T0 = time.time()
 
 
+def train_bench(args, world, rank, dev):
+    """Secondary line (BASELINE config c3): training iterations/sec of CLIPDriftModel.optimize_parameters --
+    feed_data (forward diffusion) + 2 UNet forwards + losses + backward + flat RCCL all-reduce + fused Adam."""
+    import torch.distributed as dist
+    from instancediff_amd import pipeline
+    from instancediff_amd.utils.synthetic import make_batch
+    T = 100 if args.T == 1000 else args.T
+    model, sde = pipeline.build(phase="train", device=dev, T=T, seed=0, dist=world > 1)
+    model.set_train()
+    sde.set_seed(1234 + rank)
+    batch = make_batch(args.batch, args.size, seed=1234 + rank, mixed=True)
+    torch.manual_seed(99 + rank)
+
+    def it():
+        model.feed_data(batch)
+        return model.optimize_parameters()[0]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log("train: model built; warmup")
+    for _ in range(args.warmup):
+        loss = it()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = it()
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        el = float(tmax.item())
+    if rank == 0:
+        value = world * args.steps / el
+        print(json.dumps({"metric": "training iterations/sec (%dx%d bs%d/GPU)" % (args.size, args.size, args.batch), "value": round(value, 4),
+                          "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(el / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f32", "data": "synthetic", "last_loss": loss,
+                          "config": {"workload": "%dx%d synthetic, batch %d per GPU, drift+noise UNet fwd/bwd, pyramid losses, Adam"
+                                                 % (args.size, args.size, args.batch), "global_batch": args.batch * world,
+                                     "parallelism": "dp%d (flat RCCL all-reduce)" % world,
+                                     "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -174,6 +226,9 @@ def main():
 
     from instancediff_amd import ops, pipeline
     from instancediff_amd.utils.synthetic import make_batch
+
+    if args.mode == "train":
+        return train_bench(args, world, rank, dev)
 
     model, sde = pipeline.build(phase="test", device=dev, T=args.T, seed=0)
     model.set_eval()

@@ -246,8 +246,9 @@ int idiff_scatter_channel(const float* x, const int32_t* idx, float* out, int B,
 
 /* generic batched GEMM on the f32 matrix cores:  C[b] = alpha * op(A[b]) (MxK) . op(B[b]) (KxN) + beta * C[b]
  * (row-major; transX != 0 -> the matrix is stored transposed); sA/sB/sC = batch strides in elements */
+int64_t idiff_bgemm_ws_floats(int M, int N, int K, int batch); /* 0 unless the shape is K-split (long K, tiny output) */
 int idiff_bgemm(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
-                int transA, int transB, int64_t sA, int64_t sB, int64_t sC, int batch, float alpha, float beta,
+                int transA, int transB, int64_t sA, int64_t sB, int64_t sC, int batch, float alpha, float beta, float* ws,
                 idiff_stream_t stream);
 /* out = softmax(scale * x) over each row;  ds = scale * p * (dp - <p, dp>) */
 int idiff_softmax_rows_fwd(const float* x, int64_t ldx, float* out, int64_t ldo, int R, int N, float scale,

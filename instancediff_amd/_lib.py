@@ -83,7 +83,8 @@ SIGNATURES = {
     "idiff_chan_normalize_fwd": (I, [P, I64, P, P, I, I, I, c_stream]),
     "idiff_chan_normalize_bwd": (I, [P, P, P, P, I64, I, I, I, c_stream]),
     "idiff_scatter_channel": (I, [P, P, P, I, I, I, c_stream]),
-    "idiff_bgemm": (I, [P, P, P, I, I, I, I64, I64, I64, I, I, I64, I64, I64, I, F, F, c_stream]),
+    "idiff_bgemm_ws_floats": (I64, [I, I, I, I]),
+    "idiff_bgemm": (I, [P, P, P, I, I, I, I64, I64, I64, I, I, I64, I64, I64, I, F, F, P, c_stream]),
     "idiff_softmax_rows_fwd": (I, [P, I64, P, I64, I, I, F, c_stream]),
     "idiff_softmax_rows_bwd": (I, [P, I64, P, I64, P, I64, I, I, F, c_stream]),
     "idiff_resize_bilinear": (I, [P, P, I64, I, I, I, I, c_stream]),

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                 const int c4 = f - row * (BM / 4);
                 const int tap = row / CK;
                 const int ci = row - tap * CK;
-                const bool v = f < W_TILE / 4 && cb + ci < a.Cin;
+                const bool v = f < W_TILE / 4 && cb + ci < a.Cin && co0 + c4 * 4 < a.Cout;  // Cout % 4 == 0
                 const float* p = v ? a.wpk + ((long long)tap * a.Cin + cb + ci) * a.Cout + co0 + c4 * 4 : a.wpk;
                 rwv[i] = *reinterpret_cast<const floatx4*>(p);
             }
@@ -191,8 +191,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                 const int row = f / (BM / 4);
                 const int tap = row / CK;
                 const int ci = row - tap * CK;
+                const int c4 = f - row * (BM / 4);
                 floatx4 w = rwv[i];
-                if (!(cb + ci < a.Cin)) w = floatx4{0.f, 0.f, 0.f, 0.f};
+                if (!(cb + ci < a.Cin && co0 + c4 * 4 < a.Cout)) w = floatx4{0.f, 0.f, 0.f, 0.f};
                 if (f < W_TILE / 4) *reinterpret_cast<floatx4*>(wb + f * 4) = w;
             }
         } else {
@@ -499,7 +500,7 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
     const long long total = (long long)a.B * a.ntiles * a.ncob;
     IDIFF_CHECK_ARG(total < (1ll << 31), "conv2d: grid too large");
     a.total_wg = (unsigned)total;
-    const bool vecw = (a.Cout % bm == 0) && ((reinterpret_cast<uintptr_t>(a.wpk) & 15) == 0);
+    const bool vecw = (a.Cout % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.wpk) & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
     if (d->ks == 3) {
         if (d->mode == IDIFF_CONV_NORMAL) return dispatch_mb<3, 8, IDIFF_CONV_NORMAL>(a, twl, mb, vecw, st);

@@ -1,59 +1,63 @@
 // Generic batched GEMM on the f32 matrix cores + row softmax forward/backward.
-// Building blocks of the attention / token-side BACKWARD passes (training path), where shapes are small
-// (<= a few GFLOP) and generality matters more than the last 20 % of MFMA utilisation.
+// Building blocks of the attention / token-side passes of the TRAINING path (forward of the unfused chains and
+// every backward), where shapes are small and generality matters more than the last 20 % of MFMA utilisation.
 //   C[b] = alpha * op(A[b]) (M x K) . op(B[b]) (K x N) + beta * C[b],   row-major, leading dims lda/ldb/ldc,
-//   op(X) = X or X^T.  64x64 tile per workgroup, 4 waves x one 32x32 accumulator, K chunks of 16 through LDS
-//   (both operands are stored k-major in LDS so the MFMA operand reads are unit-stride along m / n).
+//   op(X) = X or X^T.  Workgroup tile TM x TN = 64x64 (waves 2x2) or 32x128 (waves 1x4, for the ScoreMapModule's
+//   20-row query blocks), K chunks of 16 through LDS (both operands stored k-major so the MFMA operand reads are
+//   unit-stride along m / n).  Long-K / tiny-output products (dQ = dS . mem^T with K = H*W) are split over K into
+//   per-split partial tiles that a second kernel sums in a fixed order (deterministic, no atomics).
 #include <math.h>
 
 #include "common.h"
 
 namespace {
 
-constexpr int GT = 64;   // tile M = N
-constexpr int GK = 16;   // K chunk
-constexpr int GLD = GT + 1;
+constexpr int GK = 16;  // K chunk
 
+template <int TM, int TN>
 __global__ __launch_bounds__(256) void bgemm_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N,
                                                     int K, long long lda, long long ldb, long long ldc, int transA, int transB, long long sA,
-                                                    long long sB, long long sC, float alpha, float beta) {
-    __shared__ float As[GK][GLD];
-    __shared__ float Bs[GK][GLD];
+                                                    long long sB, long long sC, float alpha, float beta, int nsplit, int kper) {
+    constexpr int WN = TN / 32;  // waves along n; waves along m = 4 / WN = TM / 32
+    __shared__ float As[GK][TM + 1];
+    __shared__ float Bs[GK][TN + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
-    const float* Ab = A + (long long)blockIdx.z * sA;
-    const float* Bb = B + (long long)blockIdx.z * sB;
-    float* Cb = C + (long long)blockIdx.z * sC;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    const int bz = blockIdx.z / nsplit, sp = blockIdx.z % nsplit;
+    const float* Ab = A + (long long)bz * sA;
+    const float* Bb = B + (long long)bz * sB;
+    float* Cb = C + (long long)blockIdx.z * sC;  // with nsplit > 1, C is the partial buffer [batch*nsplit][M][N]
+    const int kbeg = sp * kper, kend = min(K, kbeg + kper);
     floatx16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int k0 = 0; k0 < K; k0 += GK) {
-        // stage A tile (64 m x 16 k) and B tile (16 k x 64 n): 4 elements per thread each, unit stride in memory
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
+    for (int k0 = kbeg; k0 < kend; k0 += GK) {
+        for (int e = tid; e < TM * GK; e += 256) {
             int m, k;
             if (transA) {  // memory [k][m]
-                k = tid >> 4;
-                m = (tid & 15) * 4 + i;
+                k = e / TM;
+                m = e - k * TM;
             } else {  // memory [m][k]
-                m = tid >> 2;
-                k = (tid & 3) * 4 + i;
+                m = e / GK;
+                k = e - m * GK;
             }
             float v = 0.f;
-            if (m0 + m < M && k0 + k < K) v = transA ? Ab[(long long)(k0 + k) * lda + m0 + m] : Ab[(long long)(m0 + m) * lda + k0 + k];
+            if (m0 + m < M && k0 + k < kend) v = transA ? Ab[(long long)(k0 + k) * lda + m0 + m] : Ab[(long long)(m0 + m) * lda + k0 + k];
             As[k][m] = v;
-            int n, kb;
+        }
+        for (int e = tid; e < TN * GK; e += 256) {
+            int n, k;
             if (transB) {  // memory [n][k]
-                n = tid >> 2;
-                kb = (tid & 3) * 4 + i;
+                n = e / GK;
+                k = e - n * GK;
             } else {  // memory [k][n]
-                kb = tid >> 4;
-                n = (tid & 15) * 4 + i;
+                k = e / TN;
+                n = e - k * TN;
             }
             float w = 0.f;
-            if (n0 + n < N && k0 + kb < K) w = transB ? Bb[(long long)(n0 + n) * ldb + k0 + kb] : Bb[(long long)(k0 + kb) * ldb + n0 + n];
-            Bs[kb][n] = w;
+            if (n0 + n < N && k0 + k < kend) w = transB ? Bb[(long long)(n0 + n) * ldb + k0 + k] : Bb[(long long)(k0 + k) * ldb + n0 + n];
+            Bs[k][n] = w;
         }
         __syncthreads();
 #pragma unroll
@@ -72,6 +76,19 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const float* __restrict__ A,
                 Cb[(long long)m * ldc + n] = v;
             }
         }
+    }
+}
+
+// C[b][m][n] = (beta * C) + sum_s part[b*nsplit+s][m][n]
+__global__ void bgemm_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, int M, int N, long long ldc, long long sC, int nsplit,
+                                    float beta) {
+    const int b = blockIdx.y;
+    const long long mn = (long long)M * N;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < mn; i += (long long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += part[((long long)b * nsplit + k) * mn + i];
+        float* c = C + (long long)b * sC + (i / N) * ldc + (i % N);
+        *c = beta != 0.f ? beta * *c + s : s;
     }
 }
 
@@ -115,17 +132,54 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __re
     for (int i = tid; i < N; i += 256) o[i] = scale * pr[i] * (dr[i] - dot);
 }
 
+// K split: only when the output is tiny and K long (few workgroups would each walk a very long K)
+inline int pick_nsplit(int M, int N, int K, int batch) {
+    const int tm = M <= 32 ? 32 : 64, tn = M <= 32 ? 128 : 64;
+    const long long tiles = (long long)((M + tm - 1) / tm) * ((N + tn - 1) / tn) * batch;
+    if (K < 2048 || tiles >= 512) return 1;
+    long long want = 1024 / tiles;
+    long long maxs = K / 512;
+    if (want > maxs) want = maxs;
+    if (want > 128) want = 128;
+    return want < 2 ? 1 : (int)want;
+}
+
 }  // namespace
 
+extern "C" int64_t idiff_bgemm_ws_floats(int M, int N, int K, int batch) {
+    const int ns = pick_nsplit(M, N, K, batch);
+    return ns > 1 ? (int64_t)ns * batch * M * N : 0;
+}
+
 extern "C" int idiff_bgemm(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int transA,
-                           int transB, int64_t sA, int64_t sB, int64_t sC, int batch, float alpha, float beta, idiff_stream_t stream) {
+                           int transB, int64_t sA, int64_t sB, int64_t sC, int batch, float alpha, float beta, float* ws, idiff_stream_t stream) {
     IDIFF_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0, "bgemm: bad args");
     IDIFF_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "bgemm: bad leading dims");
-    IDIFF_CHECK_ARG(batch <= 65535, "bgemm: batch too large");
-    dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, batch);
-    hipLaunchKernelGGL(bgemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, (long long)lda, (long long)ldb, (long long)ldc,
-                       transA, transB, (long long)sA, (long long)sB, (long long)sC, alpha, beta);
+    const int ns = pick_nsplit(M, N, K, batch);
+    IDIFF_CHECK_ARG(ns == 1 || ws, "bgemm: this shape needs a workspace of idiff_bgemm_ws_floats() floats");
+    IDIFF_CHECK_ARG((long long)batch * ns <= 65535, "bgemm: batch too large");
+    int kper = (K + ns - 1) / ns;
+    kper = ((kper + GK - 1) / GK) * GK;
+    hipStream_t st = (hipStream_t)stream;
+    float* dst = ns > 1 ? ws : C;
+    const long long dld = ns > 1 ? N : ldc, dsC = ns > 1 ? (long long)M * N : sC;
+    const float a2 = alpha, b2 = ns > 1 ? 0.f : beta;
+    if (M <= 32) {
+        dim3 grid((N + 127) / 128, (M + 31) / 32, batch * ns);
+        hipLaunchKernelGGL((bgemm_kernel<32, 128>), grid, dim3(256), 0, st, A, B, dst, M, N, K, (long long)lda, (long long)ldb, dld, transA, transB,
+                           (long long)sA, (long long)sB, dsC, a2, b2, ns, kper);
+    } else {
+        dim3 grid((N + 63) / 64, (M + 63) / 64, batch * ns);
+        hipLaunchKernelGGL((bgemm_kernel<64, 64>), grid, dim3(256), 0, st, A, B, dst, M, N, K, (long long)lda, (long long)ldb, dld, transA, transB,
+                           (long long)sA, (long long)sB, dsC, a2, b2, ns, kper);
+    }
     IDIFF_CHECK_LAUNCH("bgemm");
+    if (ns > 1) {
+        const long long mn = (long long)M * N;
+        dim3 grid((unsigned)((mn + 255) / 256 > 1024 ? 1024 : (mn + 255) / 256), batch);
+        hipLaunchKernelGGL(bgemm_reduce_kernel, grid, dim3(256), 0, st, ws, C, M, N, (long long)ldc, (long long)sC, ns, beta);
+        IDIFF_CHECK_LAUNCH("bgemm_reduce");
+    }
     return IDIFF_OK;
 }
 

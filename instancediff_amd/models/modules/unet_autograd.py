@@ -101,15 +101,18 @@ def _smm(smm, feat, text_encoder, idx):
         x = AddFn.apply(x, LinearFn.apply(a, sa.proj.weight, sa.proj.bias), 1.0)
         n2 = LayerNormRowsFn.apply(x, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
         qc = LinearFn.apply(n2, ca.q_proj.weight, None)  # [R, Wd]
+        # k/v projections folded onto the queries: qf_h = q_h Wk_h ; S = qf mem ; o = P mem^T ; av_h = o_h Wv_h^T.
+        # All heads' query rows are stacked ([B, heads*K, Wd]) so `mem` is read once per product, not once per head.
+        qfs = [BgemmFn.apply(qc[:, h * dh:(h + 1) * dh].unsqueeze(0), ca.k_proj.weight[h * dh:(h + 1) * dh].unsqueeze(0), False, False)
+               .reshape(B, K, Wd) for h in range(heads)]
+        qf = torch.cat(qfs, dim=1)                                   # [B, heads*K, Wd], row = h*K + k
+        s = BgemmFn.apply(qf, mem, False, False)                     # [B, heads*K, N]
+        p = SoftmaxRowsFn.apply(s, ca.scale)
+        o = BgemmFn.apply(p, mem, False, True)                       # [B, heads*K, Wd]
         avs = []
         for h in range(heads):
-            sl = slice(h * dh, (h + 1) * dh)
-            # k/v projections folded onto the queries: qf = q_h Wk_h ; S = qf mem ; o = P mem^T ; av_h = o Wv_h^T
-            qf = BgemmFn.apply(qc[:, sl].unsqueeze(0), ca.k_proj.weight[sl].unsqueeze(0), False, False).reshape(B, K, Wd)
-            s = BgemmFn.apply(qf, mem, False, False)               # [B,K,N]
-            p = SoftmaxRowsFn.apply(s, ca.scale)
-            o = BgemmFn.apply(p, mem, False, True).reshape(1, R, Wd)  # [B,K,Wd]
-            avs.append(BgemmFn.apply(o, ca.v_proj.weight[sl].unsqueeze(0), False, True).reshape(R, dh))
+            oh = o[:, h * K:(h + 1) * K].reshape(1, R, Wd)
+            avs.append(BgemmFn.apply(oh, ca.v_proj.weight[h * dh:(h + 1) * dh].unsqueeze(0), False, True).reshape(R, dh))
         av = torch.cat(avs, dim=-1)
         x = AddFn.apply(x, LinearFn.apply(av, ca.proj.weight, ca.proj.bias), 1.0)
         n3 = LayerNormRowsFn.apply(x, layer.norm3.weight, layer.norm3.bias, layer.norm3.eps)

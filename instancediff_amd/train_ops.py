@@ -101,8 +101,10 @@ def bgemm(A, B, M, N, K, lda, ldb, transA, transB, sA, sB, batch, out=None, alph
     _chk(A), _chk(B)
     if out is None:
         out = torch.empty((batch, M, N), device=A.device, dtype=torch.float32)
+    nws = lib.idiff_bgemm_ws_floats(M, N, K, batch)
+    ws = torch.empty((nws,), device=A.device, dtype=torch.float32) if nws else None
     check(lib.idiff_bgemm(_p(A), _p(B), _p(out), M, N, K, lda, ldb, N, 1 if transA else 0, 1 if transB else 0, sA, sB, M * N, batch, alpha, beta,
-                          _stream()), "bgemm")
+                          _p(ws), _stream()), "bgemm")
     return out
 
 

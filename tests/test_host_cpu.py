@@ -196,6 +196,14 @@ dist.all_gather(gs, g_local)
 f = sync.all_reduce(average=False)
 assert abs(f - 0.5) < 1e-12
 assert torch.allclose(sync.flat, gs[0] + gs[1])
+# GradSync: the form the fused-Adam train step uses (one all-reduce per optimizer-owned flat buffer, scale deferred)
+gs = parallel.GradSync()
+fa, fb = torch.full((7,), float(rank + 1)), torch.arange(5, dtype=torch.float32) * (rank + 1)
+scale = gs.all_reduce_flat([fa, fb])
+assert scale == 0.5 and torch.equal(fa, torch.full((7,), 3.0)) and torch.equal(fb, torch.arange(5, dtype=torch.float32) * 3)
+pw = torch.nn.Parameter(torch.full((4,), float(rank)))
+gs.broadcast_parameters([pw])
+assert torch.equal(pw.data, torch.zeros(4))
 # sampling shards: disjoint cover (data_sampler.py:59 semantics)
 idx = parallel.shard_indices(11, rank, world)
 alli = [None, None]
