@@ -283,6 +283,13 @@ def main():
                 "conv_share_of_step": round(all_ms / args.steps / (el / args.steps * 1e3), 3),
                 "all_conv_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2),
                 "step_conv_gflop": round(all_fl / args.steps / 1e9, 1)}
+        try:  # HBM bytes per launch of the same kernel from a separate rocprofv3 --pmc run of this command (profiles/)
+            with open(os.path.join(ROOT, "profiles", "r01", "c_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            roof["traffic"] = pmc["hbm_bytes_per_launch"]
+            roof["traffic_unit"] = "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/r01/c_pmc_traffic.json)"
+        except (OSError, KeyError, ValueError):
+            pass
     if world > 1:
         barrier()
 
