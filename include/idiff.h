@@ -262,6 +262,11 @@ int idiff_softmax_rows_bwd(const float* p, int64_t ldp, const float* dp, int64_t
 int idiff_resize_bilinear(const float* x, float* out, int64_t planes, int H, int W, int oh, int ow, idiff_stream_t stream);
 int idiff_mse_loss(const float* a, const float* b, float* loss, float* grad, float* ws, int64_t n, float grad_scale,
                    idiff_stream_t stream);
+/* validation metrics of the drivers (trainUM.py:314-329, testUM.py:151-164) on x/2+0.5, data_range 1:
+ * out_b3[b] = {RMSE, PSNR dB, SSIM (skimage: gaussian 11x11 sigma 1.5, K1 .01, K2 .03, interior crop)};
+ * pred/target [B,H,W]; ws: B*128 floats */
+int idiff_image_metrics(const float* pred, const float* target, float* out_b3, float* ws, int B, int H, int W,
+                        idiff_stream_t stream);
 /* torch.optim.Adam semantics (L2-in-gradient weight decay, config.yml:138-143), grad pre-scaled by grad_scale
  * (1/world after the flat RCCL all-reduce); step >= 1 */
 int idiff_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,

@@ -89,6 +89,7 @@ SIGNATURES = {
     "idiff_softmax_rows_bwd": (I, [P, I64, P, I64, P, I64, I, I, F, c_stream]),
     "idiff_resize_bilinear": (I, [P, P, I64, I, I, I, I, c_stream]),
     "idiff_mse_loss": (I, [P, P, P, P, P, I64, F, c_stream]),
+    "idiff_image_metrics": (I, [P, P, P, P, I, I, I, c_stream]),
     "idiff_adam_step": (I, [P, P, P, P, I64, F, F, F, F, F, F, I, c_stream]),
 }
 

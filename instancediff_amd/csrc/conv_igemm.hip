@@ -49,7 +49,10 @@ struct ConvArgs {
     unsigned total_wg;
 };
 
-template <int KS, int CK, int TWL, int MODE, bool VECW, int MB>
+// SPEC: 0 = generic (prologue / second source decided at run time); 1 = single source, no prologue;
+//       2 = single source + GN/SiLU prologue; 3 = two sources, no prologue.  The specialised forms drop the per-element
+//       branches and 64-bit address selects from the staging code of the hot 3x3 layers.
+template <int KS, int CK, int TWL, int MODE, bool VECW, int MB, int SPEC>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int BM = 32 * MB;
     constexpr int TW = 1 << TWL;
@@ -84,7 +87,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const int x0 = (tile % a.tiles_x) * TW;
 
     const int HWin = a.Hin * a.Win;
-    const bool has_pro = a.pro_a != nullptr;
+    const bool has_pro = SPEC == 0 ? (a.pro_a != nullptr) : (SPEC == 2);
+    const bool two_src = SPEC == 0 ? (a.src1 != nullptr) : (SPEC == 3);
 
     // ---- per-thread gather descriptors (constant across chunks) ---------------------------------
     int goff[NL];
@@ -130,15 +134,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     auto load_regs = [&](int cc) {
         const int cb = cc * CK;
         const float* base0 = sample0 + (long long)(MODE == IDIFF_CONV_UNSHUFFLE2 ? (cb >> 2) : cb) * HWin;
-        const float* base1 = a.src1 ? a.src1 + (long long)b * a.bs1 + (long long)(cb - a.C0v) * HWin : sample0;
+        if (two_src) {
+            const float* base1 = a.src1 + (long long)b * a.bs1 + (long long)(cb - a.C0v) * HWin;
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const int e = tid + i * 256;
-            const int ch = cb + e / PS;
-            const bool v = gval[i] && ch < a.Cin;
-            const float* p = v ? (ch < a.C0v ? base0 : base1) + goff[i] : sample0;
-            rin[i] = *p;
+            for (int i = 0; i < NL; ++i) {
+                const int e = tid + i * 256;
+                const int ch = cb + e / PS;
+                const bool v = gval[i] && ch < a.Cin;
+                const float* p = v ? (ch < a.C0v ? base0 : base1) + goff[i] : sample0;
+                rin[i] = *p;
+            }
+        } else {
+            // single source: uniform (scalar) base + 32-bit per-lane offset; masked lanes read base0[0] (in range: cb < Cin)
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int e = tid + i * 256;
+                const int ch = cb + e / PS;
+                const int off = (gval[i] && ch < a.Cin) ? goff[i] : 0;
+                rin[i] = base0[off];
+            }
         }
+        const float* wchunk = a.wpk + (long long)cb * a.Cout;  // uniform base of this chunk's weight rows
         if (VECW) {
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
@@ -148,8 +164,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                 const int tap = row / CK;
                 const int ci = row - tap * CK;
                 const bool v = f < W_TILE / 4 && cb + ci < a.Cin && co0 + c4 * 4 < a.Cout;  // Cout % 4 == 0
-                const float* p = v ? a.wpk + ((long long)tap * a.Cin + cb + ci) * a.Cout + co0 + c4 * 4 : a.wpk;
-                rwv[i] = *reinterpret_cast<const floatx4*>(p);
+                const int off = v ? (tap * a.Cin + ci) * a.Cout + co0 + c4 * 4 : 0;           // < 2^31: weights are small
+                rwv[i] = *reinterpret_cast<const floatx4*>(wchunk + off);
             }
         } else {
 #pragma unroll
@@ -371,7 +387,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     }
 }
 
-template <int KS, int CK, int TWL, int MODE, bool VECW, int MB>
+template <int KS, int CK, int TWL, int MODE, bool VECW, int MB, int SPEC>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
     constexpr int BM = 32 * MB;
     constexpr int TW = 1 << TWL;
@@ -383,7 +399,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     const size_t lds = ((size_t)2 * (IN_TILE + W_TILE) + (a.pro_a ? 2 * (size_t)a.C0r : 0)) * sizeof(float);
     if (lds > 160 * 1024) IDIFF_FAIL(IDIFF_E_UNSUPPORTED, "conv2d: LDS budget exceeded (%zu bytes)", lds);
     static size_t attr_set = 0;
-    auto kern = conv_igemm_kernel<KS, CK, TWL, MODE, VECW, MB>;
+    auto kern = conv_igemm_kernel<KS, CK, TWL, MODE, VECW, MB, SPEC>;
     if (lds > attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "conv2d: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -396,9 +412,16 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
 
 template <int KS, int CK, int MODE, int MB>
 int dispatch_tw(const ConvArgs& a, int twl, bool vecw, hipStream_t st) {
-    if (twl == 5) return vecw ? launch_conv<KS, CK, 5, MODE, true, MB>(a, st) : launch_conv<KS, CK, 5, MODE, false, MB>(a, st);
-    if (twl == 4) return vecw ? launch_conv<KS, CK, 4, MODE, true, MB>(a, st) : launch_conv<KS, CK, 4, MODE, false, MB>(a, st);
-    return vecw ? launch_conv<KS, CK, 3, MODE, true, MB>(a, st) : launch_conv<KS, CK, 3, MODE, false, MB>(a, st);
+    if (twl == 5) {
+        if (KS == 3 && MODE == IDIFF_CONV_NORMAL && MB == 2 && vecw) {  // the hot layers: exact specialisations
+            if (a.pro_a) return launch_conv<KS, CK, 5, MODE, true, MB, 2>(a, st);
+            if (a.src1) return launch_conv<KS, CK, 5, MODE, true, MB, 3>(a, st);
+            return launch_conv<KS, CK, 5, MODE, true, MB, 1>(a, st);
+        }
+        return vecw ? launch_conv<KS, CK, 5, MODE, true, MB, 0>(a, st) : launch_conv<KS, CK, 5, MODE, false, MB, 0>(a, st);
+    }
+    if (twl == 4) return vecw ? launch_conv<KS, CK, 4, MODE, true, MB, 0>(a, st) : launch_conv<KS, CK, 4, MODE, false, MB, 0>(a, st);
+    return vecw ? launch_conv<KS, CK, 3, MODE, true, MB, 0>(a, st) : launch_conv<KS, CK, 3, MODE, false, MB, 0>(a, st);
 }
 
 template <int KS, int CK, int MODE>

@@ -51,8 +51,12 @@ class EMA(nn.Module):
                 pe.copy_(po)
             self.initted.fill_(True)
             return
+        from .. import ops
         for pe, po in zip(self.ema_model.parameters(), self.online_model.parameters()):
-            pe.lerp_(po.to(pe.dtype), 1.0 - self.beta)
+            if pe.is_cuda and pe.is_contiguous() and po.is_contiguous():
+                ops.axpby(pe.data, po.data, self.beta, 1.0 - self.beta, out=pe.data)  # HIP kernel, in place
+            else:
+                pe.lerp_(po.to(pe.dtype), 1.0 - self.beta)
 
     def forward(self, *a, **k):
         return self.ema_model(*a, **k)

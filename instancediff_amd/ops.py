@@ -303,6 +303,18 @@ def scoremap(feat, tv, idx=None):
     return out, sel
 
 
+def image_metrics(pred, target):
+    """pred/target [B,H,W] in [-1,1] -> [B,3] = (RMSE, PSNR dB, SSIM) on x/2+0.5, data_range 1 (device tensor)."""
+    lib = _lib.load()
+    pred, target = pred.contiguous(), target.contiguous()
+    _c(pred, "pred"), _c(target, "target")
+    B, H, W = pred.shape
+    out = torch.empty((B, 3), device=pred.device, dtype=torch.float32)
+    ws = torch.empty((B * 128,), device=pred.device, dtype=torch.float32)
+    check(lib.idiff_image_metrics(_p(pred), _p(target), _p(out), _p(ws), B, H, W, _stream()), "image_metrics")
+    return out
+
+
 def gather_channel(x, idx):
     lib = _lib.load()
     _c(x, "x"), _c(idx, "idx", torch.int32)

@@ -597,6 +597,9 @@ def train_step_inputRes(model):
     m.noise_optimizer.grad_scale = m.drift_optimizer.grad_scale = scale
     m.noise_optimizer.step()
     m.drift_optimizer.step()
+    for ema in (getattr(m, "dp_ema", None), getattr(m, "np_ema", None), m.dn_ema, m.nn_ema):
+        if ema is not None:  # the reference builds the EMA objects but never calls update()
+            ema.update()
     r = rec.cpu()  # the step's single device->host synchronisation (the reference does nine .item() calls)
     dl, nl = float(r[0]), float(r[1])
     dsml = float(r[2:6].sum()) / 2.0 if use_dsm else 0.0
