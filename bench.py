@@ -67,8 +67,7 @@ class StepRunner:
         sde, m, ops = self.sde, self.model, self.ops
         t = self.t
         self.tdev.fill_(float(t))
-        r_hat = m.drift_net(self.xa, self.cond, self.tdev, self.names, m.text_encoder, image_context=self.ctx)[0]
-        e_hat = m.noise_net(self.xa, self.x, self.tdev, self.names, m.text_encoder, image_context=self.ctx)[0]
+        r_hat, e_hat = sde.predict(self.xa, self.x, self.cond, self.tdev, self.names, m.text_encoder, self.ctx)
         off = self.calls * ((self.x.numel() + 3) // 4)
         self.calls += 1
         ops.drift_reverse_step(self.x, r_hat, e_hat, None, float(sde._a[t]), float(sde._b[t]), float(sde._c[t]), cond=self.cond, seed=4321,

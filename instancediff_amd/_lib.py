@@ -8,7 +8,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libidiff_hip.so")
+LIB_PATH = os.environ.get("IDIFF_LIB") or os.path.join(_HERE, "libidiff_hip.so")  # IDIFF_LIB: A/B kernel experiments
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "idiff.h")
 
 c_f32p = C.c_void_p  # device pointers travel as integers

@@ -14,6 +14,7 @@ with (a_t, b_t, c_t) from oracle-identical fp64 host arithmetic; ONE kernel per 
 (Philox) and emits the next step's `x_t - cond` network input.
 """
 import math
+import os
 
 import torch
 
@@ -71,6 +72,8 @@ class driftSDE:
         self.noise_schedule = self._h_noise.to(device) if device is not None else self._h_noise
         self.seed = 0
         self._calls = 0
+        self.two_streams = bool(int(os.environ.get("IDIFF_TWO_STREAMS", "1")))
+        self._streams = None
 
     def set_gpu(self, device):
         self.device = device
@@ -114,6 +117,29 @@ class driftSDE:
         out = net(a, b, t, names, text_encoder, image_context=image_context)
         return out[0] if isinstance(out, tuple) else out
 
+    def predict(self, xa, x, cond, tdev, names, text_encoder, image_context):
+        """(R_hat, eps_hat) of one denoising step.  The two networks are independent given the state, so on a GPU they
+        are enqueued on two HIP streams: each net's small late-stage kernels (32x32 levels, token chains, kernel tails)
+        overlap with the other net's work instead of leaving CUs idle."""
+        if not (self.two_streams and xa.is_cuda):
+            return (self._pred(self.drift_net, xa, cond, tdev, names, text_encoder, image_context),
+                    self._pred(self.noise_net, xa, x, tdev, names, text_encoder, image_context))
+        main = torch.cuda.current_stream()
+        if self._streams is None:
+            self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        s1, s2 = self._streams
+        s1.wait_stream(main)
+        s2.wait_stream(main)
+        with torch.cuda.stream(s1):
+            r_hat = self._pred(self.drift_net, xa, cond, tdev, names, text_encoder, image_context)
+        with torch.cuda.stream(s2):
+            e_hat = self._pred(self.noise_net, xa, x, tdev, names, text_encoder, image_context)
+        main.wait_stream(s1)
+        main.wait_stream(s2)
+        r_hat.record_stream(main)
+        e_hat.record_stream(main)
+        return r_hat, e_hat
+
     @torch.no_grad()
     def reverse_ddpm(self, cond, names, text_encoder, reverse_type="std", optimize_type="inputRes", image_context=None, x_T=None,
                      noises=None, T_stop=0):
@@ -133,8 +159,7 @@ class driftSDE:
         nper = (x.numel() + 3) // 4
         for i, t in enumerate(range(self.T, T_stop, -1)):
             tdev.fill_(float(t))
-            r_hat = self._pred(self.drift_net, xa, cond, tdev, names, text_encoder, image_context)
-            e_hat = self._pred(self.noise_net, xa, x, tdev, names, text_encoder, image_context)
+            r_hat, e_hat = self.predict(xa, x, cond, tdev, names, text_encoder, image_context)
             z = None if noises is None else noises[i].contiguous()
             off = self._calls * nper
             self._calls += 1
