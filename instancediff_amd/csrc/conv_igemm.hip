@@ -18,36 +18,12 @@
 // reference's fp32 cuDNN/ATen convs; roofline for this kernel = 157.3 TFLOP/s (f32 matrix peak).
 #include <stdlib.h>
 
-#include "common.h"
+#include "conv_args.h"
+
+using idiff_detail::ConvArgs;
 
 namespace {
 
-struct ConvArgs {
-    const float* src0;
-    const float* src1;
-    long long bs0, bs1;
-    int C0v, C1v;  // virtual channel counts (x4 for unshuffle)
-    int C0r;       // real channel count of src0 (prologue tables are indexed by real channel)
-    int Cin;       // C0v + C1v
-    int B, Hin, Win, Hout, Wout;
-    int Cout;
-    const float* wpk;
-    const float* bias;
-    const float* pro_a;
-    const float* pro_b;
-    float* out;
-    long long obs;
-    const float* res;
-    long long rbs;
-    const float* vec;
-    const float* aux;
-    long long abs_;
-    const float* aux_a;
-    const float* aux_b;
-    float* stats;
-    int tiles_x, ntiles, ncob;
-    unsigned total_wg;
-};
 
 // SPEC: 0 = generic (prologue / second source decided at run time); 1 = single source, no prologue;
 //       2 = single source + GN/SiLU prologue; 3 = two sources, no prologue.  The specialised forms drop the per-element
@@ -478,6 +454,7 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
     a.Win = d->Win;
     a.Cout = d->Cout;
     a.wpk = d->wpk;
+    a.wwino = d->wwino;
     a.bias = d->bias;
     a.pro_a = d->pro_a;
     a.pro_b = d->pro_b;
@@ -523,8 +500,9 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
     const long long total = (long long)a.B * a.ntiles * a.ncob;
     IDIFF_CHECK_ARG(total < (1ll << 31), "conv2d: grid too large");
     a.total_wg = (unsigned)total;
-    const bool vecw = (a.Cout % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.wpk) & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
+    if (idiff_detail::conv_wino_eligible(a, d->ks, d->mode)) return idiff_detail::launch_conv_wino(a, d->mode, st);
+    const bool vecw = (a.Cout % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.wpk) & 15) == 0);
     if (d->ks == 3) {
         if (d->mode == IDIFF_CONV_NORMAL) return dispatch_mb<3, 8, IDIFF_CONV_NORMAL>(a, twl, mb, vecw, st);
         return dispatch_mb<3, 8, IDIFF_CONV_UPSAMPLE2>(a, twl, mb, vecw, st);

@@ -2,6 +2,7 @@
 stream; every arithmetic operation below runs in the hand-written HIP kernels.  No fallbacks."""
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -51,6 +52,10 @@ def _c(t, name="tensor", dtype=torch.float32):
     return t
 
 
+# IDIFF_WINOGRAD=0 keeps every 3x3 conv on the direct implicit-GEMM kernel (A/B runs, parity bisection)
+WINOGRAD = bool(int(os.environ.get("IDIFF_WINOGRAD", "1")))
+
+
 # ---------------------------------------------------------------------------------------------------
 def pack_conv_weight(w, transpose=False):
     """[Cout,Cin,k,k] -> packed [k*k][Cin][Cout] (or the flipped/transposed pack for the data gradient)."""
@@ -60,6 +65,11 @@ def pack_conv_weight(w, transpose=False):
     out = torch.empty((k * k, co, ci) if transpose else (k * k, ci, co), device=w.device, dtype=torch.float32)
     fn = lib.idiff_pack_conv_weight_T if transpose else lib.idiff_pack_conv_weight
     check(fn(_p(w), _p(out), co, ci, k, _stream()), "pack_conv_weight")
+    if k == 3 and WINOGRAD and co % 8 == 0 and ci % 8 == 0 and (ci if transpose else co) % 64 == 0:
+        # Winograd-domain copy rides along as an attribute; conv2d hands it to the C ABI (idiff_conv_desc.wwino)
+        wino = torch.empty((16 * co * ci,), device=w.device, dtype=torch.float32)
+        check(lib.idiff_pack_conv_weight_wino(_p(w), _p(wino), co, ci, 1 if transpose else 0, _stream()), "pack_conv_weight_wino")
+        out.wino = wino
     return out
 
 
@@ -81,6 +91,9 @@ def conv2d(src0, wpk, bias, ks, Cout, src1=None, mode=CONV_NORMAL, pro=None, out
     d.B, d.Hin, d.Win, d.mode, d.ks, d.Cout = B, Hin, Win, mode, ks, Cout
     _c(wpk, "wpk")
     d.wpk = wpk.data_ptr()
+    wino = getattr(wpk, "wino", None)
+    if wino is not None and ks == 3:
+        d.wwino = wino.data_ptr()
     if bias is not None:
         d.bias = _c(bias, "bias").data_ptr()
     if pro is not None:

@@ -298,3 +298,77 @@ def test_philox_bit_exact_and_randn():
     a = ops.irsde_reverse_step(x, mu, npred, zz, **kw)
     b = ops.irsde_reverse_step(x, mu, npred, None, seed=7, offset=100, **kw)
     assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Winograd F(2x2,3x3) kernel (conv_wino.hip) vs the direct implicit-GEMM kernel and the fp64 reference
+def _pack(w, wino, transpose=False):
+    old = ops.WINOGRAD
+    ops.WINOGRAD = wino
+    try:
+        p = ops.pack_conv_weight(w, transpose=transpose)
+    finally:
+        ops.WINOGRAD = old
+    assert hasattr(p, "wino") == wino
+    return p
+
+
+@pytest.mark.parametrize("B,C0,C1,Cout,H,W,variant", [
+    (2, 64, 0, 64, 32, 32, "plain"),
+    (1, 8, 0, 128, 8, 64, "plain"),         # one chunk, two channel blocks, 1x2 patches
+    (2, 64, 0, 64, 16, 96, "prologue"),
+    (1, 24, 40, 192, 24, 32, "concat"),
+    (2, 32, 0, 64, 16, 16, "upsample"),     # out 32x32
+    (1, 128, 0, 256, 64, 64, "epilogue"),
+])
+def test_conv_winograd_matches_direct_and_fp64(B, C0, C1, Cout, H, W, variant):
+    g = _g(11)
+    Cin = C0 + C1
+    x0 = torch.randn(B, C0, H, W, generator=g)
+    x1 = torch.randn(B, C1, H, W, generator=g) if C1 else None
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    kw = {}
+    xin = x0.double() if x1 is None else torch.cat([x0, x1], 1).double()
+    if variant == "prologue":
+        pa, pb = torch.randn(B, C0, generator=g), torch.randn(B, C0, generator=g)
+        xin = silu64(pa.double()[:, :, None, None] * xin + pb.double()[:, :, None, None])
+        kw["pro"] = (pa.to(DEV), pb.to(DEV))
+    if variant == "upsample":
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+        kw["mode"] = ops.CONV_UPSAMPLE2
+    if x1 is not None:
+        kw["src1"] = x1.to(DEV)
+    raw = F.conv2d(xin, w.double(), b.double(), padding=1)
+    ref = raw
+    Ho, Wo = raw.shape[2:]
+    if variant == "epilogue":
+        res = torch.randn(B, Cout, Ho, Wo, generator=g)
+        vec = torch.randn(B, Cout, generator=g)
+        aux = torch.randn(B, Cout, Ho, Wo, generator=g)
+        aa, ab = torch.randn(B, Cout, generator=g), torch.randn(B, Cout, generator=g)
+        ref = raw + res.double() + vec.double()[:, :, None, None] + silu64(aa.double()[:, :, None, None] * aux.double() + ab.double()[:, :, None, None])
+        kw.update(res=res.to(DEV), vec=vec.to(DEV), aux=(aux.to(DEV), aa.to(DEV), ab.to(DEV)))
+    wd = w.to(DEV)
+    out_w, st_w = ops.conv2d(x0.to(DEV), _pack(wd, True), b.to(DEV), 3, Cout, want_stats=True, **kw)
+    out_d, st_d = ops.conv2d(x0.to(DEV), _pack(wd, False), b.to(DEV), 3, Cout, want_stats=True, **kw)
+    _close(out_d, ref, 2e-6, "direct")
+    _close(out_w, ref, 6e-6, "winograd")          # a few ulps of reassociation more than the direct kernel
+    assert st_w.shape == st_d.shape
+    _close(st_w.sum(1)[..., 0], raw.sum(dim=(2, 3)), 1e-5, "winograd stats sum")
+    _close(st_w.sum(1)[..., 1], (raw ** 2).sum(dim=(2, 3)), 1e-5, "winograd stats sumsq")
+    _close(st_w, st_d.cpu(), 2e-5, "per-patch stats layout")
+
+
+def test_conv_winograd_data_gradient_pack():
+    """The transposed pack feeds the data-gradient conv: dX = conv(dY, flip(W)^T)."""
+    g = _g(12)
+    B, Cin, Cout, H, W = 2, 64, 128, 16, 32
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    ref = F.conv_transpose2d(dy.double(), w.double(), padding=1)
+    wd = w.to(DEV)
+    dx_w = ops.conv2d(dy.to(DEV), _pack(wd, True, transpose=True), None, 3, Cin)
+    dx_d = ops.conv2d(dy.to(DEV), _pack(wd, False, transpose=True), None, 3, Cin)
+    _close(dx_d, ref, 2e-6, "direct dgrad")
+    _close(dx_w, ref, 6e-6, "winograd dgrad")
