@@ -21,6 +21,8 @@
 //   conv_igemm.hip; the two kernels are interchangeable behind idiff_conv2d_fwd.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "conv_args.h"
 
 using idiff_detail::ConvArgs;
@@ -33,27 +35,31 @@ constexpr int RS = TW + 2;         // 34
 constexpr int TRH = TH + 2;        // 10
 constexpr int PS = TRH * RS;       // 340
 constexpr int PSP = 352;           // padded channel stride of R: ci and ci+1 land 32 banks apart
-constexpr int R_FLOATS = CK * PSP; // 2816
+constexpr int NT = 512;
+constexpr int R_FLOATS = 6 * NT;   // 8*352 = 2816 used; rounded up so every thread stages exactly 6 elements, unmasked
 constexpr int V_FLOATS = 16 * 4 * 4 * 16 * 2;  // 8192
 constexpr int U_FLOATS = V_FLOATS;
-constexpr int NT = 512;
-constexpr int NL = (CK * PS + NT - 1) / NT;    // 6 gathered elements per thread per chunk
+constexpr int NL = R_FLOATS / NT;              // 6 gathered elements per thread per chunk (element index = R index)
 constexpr int NU = U_FLOATS / 4 / NT;          // 4 float4 of weights per thread per chunk
 
 typedef float floatx2 __attribute__((ext_vector_type(2)));
+
+#ifndef IDIFF_WINO_PD
+#define IDIFF_WINO_PD 1  // operand prefetch distance of the MFMA loop, in Winograd positions
+#endif
 
 // SPEC: 1 = single source, no prologue; 2 = single source + GN/FiLM/SiLU prologue; 3 = two sources (virtual concat)
 template <int MODE, int SPEC>
 __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const R = smem;
-    float* const Vb = smem + R_FLOATS;
+    float* const Rb = smem;                   // [2][R_FLOATS]
+    float* const Vb = smem + 2 * R_FLOATS;
     float* const Ub = Vb + 2 * V_FLOATS;
     float* const protab = Ub + 2 * U_FLOATS;  // [2][C0r] (SPEC 2)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: role tests below are uniform branches
     const int j = lane & 15;   // tile column (B operand / C column) and co row within a 16-block (A operand)
     const int k4 = lane >> 4;  // k index within a group of 4 (operands) / row group of the C layout
     const int ch = wave & 1;   // co half of the MFMA role; u-pair of the transform role
@@ -69,20 +75,21 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a) {
     const int HWin = a.Hin * a.Win;
 
     // ---- per-thread gather descriptors (constant across chunks) ---------------------------------
-    int goff[NL], rdst[NL];
+    // thread stages R[tid + i*512]: the R index itself enumerates (ci, row, col) with the padded channel stride, so the
+    // LDS writes are linear and unmasked; pad slots and out-of-image pixels carry offset -1, which the raw buffer load answers with 0.0
+    int goff[NL];
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         const int e = tid + i * NT;
-        const int ci = e / PS;
-        const int rem = e - ci * PS;
+        const int ci = e / PSP;
+        const int rem = e - ci * PSP;
         const int r = rem / RS;
         const int c = rem - r * RS;
         const int oy = y0 - 1 + r;
         const int ox = x0 - 1 + c;
-        const bool inb = oy >= 0 && oy < a.Hout && ox >= 0 && ox < a.Wout;
+        const bool inb = ci < CK && rem < PS && oy >= 0 && oy < a.Hout && ox >= 0 && ox < a.Wout;
         const int sp = MODE == IDIFF_CONV_UPSAMPLE2 ? (oy >> 1) * a.Win + (ox >> 1) : oy * a.Win + ox;
-        goff[i] = (e < CK * PS && inb) ? ci * HWin + sp : -1;   // -1: zero padding (or no element)
-        rdst[i] = e < CK * PS ? ci * PSP + r * RS + c : -1;
+        goff[i] = inb ? (ci * HWin + sp) * 4 : -1;  // byte offset; -1 is out of range for the buffer load -> reads 0.0
     }
     if (SPEC == 2) {
         for (int i = tid; i < a.C0r; i += NT) {
@@ -92,84 +99,93 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a) {
     }
 
     const int nchunks = a.Cin / CK;
-    const float* const sample0 = a.src0 + (long long)b * a.bs0;
-    const float* const sample1 = SPEC == 3 ? a.src1 + (long long)b * a.bs1 : nullptr;
-    const float* const ubase = a.wwino + (long long)cob * U_FLOATS;
-    const long long ustride = (long long)a.ncob * U_FLOATS;
+    // Raw buffer loads: uniform base in the resource, chunk offset in an SGPR, per-lane byte offset in one VGPR -> no
+    // per-load address arithmetic on the vector ALU (which the f32 MFMAs share), and offset -1 fails the range check
+    // and returns 0.0, which is the zero padding.
+    constexpr int RSRC_FLAGS = 0x00020000;
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0 + (long long)b * a.bs0), 0, 0x7fffffff, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(SPEC == 3 ? a.src1 + (long long)b * a.bs1 : a.src0), 0, 0x7fffffff, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wwino + (long long)cob * U_FLOATS), 0, 0x7fffffff, RSRC_FLAGS);
+    const int ustride_b = a.ncob * U_FLOATS * 4;  // bytes between chunks of this channel block (whole U < 2^31 bytes)
 
     float rin[NL];
     floatx4 ru[NU];
 
-    auto load_regs = [&](int cc) {
+    // ---- the pieces of one chunk's staging work; the main loop deals them out between the MFMA groups ------------
+    auto load_raw = [&](int cc) {  // global -> registers (consumed one iteration later)
         const int cb = cc * CK;
-        const float* base = sample0 + (long long)cb * HWin;
-        if (SPEC == 3 && cb >= a.C0v) base = sample1 + (long long)(cb - a.C0v) * HWin;  // chunk-uniform: C0v % 8 == 0
+        if (SPEC == 3 && cb >= a.C0v) {  // chunk-uniform: C0v % 8 == 0
+            const int so = (cb - a.C0v) * HWin * 4;
 #pragma unroll
-        for (int i = 0; i < NL; ++i) rin[i] = base[goff[i] < 0 ? 0 : goff[i]];
-        const floatx4* up = reinterpret_cast<const floatx4*>(ubase + cc * ustride);
+            for (int i = 0; i < NL; ++i) rin[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, goff[i], so, 0));
+        } else {
+            const int so = cb * HWin * 4;
 #pragma unroll
-        for (int i = 0; i < NU; ++i) ru[i] = up[tid + i * NT];
-    };
-
-    // activation + zero padding + LDS write of the staged chunk cc (R, single buffer) and its weights (U[buf])
-    auto stage = [&](int cc, int buf) {
-        const int cb = cc * CK;
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            float x = rin[i];
-            if (SPEC == 2) {
-                const int chn = cb + (tid + i * NT) / PS;
-                const int chc = chn < a.C0r ? chn : 0;
-                x = silu_fast(protab[chc] * x + protab[a.C0r + chc]);
-            }
-            if (rdst[i] >= 0) R[rdst[i]] = goff[i] >= 0 ? x : 0.f;
+            for (int i = 0; i < NL; ++i) rin[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs0, goff[i], so, 0));
         }
-        floatx4* ud = reinterpret_cast<floatx4*>(Ub + buf * U_FLOATS);
-#pragma unroll
-        for (int i = 0; i < NU; ++i) ud[tid + i * NT] = ru[i];
     };
+    auto load_u = [&](int cc) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i)
+            ru[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsu, tid * 16, cc * ustride_b + i * NT * 16, 0));
+    };
+    // activation (GroupNorm/FiLM affine + SiLU of the producer) + zero padding + LDS write of staged element i
+    auto stage_raw = [&](int i, int cc, int rbuf) {
+        float x = rin[i];
+        if (SPEC == 2) {
+            const int cil = (tid + i * NT) / PSP;
+            const int chc = cc * CK + (cil < CK ? cil : 0);
+            x = silu_fast(protab[chc] * x + protab[a.C0r + chc]);
+        }
+        Rb[rbuf * R_FLOATS + tid + i * NT] = (SPEC == 2 && goff[i] < 0) ? 0.f : x;  // padding is zero AFTER the activation
+    };
+    auto stage_u = [&](int i, int buf) { reinterpret_cast<floatx4*>(Ub + buf * U_FLOATS)[tid + i * NT] = ru[i]; };
 
     // input transform B^T d B of the patch in R -> V[buf].  Thread = (u-pair ch, tile row tb, k4, tile j), both
     // channels ci = k4, k4+4 of the chunk; u-pair 0 needs patch rows 0..2 of the tile, u-pair 1 rows 1..3.
-    auto transform = [&](int buf) {
-        float* const V = Vb + buf * V_FLOATS;
-        float o[2][4][2];
+    // Roles are made arithmetically uniform (no per-role selects on the vector ALU): u-pair 0 reads patch rows
+    // (p,q,r) = (0,1,2) of its tile, u-pair 1 reads them reversed, (3,2,1); then for both
+    //     tA = p - r          -> u = 0          | -(d1 - d3) = -t[u=3]
+    //     tB = q + s*r        -> u = 1 (s = +1) |   d2 - d1  =  t[u=2]   (s = -1)
+    // so Winograd rows are kept in the order rho = (u0, u1, -u3, u2); idiff_pack_conv_weight_wino stores U in the
+    // same order with row u3 negated (the product U.V is unchanged), and the output transform reads acc rows (0,1,3,2).
+    float td[3][4];     // patch rows (p, q, r) in flight between tr_read and tr_compute
+    float to[2][4][2];  // transformed values [row within pair][v][g]
+    const float* const trP = Rb + k4 * PSP + (2 * tb + 3 * ch) * RS + 2 * j;
+    const float* const trQ = Rb + k4 * PSP + (2 * tb + 1 + ch) * RS + 2 * j;
+    const float* const trR = Rb + k4 * PSP + (2 * tb + 2 - ch) * RS + 2 * j;
+    const float tsign = ch ? -1.f : 1.f;
+    auto tr_read = [&](int g, int rbuf) {
+        const int o = rbuf * R_FLOATS + 4 * g * PSP;
+        const float* rows[3] = {trP + o, trQ + o, trR + o};
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const float* p = R + (k4 + 4 * g) * PSP + (2 * tb + ch) * RS + 2 * j;
-            float d[3][4];
+        for (int r = 0; r < 3; ++r) {
+            const floatx2 lo = *reinterpret_cast<const floatx2*>(rows[r]);
+            const floatx2 hi = *reinterpret_cast<const floatx2*>(rows[r] + 2);
+            td[r][0] = lo.x, td[r][1] = lo.y, td[r][2] = hi.x, td[r][3] = hi.y;
+        }
+    };
+    auto tr_compute = [&](int g) {
+        float t[2][4];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const floatx2 lo = *reinterpret_cast<const floatx2*>(p + r * RS);
-                const floatx2 hi = *reinterpret_cast<const floatx2*>(p + r * RS + 2);
-                d[r][0] = lo.x, d[r][1] = lo.y, d[r][2] = hi.x, d[r][3] = hi.y;
-            }
-            float t[2][4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (ch == 0) {  // rows (0,1,2): u=0: d0-d2, u=1: d1+d2
-                    t[0][c] = d[0][c] - d[2][c];
-                    t[1][c] = d[1][c] + d[2][c];
-                } else {        // rows (1,2,3): u=2: d2-d1, u=3: d1-d3
-                    t[0][c] = d[1][c] - d[0][c];
-                    t[1][c] = d[0][c] - d[2][c];
-                }
-            }
-#pragma unroll
-            for (int uu = 0; uu < 2; ++uu) {
-                o[uu][0][g] = t[uu][0] - t[uu][2];
-                o[uu][1][g] = t[uu][1] + t[uu][2];
-                o[uu][2][g] = t[uu][2] - t[uu][1];
-                o[uu][3][g] = t[uu][1] - t[uu][3];
-            }
+        for (int c = 0; c < 4; ++c) {
+            t[0][c] = td[0][c] - td[2][c];
+            t[1][c] = __builtin_fmaf(tsign, td[2][c], td[1][c]);
         }
 #pragma unroll
-        for (int uu = 0; uu < 2; ++uu)
+        for (int uu = 0; uu < 2; ++uu) {
+            to[uu][0][g] = t[uu][0] - t[uu][2];
+            to[uu][1][g] = t[uu][1] + t[uu][2];
+            to[uu][2][g] = t[uu][2] - t[uu][1];
+            to[uu][3][g] = t[uu][1] - t[uu][3];
+        }
+    };
+    float* const vwbase = Vb + ch * 4096 + (tb * 4 + k4) * 32 + j * 2;  // Winograd position = 8*ch + 4*uu + v
+    auto tr_write = [&](int uu, int buf) {
+        float* const V = vwbase + buf * V_FLOATS;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int xi = (2 * ch + uu) * 4 + v;
-                *reinterpret_cast<floatx2*>(V + ((xi * 4 + tb) * 4 + k4) * 32 + j * 2) = floatx2{o[uu][v][0], o[uu][v][1]};
-            }
+        for (int v = 0; v < 4; ++v) *reinterpret_cast<floatx2*>(V + (uu * 4 + v) * 512) = floatx2{to[uu][v][0], to[uu][v][1]};
     };
 
     floatx4 acc[16][2];
@@ -178,46 +194,84 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a) {
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) acc[xi][mb] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    // 8 Winograd positions of chunk buffer `buf`: per xi one B read + two A reads (ds_read_b64) -> 4 MFMAs
-    auto mfma8 = [&](int buf, int lo) {
-        const float* V = Vb + buf * V_FLOATS + (tb * 4 + k4) * 32 + j * 2;
-        const float* U = Ub + buf * U_FLOATS + (ch * 2 * 4 + k4) * 32 + j * 2;
+    // ---- pipeline fill: V[0], U[0] hold chunk 0, R[1] chunk 1; raw(2) and U(1) are in registers ----------------------
+    auto clampc = [&](int c) { return c < nchunks ? c : nchunks - 1; };
+    load_raw(0);
+    load_u(0);
+    if (SPEC == 2) __syncthreads();  // protab visible
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int xi = lo + q;
-            const floatx2 bv = *reinterpret_cast<const floatx2*>(V + xi * 512);
+    for (int i = 0; i < NL; ++i) stage_raw(i, 0, 0);
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const floatx2 av = *reinterpret_cast<const floatx2*>(U + xi * 512 + mb * 128);
-                acc[xi][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[xi][mb], 0, 0, 0);
-                acc[xi][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[xi][mb], 0, 0, 0);
+    for (int i = 0; i < NU; ++i) stage_u(i, 0);
+    load_raw(clampc(1));
+    __syncthreads();
+    tr_read(0, 0), tr_compute(0);
+    tr_read(1, 0), tr_compute(1);
+    tr_write(0, 0), tr_write(1, 0);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) stage_raw(i, clampc(1), 1);
+    load_raw(clampc(2));
+    load_u(clampc(1));
+    __syncthreads();
+
+    // ---- main loop, ONE barrier per chunk.  Iteration c runs the 16 Winograd positions of chunk c (per position one B
+    // read + two A reads (ds_read_b64) -> 4 MFMAs, operands requested PD positions ahead) and, dealt out one slice per
+    // position and fenced with sched_barrier so each slice issues while the matrix pipe is busy:
+    //   stage raw(c+2) registers -> R[c&1],  stage U(c+1) registers -> U[(c+1)&1],
+    //   global loads raw(c+3), U(c+2) -> registers,  transform R[(c+1)&1] (staged one iteration ago) -> V[(c+1)&1].
+    // The slices of one iteration are mutually independent; every buffer written here was last read one barrier ago.
+    // (Left alone, hipcc hoists the operand reads and sinks the MFMAs across barriers, idling the matrix pipe.)
+    constexpr int PD = IDIFF_WINO_PD;
+    const int opoff = k4 * 32 + j * 2;
+    auto chunk = [&](int cc, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;  // false: last chunk, nothing left to stage
+        const int buf = cc & 1;
+        const float* V = Vb + buf * V_FLOATS + tb * 128 + opoff;
+        const float* U = Ub + buf * U_FLOATS + ch * 256 + opoff;
+        floatx2 ob[PD + 1], oa0[PD + 1], oa1[PD + 1];
+#pragma unroll
+        for (int q = 0; q < PD; ++q) {
+            ob[q] = *reinterpret_cast<const floatx2*>(V + q * 512);
+            oa0[q] = *reinterpret_cast<const floatx2*>(U + q * 512);
+            oa1[q] = *reinterpret_cast<const floatx2*>(U + q * 512 + 128);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+#if defined(IDIFF_WINO_EXP) && IDIFF_WINO_EXP >= 2
+            if (false) {
+#else
+            if (q + PD < 16) {
+#endif
+                ob[(q + PD) % (PD + 1)] = *reinterpret_cast<const floatx2*>(V + (q + PD) * 512);
+                oa0[(q + PD) % (PD + 1)] = *reinterpret_cast<const floatx2*>(U + (q + PD) * 512);
+                oa1[(q + PD) % (PD + 1)] = *reinterpret_cast<const floatx2*>(U + (q + PD) * 512 + 128);
+            }
+            const floatx2 bv = ob[q % (PD + 1)], av0 = oa0[q % (PD + 1)], av1 = oa1[q % (PD + 1)];
+            acc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0.x, bv.x, acc[q][0], 0, 0, 0);
+            acc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1.x, bv.x, acc[q][1], 0, 0, 0);
+            acc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0.y, bv.y, acc[q][0], 0, 0, 0);
+            acc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1.y, bv.y, acc[q][1], 0, 0, 0);
+            if (MORE) {
+#ifndef IDIFF_WINO_SKIP
+#define IDIFF_WINO_SKIP 0
+#endif
+                if (!(IDIFF_WINO_SKIP & 1) && q < 6) stage_raw(q, clampc(cc + 2), buf);
+                if (!(IDIFF_WINO_SKIP & 2) && q >= 4 && q < 8) stage_u(q - 4, buf ^ 1);
+                if (!(IDIFF_WINO_SKIP & 4) && q == 8) load_raw(clampc(cc + 3));
+                if (!(IDIFF_WINO_SKIP & 4) && q == 9) load_u(clampc(cc + 2));
+                if (!(IDIFF_WINO_SKIP & 8) && q == 10) tr_read(0, buf ^ 1);
+                if (!(IDIFF_WINO_SKIP & 8) && q == 11) tr_compute(0);
+                if (!(IDIFF_WINO_SKIP & 8) && q == 12) tr_read(1, buf ^ 1);
+                if (!(IDIFF_WINO_SKIP & 8) && q == 13) tr_compute(1);
+                if (!(IDIFF_WINO_SKIP & 8) && q == 14) tr_write(0, buf ^ 1);
+                if (!(IDIFF_WINO_SKIP & 8) && q == 15) tr_write(1, buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(IDIFF_WINO_SKIP & 16) && q == 15) __syncthreads();
             }
         }
     };
-
-    load_regs(0);
-    if (SPEC == 2) __syncthreads();  // protab visible
-    stage(0, 0);
-    __syncthreads();
-    transform(0);
-    load_regs(nchunks > 1 ? 1 : 0);
-    __syncthreads();
-
-    for (int cc = 0; cc + 1 < nchunks; ++cc) {
-        const int buf = cc & 1;
-        mfma8(buf, 0);
-        stage(cc + 1, buf ^ 1);
-        __syncthreads();
-        mfma8(buf, 8);
-        transform(buf ^ 1);
-        load_regs(cc + 2 < nchunks ? cc + 2 : nchunks - 1);
-        __syncthreads();
-    }
-    {
-        const int buf = (nchunks - 1) & 1;
-        mfma8(buf, 0);
-        mfma8(buf, 8);
-    }
+    for (int cc = 0; cc + 1 < nchunks; ++cc) chunk(cc, std::true_type{});
+    chunk(nchunks - 1, std::false_type{});
 
     // ---- epilogue: in-lane output transform A^T m A, then the conv_igemm epilogue contract -----------------------
     // C layout of 16x16x4: lane holds column j (tile) and rows 4*k4 + r of each 16-row block
@@ -236,7 +290,8 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a) {
             float z[4][2];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float m0 = acc[u * 4 + 0][mb][r], m1 = acc[u * 4 + 1][mb][r], m2 = acc[u * 4 + 2][mb][r], m3 = acc[u * 4 + 3][mb][r];
+                const int rho = u < 2 ? u : 5 - u;  // accumulator rows are stored in the order (u0, u1, u3, u2)
+                const float m0 = acc[rho * 4 + 0][mb][r], m1 = acc[rho * 4 + 1][mb][r], m2 = acc[rho * 4 + 2][mb][r], m3 = acc[rho * 4 + 3][mb][r];
                 z[u][0] = m0 + m1 + m2;
                 z[u][1] = m1 - m2 - m3;
             }
@@ -286,15 +341,15 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a) {
                 sv[q] = keep + __shfl_xor(send, m, 64);
             }
         }
-        __syncthreads();  // all MFMA-phase LDS reads are done: reuse R as the cross-wave scratch [4 tb][64 co][2]
+        __syncthreads();  // all MFMA-phase LDS reads are done: reuse R[0] as the cross-wave scratch [4 tb][64 co][2]
         {
             const int mb = j >> 3, r = (j >> 1) & 3, w = j & 1;
             const int col = ch * 32 + mb * 16 + 4 * k4 + r;
-            R[(tb * 64 + col) * 2 + w] = sv[0];
+            Rb[(tb * 64 + col) * 2 + w] = sv[0];
         }
         __syncthreads();
         if (tid < 128) {
-            const float t = (R[tid] + R[128 + tid]) + (R[256 + tid] + R[384 + tid]);
+            const float t = (Rb[tid] + Rb[128 + tid]) + (Rb[256 + tid] + Rb[384 + tid]);
             const int col = tid >> 1, w = tid & 1;
             a.stats[(((long long)b * a.ntiles + tile) * a.Cout + co0 + col) * 2 + w] = t;
         }
@@ -303,7 +358,7 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a) {
 
 template <int MODE, int SPEC>
 int launch(const ConvArgs& a, hipStream_t st) {
-    const size_t lds = ((size_t)R_FLOATS + 2 * V_FLOATS + 2 * U_FLOATS + (SPEC == 2 ? 2 * (size_t)a.C0r : 0)) * sizeof(float);
+    const size_t lds = ((size_t)2 * R_FLOATS + 2 * V_FLOATS + 2 * U_FLOATS + (SPEC == 2 ? 2 * (size_t)a.C0r : 0)) * sizeof(float);
     if (lds > 160 * 1024) IDIFF_FAIL(IDIFF_E_UNSUPPORTED, "conv2d(winograd): LDS budget exceeded (%zu bytes)", lds);
     static size_t attr_set = 0;
     auto kern = conv_wino_kernel<MODE, SPEC>;
@@ -343,12 +398,14 @@ __global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict_
         const int cb = co >> 6, col = co & 63, coblk = col >> 4, i16 = col & 15;
         float* dst = out + ((long long)cc * ncob + cb) * U_FLOATS + ((coblk * 4 + kk) * 16 + i16) * 2 + gg;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int rho = 0; rho < 4; ++rho) {  // stored row order (u0, u1, -u3, u2): see the kernel's input transform
+            const int u = rho < 2 ? rho : 5 - rho;
+            const float sg = rho == 2 ? -1.f : 1.f;
             const float v0 = t[u][0], v1 = 0.5f * (t[u][0] + t[u][1] + t[u][2]), v2 = 0.5f * (t[u][0] - t[u][1] + t[u][2]), v3 = t[u][2];
-            dst[(u * 4 + 0) * 512] = v0;
-            dst[(u * 4 + 1) * 512] = v1;
-            dst[(u * 4 + 2) * 512] = v2;
-            dst[(u * 4 + 3) * 512] = v3;
+            dst[(rho * 4 + 0) * 512] = sg * v0;
+            dst[(rho * 4 + 1) * 512] = sg * v1;
+            dst[(rho * 4 + 2) * 512] = sg * v2;
+            dst[(rho * 4 + 3) * 512] = sg * v3;
         }
     }
 }
