@@ -44,13 +44,37 @@ constexpr int NU = U_FLOATS / 4 / NT;          // 4 float4 of weights per thread
 
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 
+// -DIDIFF_WINO_TRACE: per-phase cycle counts (s_memtime) summed over all items, printed by the launcher (debug builds)
+#ifdef IDIFF_WINO_TRACE
+#define TRACE_PARAM , long long* trace
+#define TRACE_INIT long long tr_t[4] = {0, 0, 0, 0}, tr_acc[3] = {0, 0, 0};
+#define TRACE_MARK(k)                                      \
+    tr_t[k] = __builtin_readcyclecounter();                \
+    if (k > 0) tr_acc[k - 1] += tr_t[k] - tr_t[k - 1];
+#define TRACE_FINI                                                                  \
+    if (tid == 0) {                                                                 \
+        atomicAdd((unsigned long long*)trace + 0, (unsigned long long)tr_acc[0]);   \
+        atomicAdd((unsigned long long*)trace + 1, (unsigned long long)tr_acc[1]);   \
+        atomicAdd((unsigned long long*)trace + 2, (unsigned long long)tr_acc[2]);   \
+    }
+#else
+#define TRACE_PARAM
+#define TRACE_INIT
+#define TRACE_MARK(k)
+#define TRACE_FINI
+#endif
+
 #ifndef IDIFF_WINO_PD
 #define IDIFF_WINO_PD 1  // operand prefetch distance of the MFMA loop, in Winograd positions
 #endif
 
 // SPEC: 1 = single source, no prologue; 2 = single source + GN/FiLM/SiLU prologue; 3 = two sources (virtual concat)
+//
+// Persistent: the grid is one workgroup per CU (the 155 KB of LDS allow one anyway); workgroup w walks the contiguous
+// item range [w*per, (w+1)*per) of (sample, patch, channel-block) items, channel block fastest, so the blocks of one
+// patch reuse its input from L2.  The first global loads of item i+1 are issued before the epilogue of item i.
 template <int MODE, int SPEC>
-__global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a, const int per TRACE_PARAM) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const Rb = smem;                   // [2][R_FLOATS]
     float* const Vb = smem + 2 * R_FLOATS;
@@ -59,25 +83,21 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: role tests below are uniform branches
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: role-dependent addresses stay on the SALU
     const int j = lane & 15;   // tile column (B operand / C column) and co row within a 16-block (A operand)
     const int k4 = lane >> 4;  // k index within a group of 4 (operands) / row group of the C layout
     const int ch = wave & 1;   // co half of the MFMA role; u-pair of the transform role
     const int tb = wave >> 1;  // tile row (both roles)
-
-    const unsigned logical = xcd_remap(blockIdx.x, a.total_wg);
-    const int cob = logical % a.ncob;
-    const int tile = (logical / a.ncob) % a.ntiles;
-    const int b = logical / (a.ncob * a.ntiles);
-    const int co0 = cob * 64;
-    const int y0 = (tile / a.tiles_x) * TH;
-    const int x0 = (tile % a.tiles_x) * TW;
     const int HWin = a.Hin * a.Win;
+    const int nchunks = a.Cin / CK;
 
-    // ---- per-thread gather descriptors (constant across chunks) ---------------------------------
-    // thread stages R[tid + i*512]: the R index itself enumerates (ci, row, col) with the padded channel stride, so the
-    // LDS writes are linear and unmasked; pad slots and out-of-image pixels carry offset -1, which the raw buffer load answers with 0.0
-    int goff[NL];
+    // ---- per-thread gather descriptors, constant for the whole kernel ------------------------------------------------
+    // Thread stages R[tid + i*512]: the R index itself enumerates (ci, row, col) with the padded channel stride, so the
+    // LDS writes are linear and unmasked.  gconst = byte offset relative to the patch origin (halo corner), or -1 for
+    // pad slots; eflags = 4 bits per element: on the top / bottom / left / right halo edge.  Per item the edges that
+    // fall outside the image turn their elements' offsets into -1, which the raw buffer load answers with 0.0.
+    int gconst[NL];
+    unsigned eflags = 0;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         const int e = tid + i * NT;
@@ -85,44 +105,52 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a) {
         const int rem = e - ci * PSP;
         const int r = rem / RS;
         const int c = rem - r * RS;
-        const int oy = y0 - 1 + r;
-        const int ox = x0 - 1 + c;
-        const bool inb = ci < CK && rem < PS && oy >= 0 && oy < a.Hout && ox >= 0 && ox < a.Wout;
-        const int sp = MODE == IDIFF_CONV_UPSAMPLE2 ? (oy >> 1) * a.Win + (ox >> 1) : oy * a.Win + ox;
-        goff[i] = inb ? (ci * HWin + sp) * 4 : -1;  // byte offset; -1 is out of range for the buffer load -> reads 0.0
-    }
-    if (SPEC == 2) {
-        for (int i = tid; i < a.C0r; i += NT) {
-            protab[i] = a.pro_a[(long long)b * a.C0r + i];
-            protab[a.C0r + i] = a.pro_b[(long long)b * a.C0r + i];
-        }
+        const int sp = MODE == IDIFF_CONV_UPSAMPLE2 ? (((r - 1) >> 1) + 1) * a.Win + ((c - 1) >> 1) + 1 : r * a.Win + c;
+        gconst[i] = (ci < CK && rem < PS) ? (ci * HWin + sp) * 4 : -1;
+        eflags |= ((r == 0 ? 1u : 0u) | (r == TRH - 1 ? 2u : 0u) | (c == 0 ? 4u : 0u) | (c == RS - 1 ? 8u : 0u)) << (4 * i);
     }
 
-    const int nchunks = a.Cin / CK;
+    // ---- per-item state ---------------------------------------------------------------------------------------------
     // Raw buffer loads: uniform base in the resource, chunk offset in an SGPR, per-lane byte offset in one VGPR -> no
-    // per-load address arithmetic on the vector ALU (which the f32 MFMAs share), and offset -1 fails the range check
-    // and returns 0.0, which is the zero padding.
+    // per-load address arithmetic on the vector ALU (which the f32 MFMAs share); offset -1 fails the range check.
     constexpr int RSRC_FLAGS = 0x00020000;
-    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0 + (long long)b * a.bs0), 0, 0x7fffffff, RSRC_FLAGS);
-    const __amdgpu_buffer_rsrc_t rs1 =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(SPEC == 3 ? a.src1 + (long long)b * a.bs1 : a.src0), 0, 0x7fffffff, RSRC_FLAGS);
-    const __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wwino + (long long)cob * U_FLOATS), 0, 0x7fffffff, RSRC_FLAGS);
-    const int ustride_b = a.ncob * U_FLOATS * 4;  // bytes between chunks of this channel block (whole U < 2^31 bytes)
+    __amdgpu_buffer_rsrc_t rs0, rs1, rsu;
+    int goff[NL];
+    int it_b = 0, it_tile = 0, it_co0 = 0, it_y0 = 0, it_x0 = 0;
+    auto setup_item = [&](int item) {
+        const int cob = item % a.ncob;
+        it_tile = (item / a.ncob) % a.ntiles;
+        it_b = item / (a.ncob * a.ntiles);
+        it_co0 = cob * 64;
+        it_y0 = (it_tile / a.tiles_x) * TH;
+        it_x0 = (it_tile % a.tiles_x) * TW;
+        // element (row 0, col 0) of the halo patch; may lie before the tensor for border patches (never dereferenced)
+        const long long org = MODE == IDIFF_CONV_UPSAMPLE2 ? (long long)(it_y0 / 2 - 1) * a.Win + (it_x0 / 2 - 1)
+                                                           : (long long)(it_y0 - 1) * a.Win + (it_x0 - 1);
+        rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0 + (long long)it_b * a.bs0 + org), 0, 0x7fffffff, RSRC_FLAGS);
+        rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(SPEC == 3 ? a.src1 + (long long)it_b * a.bs1 + org : a.src0), 0, 0x7fffffff,
+                                                RSRC_FLAGS);
+        rsu = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wwino + (long long)cob * U_FLOATS), 0, 0x7fffffff, RSRC_FLAGS);
+        const unsigned out_edges = (it_y0 == 0 ? 1u : 0u) | (it_y0 + TH == a.Hout ? 2u : 0u) | (it_x0 == 0 ? 4u : 0u) | (it_x0 + TW == a.Wout ? 8u : 0u);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) goff[i] = ((eflags >> (4 * i)) & out_edges) ? -1 : gconst[i];
+    };
+    const int ustride_b = a.ncob * U_FLOATS * 4;  // bytes between chunks of one channel block (whole U < 2^31 bytes)
 
-    float rin[NL];
+    float rin[NL], rin1[NL];
     floatx4 ru[NU];
 
     // ---- the pieces of one chunk's staging work; the main loop deals them out between the MFMA groups ------------
-    auto load_raw = [&](int cc) {  // global -> registers (consumed one iteration later)
+    auto load_raw = [&](float (&dst)[NL], int cc) {  // global -> registers
         const int cb = cc * CK;
         if (SPEC == 3 && cb >= a.C0v) {  // chunk-uniform: C0v % 8 == 0
             const int so = (cb - a.C0v) * HWin * 4;
 #pragma unroll
-            for (int i = 0; i < NL; ++i) rin[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, goff[i], so, 0));
+            for (int i = 0; i < NL; ++i) dst[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, goff[i], so, 0));
         } else {
             const int so = cb * HWin * 4;
 #pragma unroll
-            for (int i = 0; i < NL; ++i) rin[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs0, goff[i], so, 0));
+            for (int i = 0; i < NL; ++i) dst[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs0, goff[i], so, 0));
         }
     };
     auto load_u = [&](int cc) {
@@ -131,8 +159,8 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a) {
             ru[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsu, tid * 16, cc * ustride_b + i * NT * 16, 0));
     };
     // activation (GroupNorm/FiLM affine + SiLU of the producer) + zero padding + LDS write of staged element i
-    auto stage_raw = [&](int i, int cc, int rbuf) {
-        float x = rin[i];
+    auto stage_raw = [&](const float (&src)[NL], int i, int cc, int rbuf) {
+        float x = src[i];
         if (SPEC == 2) {
             const int cil = (tid + i * NT) / PSP;
             const int chc = cc * CK + (cil < CK ? cil : 0);
@@ -143,7 +171,7 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a) {
     auto stage_u = [&](int i, int buf) { reinterpret_cast<floatx4*>(Ub + buf * U_FLOATS)[tid + i * NT] = ru[i]; };
 
     // input transform B^T d B of the patch in R -> V[buf].  Thread = (u-pair ch, tile row tb, k4, tile j), both
-    // channels ci = k4, k4+4 of the chunk; u-pair 0 needs patch rows 0..2 of the tile, u-pair 1 rows 1..3.
+    // channels ci = k4, k4+4 of the chunk.
     // Roles are made arithmetically uniform (no per-role selects on the vector ALU): u-pair 0 reads patch rows
     // (p,q,r) = (0,1,2) of its tile, u-pair 1 reads them reversed, (3,2,1); then for both
     //     tA = p - r          -> u = 0          | -(d1 - d3) = -t[u=3]
@@ -187,173 +215,199 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) *reinterpret_cast<floatx2*>(V + (uu * 4 + v) * 512) = floatx2{to[uu][v][0], to[uu][v][1]};
     };
-
-    floatx4 acc[16][2];
-#pragma unroll
-    for (int xi = 0; xi < 16; ++xi)
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) acc[xi][mb] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-    // ---- pipeline fill: V[0], U[0] hold chunk 0, R[1] chunk 1; raw(2) and U(1) are in registers ----------------------
     auto clampc = [&](int c) { return c < nchunks ? c : nchunks - 1; };
-    load_raw(0);
+
+    const int first = blockIdx.x * per;
+    const int last = first + per < (int)a.total_wg ? first + per : (int)a.total_wg;
+    if (first >= last) return;
+    setup_item(first);
+    load_raw(rin, 0);
     load_u(0);
-    if (SPEC == 2) __syncthreads();  // protab visible
-#pragma unroll
-    for (int i = 0; i < NL; ++i) stage_raw(i, 0, 0);
-#pragma unroll
-    for (int i = 0; i < NU; ++i) stage_u(i, 0);
-    load_raw(clampc(1));
-    __syncthreads();
-    tr_read(0, 0), tr_compute(0);
-    tr_read(1, 0), tr_compute(1);
-    tr_write(0, 0), tr_write(1, 0);
-#pragma unroll
-    for (int i = 0; i < NL; ++i) stage_raw(i, clampc(1), 1);
-    load_raw(clampc(2));
-    load_u(clampc(1));
-    __syncthreads();
+    load_raw(rin1, clampc(1));
+    int protab_b = -1;
+    TRACE_INIT
 
-    // ---- main loop, ONE barrier per chunk.  Iteration c runs the 16 Winograd positions of chunk c (per position one B
-    // read + two A reads (ds_read_b64) -> 4 MFMAs, operands requested PD positions ahead) and, dealt out one slice per
-    // position and fenced with sched_barrier so each slice issues while the matrix pipe is busy:
-    //   stage raw(c+2) registers -> R[c&1],  stage U(c+1) registers -> U[(c+1)&1],
-    //   global loads raw(c+3), U(c+2) -> registers,  transform R[(c+1)&1] (staged one iteration ago) -> V[(c+1)&1].
-    // The slices of one iteration are mutually independent; every buffer written here was last read one barrier ago.
-    // (Left alone, hipcc hoists the operand reads and sinks the MFMAs across barriers, idling the matrix pipe.)
-    constexpr int PD = IDIFF_WINO_PD;
-    const int opoff = k4 * 32 + j * 2;
-    auto chunk = [&](int cc, auto more_tag) {
-        constexpr bool MORE = decltype(more_tag)::value;  // false: last chunk, nothing left to stage
-        const int buf = cc & 1;
-        const float* V = Vb + buf * V_FLOATS + tb * 128 + opoff;
-        const float* U = Ub + buf * U_FLOATS + ch * 256 + opoff;
-        floatx2 ob[PD + 1], oa0[PD + 1], oa1[PD + 1];
-#pragma unroll
-        for (int q = 0; q < PD; ++q) {
-            ob[q] = *reinterpret_cast<const floatx2*>(V + q * 512);
-            oa0[q] = *reinterpret_cast<const floatx2*>(U + q * 512);
-            oa1[q] = *reinterpret_cast<const floatx2*>(U + q * 512 + 128);
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-#if defined(IDIFF_WINO_EXP) && IDIFF_WINO_EXP >= 2
-            if (false) {
-#else
-            if (q + PD < 16) {
-#endif
-                ob[(q + PD) % (PD + 1)] = *reinterpret_cast<const floatx2*>(V + (q + PD) * 512);
-                oa0[(q + PD) % (PD + 1)] = *reinterpret_cast<const floatx2*>(U + (q + PD) * 512);
-                oa1[(q + PD) % (PD + 1)] = *reinterpret_cast<const floatx2*>(U + (q + PD) * 512 + 128);
-            }
-            const floatx2 bv = ob[q % (PD + 1)], av0 = oa0[q % (PD + 1)], av1 = oa1[q % (PD + 1)];
-            acc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0.x, bv.x, acc[q][0], 0, 0, 0);
-            acc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1.x, bv.x, acc[q][1], 0, 0, 0);
-            acc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0.y, bv.y, acc[q][0], 0, 0, 0);
-            acc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1.y, bv.y, acc[q][1], 0, 0, 0);
-            if (MORE) {
-#ifndef IDIFF_WINO_SKIP
-#define IDIFF_WINO_SKIP 0
-#endif
-                if (!(IDIFF_WINO_SKIP & 1) && q < 6) stage_raw(q, clampc(cc + 2), buf);
-                if (!(IDIFF_WINO_SKIP & 2) && q >= 4 && q < 8) stage_u(q - 4, buf ^ 1);
-                if (!(IDIFF_WINO_SKIP & 4) && q == 8) load_raw(clampc(cc + 3));
-                if (!(IDIFF_WINO_SKIP & 4) && q == 9) load_u(clampc(cc + 2));
-                if (!(IDIFF_WINO_SKIP & 8) && q == 10) tr_read(0, buf ^ 1);
-                if (!(IDIFF_WINO_SKIP & 8) && q == 11) tr_compute(0);
-                if (!(IDIFF_WINO_SKIP & 8) && q == 12) tr_read(1, buf ^ 1);
-                if (!(IDIFF_WINO_SKIP & 8) && q == 13) tr_compute(1);
-                if (!(IDIFF_WINO_SKIP & 8) && q == 14) tr_write(0, buf ^ 1);
-                if (!(IDIFF_WINO_SKIP & 8) && q == 15) tr_write(1, buf ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (!(IDIFF_WINO_SKIP & 16) && q == 15) __syncthreads();
-            }
-        }
-    };
-    for (int cc = 0; cc + 1 < nchunks; ++cc) chunk(cc, std::true_type{});
-    chunk(nchunks - 1, std::false_type{});
+    for (int item = first; item < last; ++item) {
+        const int b = it_b, tile = it_tile, co0 = it_co0, y0 = it_y0, x0 = it_x0;  // the epilogue's view of this item
+        TRACE_MARK(0)
 
-    // ---- epilogue: in-lane output transform A^T m A, then the conv_igemm epilogue contract -----------------------
-    // C layout of 16x16x4: lane holds column j (tile) and rows 4*k4 + r of each 16-row block
-    const int HWo = a.Hout * a.Wout;
-    const int oy = y0 + 2 * tb, ox = x0 + 2 * j;
-    float* outb = a.out + (long long)b * a.obs + (long long)oy * a.Wout + ox;
-    const float* resb = a.res ? a.res + (long long)b * a.rbs + (long long)oy * a.Wout + ox : nullptr;
-    const float* auxb = a.aux ? a.aux + (long long)b * a.abs_ + (long long)oy * a.Wout + ox : nullptr;
-    const bool want_stats = a.stats != nullptr;
-    float sv[16];
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = co0 + ch * 32 + mb * 16 + 4 * k4 + r;
-            float z[4][2];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int rho = u < 2 ? u : 5 - u;  // accumulator rows are stored in the order (u0, u1, u3, u2)
-                const float m0 = acc[rho * 4 + 0][mb][r], m1 = acc[rho * 4 + 1][mb][r], m2 = acc[rho * 4 + 2][mb][r], m3 = acc[rho * 4 + 3][mb][r];
-                z[u][0] = m0 + m1 + m2;
-                z[u][1] = m1 - m2 - m3;
+        // ---- pipeline fill: V[0], U[0] hold chunk 0, R[1] chunk 1; raw(2) and U(1) are in registers ------------------
+        __syncthreads();  // every wave is done with the previous item's LDS (last chunk's operands, stats scratch)
+        if (SPEC == 2 && protab_b != b) {
+            for (int i = tid; i < a.C0r; i += NT) {
+                protab[i] = a.pro_a[(long long)b * a.C0r + i];
+                protab[a.C0r + i] = a.pro_b[(long long)b * a.C0r + i];
             }
-            const float bv = a.bias ? a.bias[co] : 0.f;
-            float y[2][2];
-#pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                y[0][x] = z[0][x] + z[1][x] + z[2][x] + bv;
-                y[1][x] = z[1][x] - z[2][x] - z[3][x] + bv;
-            }
-            sv[(mb * 4 + r) * 2 + 0] = (y[0][0] + y[0][1]) + (y[1][0] + y[1][1]);
-            sv[(mb * 4 + r) * 2 + 1] = (y[0][0] * y[0][0] + y[0][1] * y[0][1]) + (y[1][0] * y[1][0] + y[1][1] * y[1][1]);
-            float add = 0.f, aa = 0.f, ab = 0.f;
-            if (a.vec) add = a.vec[(long long)b * a.Cout + co];
-            if (auxb) {
-                aa = a.aux_a[(long long)b * a.Cout + co];
-                ab = a.aux_b[(long long)b * a.Cout + co];
-            }
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy) {
-                const long long o = (long long)co * HWo + dy * a.Wout;
-                floatx2 v = floatx2{y[dy][0] + add, y[dy][1] + add};
-                if (resb) {
-                    const floatx2 rr = *reinterpret_cast<const floatx2*>(resb + o);
-                    v.x += rr.x, v.y += rr.y;
-                }
-                if (auxb) {
-                    const floatx2 ax = *reinterpret_cast<const floatx2*>(auxb + o);
-                    v.x += silu_fast(aa * ax.x + ab), v.y += silu_fast(aa * ax.y + ab);
-                }
-                *reinterpret_cast<floatx2*>(outb + o) = v;
-            }
+            protab_b = b;
+            __syncthreads();
         }
-    }
-    if (want_stats) {
-        // butterfly reduce-scatter over the 16 tile lanes: lane j ends with the total of value index j = (mb*4+r)*2+w
 #pragma unroll
-        for (int step = 0; step < 4; ++step) {
-            const int m = 8 >> step;
-            const int n = 8 >> step;
-            const bool up = (j & m) != 0;
+        for (int i = 0; i < NL; ++i) stage_raw(rin, i, 0, 0);
 #pragma unroll
-            for (int q = 0; q < n; ++q) {
-                const float lo = sv[q], hi = sv[q + n];
-                const float send = up ? lo : hi;
-                const float keep = up ? hi : lo;
-                sv[q] = keep + __shfl_xor(send, m, 64);
-            }
-        }
-        __syncthreads();  // all MFMA-phase LDS reads are done: reuse R[0] as the cross-wave scratch [4 tb][64 co][2]
-        {
-            const int mb = j >> 3, r = (j >> 1) & 3, w = j & 1;
-            const int col = ch * 32 + mb * 16 + 4 * k4 + r;
-            Rb[(tb * 64 + col) * 2 + w] = sv[0];
-        }
+        for (int i = 0; i < NU; ++i) stage_u(i, 0);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) stage_raw(rin1, i, clampc(1), 1);
+        load_raw(rin, clampc(2));
+        load_u(clampc(1));
         __syncthreads();
-        if (tid < 128) {
-            const float t = (Rb[tid] + Rb[128 + tid]) + (Rb[256 + tid] + Rb[384 + tid]);
-            const int col = tid >> 1, w = tid & 1;
-            a.stats[(((long long)b * a.ntiles + tile) * a.Cout + co0 + col) * 2 + w] = t;
+        tr_read(0, 0), tr_compute(0);
+        tr_read(1, 0), tr_compute(1);
+        tr_write(0, 0), tr_write(1, 0);
+
+        floatx4 acc[16][2];
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) acc[xi][mb] = floatx4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        TRACE_MARK(1)
+
+        // ---- main loop, ONE barrier per chunk.  Iteration c runs the 16 Winograd positions of chunk c (per position
+        // one B read + two A reads (ds_read_b64) -> 4 MFMAs, operands requested PD positions ahead) and, dealt out one
+        // slice per position and fenced with sched_barrier so each slice issues between MFMAs:
+        //   stage raw(c+2) registers -> R[c&1],  stage U(c+1) registers -> U[(c+1)&1],
+        //   global loads raw(c+3), U(c+2) -> registers,  transform R[(c+1)&1] (staged one iteration ago) -> V[(c+1)&1].
+        // The slices of one iteration are mutually independent; every buffer written was last read one barrier ago.
+        // (Left alone, hipcc hoists the operand reads and sinks the MFMAs across barriers, idling the matrix pipe.)
+        constexpr int PD = IDIFF_WINO_PD;
+        const int opoff = k4 * 32 + j * 2;
+        auto chunk = [&](int cc, auto more_tag) {
+            constexpr bool MORE = decltype(more_tag)::value;  // false: last chunk, nothing left to stage
+            const int buf = cc & 1;
+            const float* V = Vb + buf * V_FLOATS + tb * 128 + opoff;
+            const float* U = Ub + buf * U_FLOATS + ch * 256 + opoff;
+            floatx2 ob[PD + 1], oa0[PD + 1], oa1[PD + 1];
+#pragma unroll
+            for (int q = 0; q < PD; ++q) {
+                ob[q] = *reinterpret_cast<const floatx2*>(V + q * 512);
+                oa0[q] = *reinterpret_cast<const floatx2*>(U + q * 512);
+                oa1[q] = *reinterpret_cast<const floatx2*>(U + q * 512 + 128);
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if (q + PD < 16) {
+                    ob[(q + PD) % (PD + 1)] = *reinterpret_cast<const floatx2*>(V + (q + PD) * 512);
+                    oa0[(q + PD) % (PD + 1)] = *reinterpret_cast<const floatx2*>(U + (q + PD) * 512);
+                    oa1[(q + PD) % (PD + 1)] = *reinterpret_cast<const floatx2*>(U + (q + PD) * 512 + 128);
+                }
+                const floatx2 bv = ob[q % (PD + 1)], av0 = oa0[q % (PD + 1)], av1 = oa1[q % (PD + 1)];
+                acc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0.x, bv.x, acc[q][0], 0, 0, 0);
+                acc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1.x, bv.x, acc[q][1], 0, 0, 0);
+                acc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0.y, bv.y, acc[q][0], 0, 0, 0);
+                acc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1.y, bv.y, acc[q][1], 0, 0, 0);
+                if (MORE) {
+                    if (q < 6) stage_raw(rin, q, clampc(cc + 2), buf);
+                    if (q >= 4 && q < 8) stage_u(q - 4, buf ^ 1);
+                    if (q == 8) load_raw(rin, clampc(cc + 3));
+                    if (q == 9) load_u(clampc(cc + 2));
+                    if (q == 10) tr_read(0, buf ^ 1);
+                    if (q == 11) tr_compute(0);
+                    if (q == 12) tr_read(1, buf ^ 1);
+                    if (q == 13) tr_compute(1);
+                    if (q == 14) tr_write(0, buf ^ 1);
+                    if (q == 15) tr_write(1, buf ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (q == 15) __syncthreads();
+                }
+            }
+        };
+        for (int cc = 0; cc + 1 < nchunks; ++cc) chunk(cc, std::true_type{});
+        chunk(nchunks - 1, std::false_type{});
+        TRACE_MARK(2)
+
+        // the next item's first loads travel while this item's epilogue runs
+        if (item + 1 < last) {
+            setup_item(item + 1);
+            load_raw(rin, 0);
+            load_u(0);
+            load_raw(rin1, clampc(1));
         }
+
+        // ---- epilogue: in-lane output transform A^T m A, then the conv_igemm epilogue contract -------------------
+        // C layout of 16x16x4: lane holds column j (tile) and rows 4*k4 + r of each 16-row block
+        const int HWo = a.Hout * a.Wout;
+        const int oy = y0 + 2 * tb, ox = x0 + 2 * j;
+        float* outb = a.out + (long long)b * a.obs + (long long)oy * a.Wout + ox;
+        const float* resb = a.res ? a.res + (long long)b * a.rbs + (long long)oy * a.Wout + ox : nullptr;
+        const float* auxb = a.aux ? a.aux + (long long)b * a.abs_ + (long long)oy * a.Wout + ox : nullptr;
+        const bool want_stats = a.stats != nullptr;
+        float sv[16];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + ch * 32 + mb * 16 + 4 * k4 + r;
+                float z[4][2];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int rho = u < 2 ? u : 5 - u;  // accumulator rows are stored in the order (u0, u1, u3, u2)
+                    const float m0 = acc[rho * 4 + 0][mb][r], m1 = acc[rho * 4 + 1][mb][r], m2 = acc[rho * 4 + 2][mb][r], m3 = acc[rho * 4 + 3][mb][r];
+                    z[u][0] = m0 + m1 + m2;
+                    z[u][1] = m1 - m2 - m3;
+                }
+                const float bv = a.bias ? a.bias[co] : 0.f;
+                float y[2][2];
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    y[0][x] = z[0][x] + z[1][x] + z[2][x] + bv;
+                    y[1][x] = z[1][x] - z[2][x] - z[3][x] + bv;
+                }
+                sv[(mb * 4 + r) * 2 + 0] = (y[0][0] + y[0][1]) + (y[1][0] + y[1][1]);
+                sv[(mb * 4 + r) * 2 + 1] = (y[0][0] * y[0][0] + y[0][1] * y[0][1]) + (y[1][0] * y[1][0] + y[1][1] * y[1][1]);
+                float add = 0.f, aa = 0.f, ab = 0.f;
+                if (a.vec) add = a.vec[(long long)b * a.Cout + co];
+                if (auxb) {
+                    aa = a.aux_a[(long long)b * a.Cout + co];
+                    ab = a.aux_b[(long long)b * a.Cout + co];
+                }
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy) {
+                    const long long o = (long long)co * HWo + dy * a.Wout;
+                    floatx2 v = floatx2{y[dy][0] + add, y[dy][1] + add};
+                    if (resb) {
+                        const floatx2 rr = *reinterpret_cast<const floatx2*>(resb + o);
+                        v.x += rr.x, v.y += rr.y;
+                    }
+                    if (auxb) {
+                        const floatx2 ax = *reinterpret_cast<const floatx2*>(auxb + o);
+                        v.x += silu_fast(aa * ax.x + ab), v.y += silu_fast(aa * ax.y + ab);
+                    }
+                    *reinterpret_cast<floatx2*>(outb + o) = v;
+                }
+            }
+        }
+        if (want_stats) {
+            // butterfly reduce-scatter over the 16 tile lanes: lane j ends with the total of value index j = (mb*4+r)*2+w
+#pragma unroll
+            for (int step = 0; step < 4; ++step) {
+                const int m = 8 >> step;
+                const int n = 8 >> step;
+                const bool up = (j & m) != 0;
+#pragma unroll
+                for (int q = 0; q < n; ++q) {
+                    const float lo = sv[q], hi = sv[q + n];
+                    const float send = up ? lo : hi;
+                    const float keep = up ? hi : lo;
+                    sv[q] = keep + __shfl_xor(send, m, 64);
+                }
+            }
+            // cross-wave scratch [4 tb][64 co][2] in R[0]: the last chunk reads only U and V, and R[0] was last read
+            // (by the transform) at least one barrier ago; the barrier at the top of the next item protects its reuse
+            {
+                const int mb = j >> 3, r = (j >> 1) & 3, w = j & 1;
+                const int col = ch * 32 + mb * 16 + 4 * k4 + r;
+                Rb[(tb * 64 + col) * 2 + w] = sv[0];
+            }
+            __syncthreads();
+            if (tid < 128) {
+                const float t = (Rb[tid] + Rb[128 + tid]) + (Rb[256 + tid] + Rb[384 + tid]);
+                const int col = tid >> 1, w = tid & 1;
+                a.stats[(((long long)b * a.ntiles + tile) * a.Cout + co0 + col) * 2 + w] = t;
+            }
+        }
+        TRACE_MARK(3)
     }
+    TRACE_FINI
 }
 
 template <int MODE, int SPEC>
@@ -367,7 +421,29 @@ int launch(const ConvArgs& a, hipStream_t st) {
         if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "conv2d(winograd): hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(a.total_wg), dim3(NT), lds, st, a);
+    static int num_cu = 0;
+    if (num_cu == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            IDIFF_FAIL(IDIFF_E_HIP, "conv2d(winograd): cannot query the CU count");
+        num_cu = n;
+    }
+    const int total = (int)a.total_wg;
+    const int per = (total + num_cu - 1) / num_cu;          // items per workgroup (contiguous range)
+    const int grid = (total + per - 1) / per;               // <= one workgroup per CU, none empty
+#ifdef IDIFF_WINO_TRACE
+    static long long* tr = nullptr;
+    if (!tr) (void)hipMalloc(&tr, 4 * sizeof(long long));
+    (void)hipMemsetAsync(tr, 0, 4 * sizeof(long long), st);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, a, per, tr);
+    long long h[4];
+    (void)hipMemcpyAsync(h, tr, sizeof(h), hipMemcpyDeviceToHost, st);
+    (void)hipStreamSynchronize(st);
+    fprintf(stderr, "[wino trace] Cin=%d Cout=%d H=%d items=%d per=%d | fill %lld  loop %lld  epilogue %lld (cycles/item, wave 0 of every WG)\n", a.Cin,
+            a.Cout, a.Hout, total, per, h[0] / total, h[1] / total, h[2] / total);
+#else
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, a, per);
+#endif
     IDIFF_CHECK_LAUNCH("conv2d_fwd(winograd)");
     return IDIFF_OK;
 }
