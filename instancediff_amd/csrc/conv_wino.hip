@@ -44,18 +44,29 @@ constexpr int NU = U_FLOATS / 4 / NT;          // 4 float4 of weights per thread
 
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 
+// sum over each 16-lane row by DPP prefix adds (row_shr 1, 2, 4, 8; zeros shift in): lane 15 of the row ends with the total
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_shr(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_sum16(float v) {
+    v += dpp_row_shr<0x111>(v);
+    v += dpp_row_shr<0x112>(v);
+    v += dpp_row_shr<0x114>(v);
+    v += dpp_row_shr<0x118>(v);
+    return v;
+}
+
 // -DIDIFF_WINO_TRACE: per-phase cycle counts (s_memtime) summed over all items, printed by the launcher (debug builds)
 #ifdef IDIFF_WINO_TRACE
 #define TRACE_PARAM , long long* trace
-#define TRACE_INIT long long tr_t[4] = {0, 0, 0, 0}, tr_acc[3] = {0, 0, 0};
+#define TRACE_INIT long long tr_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_acc[7] = {0, 0, 0, 0, 0, 0, 0};
 #define TRACE_MARK(k)                                      \
     tr_t[k] = __builtin_readcyclecounter();                \
     if (k > 0) tr_acc[k - 1] += tr_t[k] - tr_t[k - 1];
 #define TRACE_FINI                                                                  \
     if (tid == 0) {                                                                 \
-        atomicAdd((unsigned long long*)trace + 0, (unsigned long long)tr_acc[0]);   \
-        atomicAdd((unsigned long long*)trace + 1, (unsigned long long)tr_acc[1]);   \
-        atomicAdd((unsigned long long*)trace + 2, (unsigned long long)tr_acc[2]);   \
+        for (int q_ = 0; q_ < 7; ++q_) atomicAdd((unsigned long long*)trace + q_, (unsigned long long)tr_acc[q_]); \
     }
 #else
 #define TRACE_PARAM
@@ -79,7 +90,8 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a, const i
     float* const Rb = smem;                   // [2][R_FLOATS]
     float* const Vb = smem + 2 * R_FLOATS;
     float* const Ub = Vb + 2 * V_FLOATS;
-    float* const protab = Ub + 2 * U_FLOATS;  // [2][C0r] (SPEC 2)
+    float* const econst = Ub + 2 * U_FLOATS;  // [4][64] bias, vec, aux_a, aux_b of the item's 64 output channels
+    float* const protab = econst + 256;       // [2][C0r] (SPEC 2)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -222,8 +234,8 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a, const i
     if (first >= last) return;
     setup_item(first);
     load_raw(rin, 0);
-    load_u(0);
     load_raw(rin1, clampc(1));
+    load_u(0);
     int protab_b = -1;
     TRACE_INIT
 
@@ -241,12 +253,23 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a, const i
             protab_b = b;
             __syncthreads();
         }
+        {
+            if (tid < 256) {  // per-channel epilogue constants -> LDS: the epilogue proper must not wait on global loads
+                const int which = tid >> 6, co = co0 + (tid & 63);
+                float v = 0.f;
+                if (which == 0 && a.bias) v = a.bias[co];
+                if (which == 1 && a.vec) v = a.vec[(long long)b * a.Cout + co];
+                if (which == 2 && a.aux) v = a.aux_a[(long long)b * a.Cout + co];
+                if (which == 3 && a.aux) v = a.aux_b[(long long)b * a.Cout + co];
+                econst[tid] = v;
+            }
 #pragma unroll
-        for (int i = 0; i < NL; ++i) stage_raw(rin, i, 0, 0);
+            for (int i = 0; i < NL; ++i) stage_raw(rin, i, 0, 0);
 #pragma unroll
-        for (int i = 0; i < NU; ++i) stage_u(i, 0);
+            for (int i = 0; i < NU; ++i) stage_u(i, 0);
 #pragma unroll
-        for (int i = 0; i < NL; ++i) stage_raw(rin1, i, clampc(1), 1);
+            for (int i = 0; i < NL; ++i) stage_raw(rin1, i, clampc(1), 1);
+        }
         load_raw(rin, clampc(2));
         load_u(clampc(1));
         __syncthreads();
@@ -312,31 +335,58 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a, const i
             }
         };
         for (int cc = 0; cc + 1 < nchunks; ++cc) chunk(cc, std::true_type{});
-        chunk(nchunks - 1, std::false_type{});
-        TRACE_MARK(2)
-
-        // the next item's first loads travel while this item's epilogue runs
+        // Nothing is staged in the last chunk, so the item state is free: switch it to the next item now (scalar
+        // work, hidden under the MFMAs) and let its first two patches and weights travel during the last chunk and the epilogue.
         if (item + 1 < last) {
             setup_item(item + 1);
             load_raw(rin, 0);
-            load_u(0);
             load_raw(rin1, clampc(1));
+            load_u(0);
         }
+        chunk(nchunks - 1, std::false_type{});
+        TRACE_MARK(2)
 
+        TRACE_MARK(3)
         // ---- epilogue: in-lane output transform A^T m A, then the conv_igemm epilogue contract -------------------
         // C layout of 16x16x4: lane holds column j (tile) and rows 4*k4 + r of each 16-row block
         const int HWo = a.Hout * a.Wout;
-        const int oy = y0 + 2 * tb, ox = x0 + 2 * j;
-        float* outb = a.out + (long long)b * a.obs + (long long)oy * a.Wout + ox;
-        const float* resb = a.res ? a.res + (long long)b * a.rbs + (long long)oy * a.Wout + ox : nullptr;
-        const float* auxb = a.aux ? a.aux + (long long)b * a.abs_ + (long long)oy * a.Wout + ox : nullptr;
+        // addresses = uniform 64-bit base (SGPRs: sample, wave's channel half and tile row) + per-step uniform offset +
+        // ONE per-lane 32-bit offset (row group 4*k4 channels down, tile column 2*j across): no 64-bit vector address
+        // arithmetic per step, and nothing loop-invariant for the compiler to hoist out of the item loop and spill
+        const long long wave_org = (long long)(co0 + ch * 32) * HWo + (long long)(y0 + 2 * tb) * a.Wout + x0;
+        float* const outb = a.out + (long long)b * a.obs + wave_org;
+        const float* const resb = a.res ? a.res + (long long)b * a.rbs + wave_org : nullptr;
+        const float* const auxb = a.aux ? a.aux + (long long)b * a.abs_ + wave_org : nullptr;
+        const unsigned lane_off = (unsigned)(4 * k4) * (unsigned)HWo + 2u * j;
+        // LDS side likewise: one base per table, the step index is an immediate offset
+        const float* const ebase = econst + ch * 32 + 4 * k4;             // + mb*16 + r (+ 64 per table)
+        float* const sbase = Rb + (tb * 64 + ch * 32 + 4 * k4) * 2;      // + (mb*16 + r)*2
         const bool want_stats = a.stats != nullptr;
-        float sv[16];
+        const bool has_res = a.res != nullptr, has_aux = a.aux != nullptr;
+        // No global load may sit between the stores of two steps: vmcnt counts loads and stores in order, so waiting
+        // for such a load would wait for every store before it.  The per-channel constants therefore come from LDS,
+        // and the residual / aux operands of step i+1 are requested BEFORE the stores of step i (s_waitcnt then only
+        // covers the stores of step i-1).  One instantiation per (residual, aux) combination keeps the steps branch-free.
+        // GroupNorm partials: 16-lane row sums by DPP prefix adds (lane 15 of each row holds the total), written to
+        // the cross-wave scratch [4 tb][64 co][2] in R[0] -- R was last read (by the transform) a barrier ago, the
+        // last chunk reads only U and V, and the barrier at the top of the next item protects its reuse.
+        auto out_steps = [&](auto res_tag, auto aux_tag) {
+            constexpr bool RES = decltype(res_tag)::value, AUX = decltype(aux_tag)::value;
+            floatx2 nres[2], naux[2];
+            auto fetch = [&](int i) {
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
+                for (int dy = 0; dy < 2; ++dy) {
+                    const long long so = (long long)((i >> 2) * 16 + (i & 3)) * HWo + dy * a.Wout;  // uniform
+                    if (RES) nres[dy] = *reinterpret_cast<const floatx2*>(resb + so + lane_off);
+                    if (AUX) naux[dy] = *reinterpret_cast<const floatx2*>(auxb + so + lane_off);
+                }
+            };
+            fetch(0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = co0 + ch * 32 + mb * 16 + 4 * k4 + r;
+            for (int i = 0; i < 8; ++i) {
+                const int mb = i >> 2, r = i & 3;
+                const floatx2 cres[2] = {nres[0], nres[1]}, caux[2] = {naux[0], naux[1]};
+                if (i + 1 < 8) fetch(i + 1);
                 float z[4][2];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -345,74 +395,59 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a, const i
                     z[u][0] = m0 + m1 + m2;
                     z[u][1] = m1 - m2 - m3;
                 }
-                const float bv = a.bias ? a.bias[co] : 0.f;
+                const float bv = ebase[mb * 16 + r];
                 float y[2][2];
 #pragma unroll
                 for (int x = 0; x < 2; ++x) {
                     y[0][x] = z[0][x] + z[1][x] + z[2][x] + bv;
                     y[1][x] = z[1][x] - z[2][x] - z[3][x] + bv;
                 }
-                sv[(mb * 4 + r) * 2 + 0] = (y[0][0] + y[0][1]) + (y[1][0] + y[1][1]);
-                sv[(mb * 4 + r) * 2 + 1] = (y[0][0] * y[0][0] + y[0][1] * y[0][1]) + (y[1][0] * y[1][0] + y[1][1] * y[1][1]);
-                float add = 0.f, aa = 0.f, ab = 0.f;
-                if (a.vec) add = a.vec[(long long)b * a.Cout + co];
-                if (auxb) {
-                    aa = a.aux_a[(long long)b * a.Cout + co];
-                    ab = a.aux_b[(long long)b * a.Cout + co];
+                if (want_stats) {
+                    float ssum = (y[0][0] + y[0][1]) + (y[1][0] + y[1][1]);
+                    float ssq = (y[0][0] * y[0][0] + y[0][1] * y[0][1]) + (y[1][0] * y[1][0] + y[1][1] * y[1][1]);
+                    ssum = row_sum16(ssum);
+                    ssq = row_sum16(ssq);
+                    if (j == 15) *reinterpret_cast<floatx2*>(sbase + (mb * 16 + r) * 2) = floatx2{ssum, ssq};
                 }
+                const float add = ebase[64 + mb * 16 + r];
+                float aa = 0.f, ab = 0.f;
+                if (AUX) aa = ebase[128 + mb * 16 + r], ab = ebase[192 + mb * 16 + r];
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy) {
-                    const long long o = (long long)co * HWo + dy * a.Wout;
                     floatx2 v = floatx2{y[dy][0] + add, y[dy][1] + add};
-                    if (resb) {
-                        const floatx2 rr = *reinterpret_cast<const floatx2*>(resb + o);
-                        v.x += rr.x, v.y += rr.y;
-                    }
-                    if (auxb) {
-                        const floatx2 ax = *reinterpret_cast<const floatx2*>(auxb + o);
-                        v.x += silu_fast(aa * ax.x + ab), v.y += silu_fast(aa * ax.y + ab);
-                    }
-                    *reinterpret_cast<floatx2*>(outb + o) = v;
+                    if (RES) v.x += cres[dy].x, v.y += cres[dy].y;
+                    if (AUX) v.x += silu_fast(aa * caux[dy].x + ab), v.y += silu_fast(aa * caux[dy].y + ab);
+                    *reinterpret_cast<floatx2*>(outb + ((long long)(mb * 16 + r) * HWo + dy * a.Wout) + lane_off) = v;
                 }
+                __builtin_amdgcn_sched_barrier(0);  // keep the steps apart: interleaving them only buys register pressure
             }
+        };
+        if (has_res) {
+            if (has_aux) out_steps(std::true_type{}, std::true_type{});
+            else out_steps(std::true_type{}, std::false_type{});
+        } else {
+            if (has_aux) out_steps(std::false_type{}, std::true_type{});
+            else out_steps(std::false_type{}, std::false_type{});
         }
+        TRACE_MARK(4)
+        TRACE_MARK(5)
         if (want_stats) {
-            // butterfly reduce-scatter over the 16 tile lanes: lane j ends with the total of value index j = (mb*4+r)*2+w
-#pragma unroll
-            for (int step = 0; step < 4; ++step) {
-                const int m = 8 >> step;
-                const int n = 8 >> step;
-                const bool up = (j & m) != 0;
-#pragma unroll
-                for (int q = 0; q < n; ++q) {
-                    const float lo = sv[q], hi = sv[q + n];
-                    const float send = up ? lo : hi;
-                    const float keep = up ? hi : lo;
-                    sv[q] = keep + __shfl_xor(send, m, 64);
-                }
-            }
-            // cross-wave scratch [4 tb][64 co][2] in R[0]: the last chunk reads only U and V, and R[0] was last read
-            // (by the transform) at least one barrier ago; the barrier at the top of the next item protects its reuse
-            {
-                const int mb = j >> 3, r = (j >> 1) & 3, w = j & 1;
-                const int col = ch * 32 + mb * 16 + 4 * k4 + r;
-                Rb[(tb * 64 + col) * 2 + w] = sv[0];
-            }
             __syncthreads();
+            TRACE_MARK(6)
             if (tid < 128) {
                 const float t = (Rb[tid] + Rb[128 + tid]) + (Rb[256 + tid] + Rb[384 + tid]);
                 const int col = tid >> 1, w = tid & 1;
                 a.stats[(((long long)b * a.ntiles + tile) * a.Cout + co0 + col) * 2 + w] = t;
             }
         }
-        TRACE_MARK(3)
+        TRACE_MARK(7)
     }
     TRACE_FINI
 }
 
 template <int MODE, int SPEC>
 int launch(const ConvArgs& a, hipStream_t st) {
-    const size_t lds = ((size_t)2 * R_FLOATS + 2 * V_FLOATS + 2 * U_FLOATS + (SPEC == 2 ? 2 * (size_t)a.C0r : 0)) * sizeof(float);
+    const size_t lds = ((size_t)2 * R_FLOATS + 2 * V_FLOATS + 2 * U_FLOATS + 256 + (SPEC == 2 ? 2 * (size_t)a.C0r : 0)) * sizeof(float);
     if (lds > 160 * 1024) IDIFF_FAIL(IDIFF_E_UNSUPPORTED, "conv2d(winograd): LDS budget exceeded (%zu bytes)", lds);
     static size_t attr_set = 0;
     auto kern = conv_wino_kernel<MODE, SPEC>;
@@ -433,14 +468,14 @@ int launch(const ConvArgs& a, hipStream_t st) {
     const int grid = (total + per - 1) / per;               // <= one workgroup per CU, none empty
 #ifdef IDIFF_WINO_TRACE
     static long long* tr = nullptr;
-    if (!tr) (void)hipMalloc(&tr, 4 * sizeof(long long));
-    (void)hipMemsetAsync(tr, 0, 4 * sizeof(long long), st);
+    if (!tr) (void)hipMalloc(&tr, 8 * sizeof(long long));
+    (void)hipMemsetAsync(tr, 0, 8 * sizeof(long long), st);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, a, per, tr);
-    long long h[4];
+    long long h[8];
     (void)hipMemcpyAsync(h, tr, sizeof(h), hipMemcpyDeviceToHost, st);
     (void)hipStreamSynchronize(st);
-    fprintf(stderr, "[wino trace] Cin=%d Cout=%d H=%d items=%d per=%d | fill %lld  loop %lld  epilogue %lld (cycles/item, wave 0 of every WG)\n", a.Cin,
-            a.Cout, a.Hout, total, per, h[0] / total, h[1] / total, h[2] / total);
+    fprintf(stderr, "[wino trace] Cin=%d Cout=%d H=%d items=%d per=%d | fill %lld  loop %lld  prefetch %lld  outsteps %lld  butterfly %lld  barrier %lld  statstore %lld (cycles/item, wave 0)\n", a.Cin,
+            a.Cout, a.Hout, total, per, h[0] / total, h[1] / total, h[2] / total, h[3] / total, h[4] / total, h[5] / total, h[6] / total);
 #else
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, a, per);
 #endif
