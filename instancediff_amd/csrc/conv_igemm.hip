@@ -18,6 +18,8 @@
 // reference's fp32 cuDNN/ATen convs; roofline for this kernel = 157.3 TFLOP/s (f32 matrix peak).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "conv_args.h"
 
 using idiff_detail::ConvArgs;
@@ -47,6 +49,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* protab = smem + 2 * BUF;  // [2][C0r] GroupNorm/FiLM affine of this sample (only when pro_a)
+    float* econst = protab + (a.pro_a ? 2 * a.C0r : 0);  // [4][BM] bias, vec, aux_a, aux_b of this block's channels
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -96,6 +99,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             protab[i] = a.pro_a[(long long)b * a.C0r + i];
             protab[a.C0r + i] = a.pro_b[(long long)b * a.C0r + i];
         }
+    }
+
+    // per-channel epilogue constants -> LDS: the epilogue must not wait on global loads between its stores (vmcnt is
+    // in order over loads and stores, so each such wait would drain every store issued before it)
+    if (tid < 4 * BM) {
+        const int which = tid / BM, co = co0 + tid % BM;
+        float v = 0.f;
+        if (co < a.Cout) {
+            if (which == 0 && a.bias) v = a.bias[co];
+            if (which == 1 && a.vec) v = a.vec[(long long)b * a.Cout + co];
+            if (which == 2 && a.aux) v = a.aux_a[(long long)b * a.Cout + co];
+            if (which == 3 && a.aux) v = a.aux_b[(long long)b * a.Cout + co];
+        }
+        econst[tid] = v;
     }
 
     float rin[NL];
@@ -283,40 +300,57 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     float* red = smem;  // [4 waves][BM co][2]
     const bool want_stats = a.stats != nullptr;
 
+    // Residual / aux operands of step i+1 are requested before the stores of step i (masked lanes read element 0 of
+    // the sample and discard it), so no wait ever covers a store younger than one step; the per-channel constants
+    // come from LDS.  One instantiation per (residual, aux) combination keeps the steps free of branches on them.
     float sv[MB * 32];  // per (mb, r): {sum, sumsq} over this lane's two pixels
+    auto out_steps = [&](auto res_tag, auto aux_tag) {
+        constexpr bool RES = decltype(res_tag)::value, AUX = decltype(aux_tag)::value;
+        float nres[2], naux[2];
+        auto fetch = [&](int i) {
+            const int co = co0 + (i >> 4) * 32 + (i & 3) + 8 * ((i & 15) >> 2) + 4 * half;
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
+            for (int nb = 0; nb < 2; ++nb) {
+                const long long o = (pval[nb] && co < a.Cout) ? (long long)co * HWo + opix[nb] : 0;
+                if (RES) nres[nb] = resb[o];
+                if (AUX) naux[nb] = auxb[o];
+            }
+        };
+        fetch(0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int i = 0; i < MB * 16; ++i) {
+            const int mb = i >> 4, r = i & 15;
             const int col = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const int co = co0 + col;
             const bool cval = co < a.Cout;
-            const float bv = (a.bias && cval) ? a.bias[co] : 0.f;
+            const float cres[2] = {nres[0], nres[1]}, caux[2] = {naux[0], naux[1]};
+            if (i + 1 < MB * 16) fetch(i + 1);
+            const float bv = econst[col], add = econst[BM + col];
+            float aa = 0.f, ab = 0.f;
+            if (AUX) aa = econst[2 * BM + col], ab = econst[3 * BM + col];
             float s = 0.f, q = 0.f;
-            float add = 0.f, aa = 0.f, ab = 0.f;
-            if (cval) {
-                if (a.vec) add = a.vec[(long long)b * a.Cout + co];
-                if (auxb) {
-                    aa = a.aux_a[(long long)b * a.Cout + co];
-                    ab = a.aux_b[(long long)b * a.Cout + co];
-                }
-            }
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
                 float v = acc[mb][nb][r] + bv;
                 if (pval[nb] && cval) {
                     s += v;
                     q += v * v;
-                    const long long o = (long long)co * HWo + opix[nb];
                     v += add;
-                    if (resb) v += resb[o];
-                    if (auxb) v += silu_fast(aa * auxb[o] + ab);
-                    outb[o] = v;
+                    if (RES) v += cres[nb];
+                    if (AUX) v += silu_fast(aa * caux[nb] + ab);
+                    outb[(long long)co * HWo + opix[nb]] = v;
                 }
             }
-            sv[(mb * 16 + r) * 2 + 0] = s;
-            sv[(mb * 16 + r) * 2 + 1] = q;
+            sv[i * 2 + 0] = s;
+            sv[i * 2 + 1] = q;
         }
+    };
+    if (resb) {
+        if (auxb) out_steps(std::true_type{}, std::true_type{});
+        else out_steps(std::true_type{}, std::false_type{});
+    } else {
+        if (auxb) out_steps(std::false_type{}, std::true_type{});
+        else out_steps(std::false_type{}, std::false_type{});
     }
     if (want_stats) {
         // butterfly reduce-scatter over the 32 lanes of each half-wave: after the step with mask m a lane keeps
@@ -372,7 +406,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     constexpr int RS = TW + KS - 1;
     constexpr int IN_TILE = ((CK * TRH * RS + 3) / 4) * 4;
     constexpr int W_TILE = KS * KS * CK * BM;
-    const size_t lds = ((size_t)2 * (IN_TILE + W_TILE) + (a.pro_a ? 2 * (size_t)a.C0r : 0)) * sizeof(float);
+    const size_t lds = ((size_t)2 * (IN_TILE + W_TILE) + (a.pro_a ? 2 * (size_t)a.C0r : 0) + 4 * BM) * sizeof(float);
     if (lds > 160 * 1024) IDIFF_FAIL(IDIFF_E_UNSUPPORTED, "conv2d: LDS budget exceeded (%zu bytes)", lds);
     static size_t attr_set = 0;
     auto kern = conv_igemm_kernel<KS, CK, TWL, MODE, VECW, MB, SPEC>;
@@ -388,6 +422,14 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
 
 template <int KS, int CK, int MODE, int MB>
 int dispatch_tw(const ConvArgs& a, int twl, bool vecw, hipStream_t st) {
+    if (twl == 8) {  // flattened 1x1: 256 consecutive pixels per tile (set up by idiff_conv2d_fwd, KS == 1 only)
+        if (KS == 1 && MODE == IDIFF_CONV_NORMAL && MB == 2 && vecw) {
+            if (a.pro_a) return launch_conv<1, CK, 8, IDIFF_CONV_NORMAL, true, 2, 2>(a, st);
+            if (a.src1) return launch_conv<1, CK, 8, IDIFF_CONV_NORMAL, true, 2, 3>(a, st);
+            return launch_conv<1, CK, 8, IDIFF_CONV_NORMAL, true, 2, 1>(a, st);
+        }
+        IDIFF_FAIL(IDIFF_E_UNSUPPORTED, "conv2d: internal: flattened tile requested for an unsupported variant");
+    }
     if (twl == 5) {
         if (KS == 3 && MODE == IDIFF_CONV_NORMAL && MB == 2 && vecw) {  // the hot layers: exact specialisations
             if (a.pro_a) return launch_conv<KS, CK, 5, MODE, true, MB, 2>(a, st);
@@ -490,9 +532,19 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
     IDIFF_CHECK_ARG(a.bs0 >= (long long)d->C0 * d->Hin * d->Win, "conv2d: src0_bstride too small");
     IDIFF_CHECK_ARG(d->C1 == 0 || a.bs1 >= (long long)d->C1 * d->Hin * d->Win, "conv2d: src1_bstride too small");
     IDIFF_CHECK_ARG(a.obs >= (long long)d->Cout * a.Hout * a.Wout, "conv2d: out_bstride too small");
-    const int twl = pick_twl(a.Wout);
-    const int TW = 1 << twl, TH = 256 / TW;
+    int twl = pick_twl(a.Wout);
     const int mb = a.Cout <= 32 ? 1 : 2;
+    const bool vecw = (a.Cout % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.wpk) & 15) == 0);
+    // A 1x1 conv has no halo, so its pixel tile may be any 256 pixels: flatten the image to one row and take 256
+    // consecutive pixels per tile -- 1 KB contiguous per input channel instead of 8 rows of 128 B (HBM-bound layers).
+    // Not when GroupNorm partials are requested: their layout is per 8x32 patch (idiff_conv2d_num_tiles).
+    if (d->ks == 1 && d->mode == IDIFF_CONV_NORMAL && !a.stats && mb == 2 && vecw && ((long long)a.Hout * a.Wout) % 256 == 0 &&
+        a.Wout >= 32) {
+        a.Win = a.Wout = a.Hout * a.Wout;
+        a.Hin = a.Hout = 1;
+        twl = 8;
+    }
+    const int TW = 1 << twl, TH = 256 / TW;
     const int bm = 32 * mb;
     a.tiles_x = (a.Wout + TW - 1) / TW;
     a.ntiles = a.tiles_x * ((a.Hout + TH - 1) / TH);
@@ -502,7 +554,6 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
     a.total_wg = (unsigned)total;
     hipStream_t st = (hipStream_t)stream;
     if (idiff_detail::conv_wino_eligible(a, d->ks, d->mode)) return idiff_detail::launch_conv_wino(a, d->mode, st);
-    const bool vecw = (a.Cout % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.wpk) & 15) == 0);
     if (d->ks == 3) {
         if (d->mode == IDIFF_CONV_NORMAL) return dispatch_mb<3, 8, IDIFF_CONV_NORMAL>(a, twl, mb, vecw, st);
         return dispatch_mb<3, 8, IDIFF_CONV_UPSAMPLE2>(a, twl, mb, vecw, st);
