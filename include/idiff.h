@@ -80,6 +80,10 @@ typedef struct {
 
 int idiff_conv2d_num_tiles(int Hout, int Wout);
 int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream);
+/* which kernel the calling thread's last idiff_conv2d_fwd launched (profiling / tests) */
+#define IDIFF_CONV_ALGO_DIRECT 0   /* implicit GEMM, conv_igemm.hip  */
+#define IDIFF_CONV_ALGO_WINOGRAD 1 /* F(2x2,3x3),   conv_wino.hip   */
+int idiff_conv2d_last_algo(void);
 /* w [Cout][Cin][ks][ks] (torch layout) -> wpk [ks*ks][Cin][Cout] */
 int idiff_pack_conv_weight(const float* w, float* wpk, int Cout, int Cin, int ks, idiff_stream_t stream);
 /* same, but spatially flipped and in/out swapped: wpk_T [ks*ks][Cout][Cin] for the data-gradient conv */
@@ -133,6 +137,15 @@ int idiff_linear_t_fwd(const float* x, int64_t ldx, const float* wT, int64_t ldw
 int idiff_smm_memproj_fwd(const float* feat, int64_t feat_bstride, const float* ln1_g, const float* ln1_b,
                           const float* wpk, const float* bias, const float* ln2_g, const float* ln2_b, float* out, int B,
                           int C, int N, float eps, idiff_stream_t stream);
+/* Compact form of the same memory for narrow feature maps (C + 1 <= Cm < 256).  With xhat = LayerNorm_C(feat[b,:,p]),
+ * z = wpk^T.xhat + bias, mu = mean(z), rstd = 1/sqrt(var(z)+eps):   LayerNorm_256(z) = g2 * ((Wc.xhat + bc) * rstd) + b2
+ * (Wc, bc = W and bias centred over the 256 outputs), i.e. the 256-wide memory is an affine image of the (C+1)-vector
+ * [xhat*rstd ; rstd].  out [B,Cm,N] = rows [xhat*rstd (C) ; rstd (1) ; zeros]; the host folds g2.[Wc|bc] into the query
+ * and value projections of the cross-attention (b2 cancels in the softmax and re-enters as a bias), so
+ * idiff_smm_xattn_fwd streams (C+1)/256 of the bytes.  Same arithmetic as idiff_smm_memproj_fwd up to fp32 rounding. */
+int idiff_smm_memproj_compact_fwd(const float* feat, int64_t feat_bstride, const float* ln1_g, const float* ln1_b,
+                                  const float* wpk, const float* bias, float* out, int B, int C, int N, int Cm, float eps,
+                                  idiff_stream_t stream);
 int idiff_layernorm_rows_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out,
                              int64_t ldo, int R, int C, float eps, float* mean_rstd, idiff_stream_t stream);
 /* sinusoidal embedding, [sin | cos] halves; freqs [dim/2] = host-built table exp(-ln(1e4) * i/(half-1))
@@ -161,7 +174,7 @@ int idiff_attn_tokens_fwd(const float* q, const float* k, const float* v, float*
                           int heads, float scale, int64_t ldq, int64_t ldkv, idiff_stream_t stream);
 /* ScoreMapModule cross-attention, K/V projections folded onto the query side:
  *   S[b,h,q,n] = scale * sum_c qf[b,q,h,c] * mem[b,c,n];  P = softmax_n(S);  o[b,q,h,c] = sum_n P * mem[b,c,n]
- * qf, o: [B, Nq, heads, Cm];  mem: [B, Cm, N] channel-major;  Nq*heads <= 32, Cm % 32 == 0.
+ * qf, o: [B, Nq, heads, Cm];  mem: [B, Cm, N] channel-major;  Nq*heads <= 32, Cm in {96, 160, 256}.
  * ws: workspace of idiff_smm_xattn_ws_floats(B,Nq,heads,Cm,N) floats. */
 int64_t idiff_smm_xattn_ws_floats(int B, int Nq, int heads, int Cm, int N);
 int idiff_smm_xattn_fwd(const float* qf, const float* mem, float* o, float* ws, int B, int Nq, int heads, int Cm,

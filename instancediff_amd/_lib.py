@@ -42,6 +42,7 @@ SIGNATURES = {
     "idiff_device_info": (I, [C.POINTER(I), C.POINTER(I), C.c_char_p, I]),
     "idiff_conv2d_num_tiles": (I, [I, I]),
     "idiff_conv2d_fwd": (I, [C.POINTER(ConvDesc), c_stream]),
+    "idiff_conv2d_last_algo": (I, []),
     "idiff_pack_conv_weight": (I, [P, P, I, I, I, c_stream]),
     "idiff_pack_conv_weight_T": (I, [P, P, I, I, I, c_stream]),
     "idiff_pack_conv_weight_wino": (I, [P, P, I, I, I, c_stream]),
@@ -50,6 +51,7 @@ SIGNATURES = {
     "idiff_linear_fwd": (I, [P, I64, P, I64, P, P, I64, P, P, I64, I, I, I, I, I, c_stream]),
     "idiff_linear_t_fwd": (I, [P, I64, P, I64, P, P, I64, P, P, I64, I, I, I, I, I, c_stream]),
     "idiff_smm_memproj_fwd": (I, [P, I64, P, P, P, P, P, P, P, I, I, I, F, c_stream]),
+    "idiff_smm_memproj_compact_fwd": (I, [P, I64, P, P, P, P, P, I, I, I, I, F, c_stream]),
     "idiff_layernorm_rows_fwd": (I, [P, I64, P, P, P, I64, I, I, F, P, c_stream]),
     "idiff_time_embed_fwd": (I, [P, P, I, I, P, c_stream]),
     "idiff_chan_layernorm_fwd": (I, [P, I64, P, P, P, I64, I, I, I, F, P, c_stream]),

@@ -213,12 +213,16 @@ __global__ __launch_bounds__(64) void attn_tokens_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------
-// ScoreMapModule cross attention, Cm == 256, rows = Nq*heads <= 32
-constexpr int XCM = 256;
-constexpr int XCW = 64;           // channels per wave
-constexpr int XTILE = XCW * 33;   // per-wave mem slice [64 c][33]
+// ScoreMapModule cross attention, Cm = 4*XCW in {96, 160, 256}, rows = Nq*heads <= 32.  XCW = channels per wave
+// (multiple of 8); the P.V product runs on whole 32-channel blocks, so a wave's LDS slice is padded to XCB*32 rows
+// (the padding rows produce accumulator rows that are never stored).
+template <int XCW>
 __global__ __launch_bounds__(256) void smm_xattn_kernel(const float* __restrict__ qf, const float* __restrict__ mem, float* __restrict__ ws,
                                                         int rows, int N, int nsplit, int kps, float scale) {
+    constexpr int XCM = 4 * XCW;
+    constexpr int XCB = (XCW + 31) / 32;      // 32-channel blocks per wave in the P.V product
+    constexpr int XTILE = XCB * 32 * 33;      // per-wave mem slice [XCB*32 c][33]
+    constexpr int NF4 = XCW / 8;              // float4 loads per lane per 32-key block
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tile = smem + (threadIdx.x >> 6) * XTILE;  // private per wave
     float* xch = smem + 4 * XTILE;                    // [4][16][64]
@@ -231,9 +235,9 @@ __global__ __launch_bounds__(256) void smm_xattn_kernel(const float* __restrict_
 #pragma unroll
     for (int t = 0; t < XCW / 2; ++t) qreg[t] = l31 < rows ? qf[((long long)b * rows + l31) * XCM + c0 + 2 * t + half] : 0.f;
 
-    floatx16 O[2];
+    floatx16 O[XCB];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < XCB; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[m][r] = 0.f;
     float mrun = -INFINITY, lrun = 0.f;
@@ -242,12 +246,12 @@ __global__ __launch_bounds__(256) void smm_xattn_kernel(const float* __restrict_
     const int kb_begin = sp * kps;
     const int kb_end = min(nkb, kb_begin + kps);
 
-    floatx4 rt[8];  // 64 c x 32 keys / 64 lanes = 32 floats per lane
+    floatx4 rt[NF4];  // XCW c x 32 keys / 64 lanes
     auto load_tile = [&](int kbi) {
         const int key0 = kbi * 32;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int f = lane + i * 64;  // float4 index in [64][8]
+        for (int i = 0; i < NF4; ++i) {
+            const int f = lane + i * 64;  // float4 index in [XCW][8]
             const int c = f >> 3, j4 = (f & 7) * 4;
             floatx4 z = {0.f, 0.f, 0.f, 0.f};
             if (key0 + j4 + 3 < N)
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(256) void smm_xattn_kernel(const float* __restrict_
     };
     auto write_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NF4; ++i) {
             const int f = lane + i * 64;
             const int c = f >> 3, j4 = (f & 7) * 4;
 #pragma unroll
@@ -304,13 +308,13 @@ __global__ __launch_bounds__(256) void smm_xattn_kernel(const float* __restrict_
         lrun = lrun * alpha + ps;
         mrun = mnew;
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < XCB; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) O[m][r] *= alpha;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < XCB; ++m)
                 O[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(tile[(m * 32 + l31) * 33 + KAPPA(r) + 4 * half], S[r], O[m], 0, 0, 0);
         if (kbi + 1 < kb_end) write_tile();
         __syncthreads();  // xch reads of this block done before the next block's writes
@@ -319,16 +323,19 @@ __global__ __launch_bounds__(256) void smm_xattn_kernel(const float* __restrict_
     float* wp = ws + ((long long)b * nsplit + sp) * (XCM + 2) * 32;
     const float l = lrun + __shfl_xor(lrun, 32, 64);
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < XCB; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) wp[(c0 + m * 32 + KAPPA(r) + 4 * half) * 32 + l31] = O[m][r];
+        for (int r = 0; r < 16; ++r) {
+            const int cl = m * 32 + KAPPA(r) + 4 * half;
+            if (cl < XCW) wp[(c0 + cl) * 32 + l31] = O[m][r];
+        }
     if (wave == 0 && half == 0) {
         wp[XCM * 32 + l31] = mrun;
         wp[(XCM + 1) * 32 + l31] = l;
     }
 }
 
-__global__ __launch_bounds__(256) void smm_xattn_combine_kernel(const float* __restrict__ ws, float* __restrict__ o, int rows, int nsplit) {
+__global__ __launch_bounds__(256) void smm_xattn_combine_kernel(const float* __restrict__ ws, float* __restrict__ o, int rows, int nsplit, int XCM) {
     const int b = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over rows*XCM
     if (i >= rows * XCM) return;
@@ -420,17 +427,23 @@ extern "C" int64_t idiff_smm_xattn_ws_floats(int B, int Nq, int heads, int Cm, i
 extern "C" int idiff_smm_xattn_fwd(const float* qf, const float* mem, float* o, float* ws, int B, int Nq, int heads, int Cm, int N, float scale,
                                    idiff_stream_t stream) {
     IDIFF_CHECK_ARG(qf && mem && o && ws && B > 0 && Nq > 0 && heads > 0 && N > 0, "smm_xattn: bad args");
-    IDIFF_CHECK_ARG(Cm == XCM, "smm_xattn: Cm must be %d (got %d)", XCM, Cm);
+    IDIFF_CHECK_ARG(Cm == 256 || Cm == 160 || Cm == 96, "smm_xattn: Cm must be 96, 160 or 256 (got %d)", Cm);
     IDIFF_CHECK_ARG(Nq * heads <= 32, "smm_xattn: Nq*heads must be <= 32 (got %d)", Nq * heads);
     IDIFF_CHECK_ARG(N % 4 == 0, "smm_xattn: N must be a multiple of 4");
     int ns, kps;
     smm_split(B, N, &ns, &kps);
     const int rows = Nq * heads;
-    const size_t lds = (size_t)(4 * XTILE + 4 * 16 * 64) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(smm_xattn_kernel, dim3(ns, B), dim3(256), lds, st, qf, mem, ws, rows, N, ns, kps, scale);
+    const int xcb = (Cm / 4 + 31) / 32;
+    const size_t lds = (size_t)(4 * xcb * 32 * 33 + 4 * 16 * 64) * sizeof(float);
+    if (Cm == 256)
+        hipLaunchKernelGGL(smm_xattn_kernel<64>, dim3(ns, B), dim3(256), lds, st, qf, mem, ws, rows, N, ns, kps, scale);
+    else if (Cm == 160)
+        hipLaunchKernelGGL(smm_xattn_kernel<40>, dim3(ns, B), dim3(256), lds, st, qf, mem, ws, rows, N, ns, kps, scale);
+    else
+        hipLaunchKernelGGL(smm_xattn_kernel<24>, dim3(ns, B), dim3(256), lds, st, qf, mem, ws, rows, N, ns, kps, scale);
     IDIFF_CHECK_LAUNCH("smm_xattn_fwd");
-    hipLaunchKernelGGL(smm_xattn_combine_kernel, dim3((rows * XCM + 255) / 256, B), dim3(256), 0, st, ws, o, rows, ns);
+    hipLaunchKernelGGL(smm_xattn_combine_kernel, dim3((rows * Cm + 255) / 256, B), dim3(256), 0, st, ws, o, rows, ns, Cm);
     IDIFF_CHECK_LAUNCH("smm_xattn_combine");
     return IDIFF_OK;
 }

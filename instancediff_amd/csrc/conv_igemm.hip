@@ -470,6 +470,9 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 
 }  // namespace
 
+static thread_local int g_last_algo = IDIFF_CONV_ALGO_DIRECT;
+extern "C" int idiff_conv2d_last_algo(void) { return g_last_algo; }
+
 extern "C" int idiff_conv2d_num_tiles(int Hout, int Wout) {
     const int twl = pick_twl(Wout);
     const int TW = 1 << twl, TH = 256 / TW;
@@ -553,7 +556,11 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
     IDIFF_CHECK_ARG(total < (1ll << 31), "conv2d: grid too large");
     a.total_wg = (unsigned)total;
     hipStream_t st = (hipStream_t)stream;
-    if (idiff_detail::conv_wino_eligible(a, d->ks, d->mode)) return idiff_detail::launch_conv_wino(a, d->mode, st);
+    if (idiff_detail::conv_wino_eligible(a, d->ks, d->mode)) {
+        g_last_algo = IDIFF_CONV_ALGO_WINOGRAD;
+        return idiff_detail::launch_conv_wino(a, d->mode, st);
+    }
+    g_last_algo = IDIFF_CONV_ALGO_DIRECT;
     if (d->ks == 3) {
         if (d->mode == IDIFF_CONV_NORMAL) return dispatch_mb<3, 8, IDIFF_CONV_NORMAL>(a, twl, mb, vecw, st);
         return dispatch_mb<3, 8, IDIFF_CONV_UPSAMPLE2>(a, twl, mb, vecw, st);

@@ -17,7 +17,8 @@ constexpr int MP_PX = 64;   // pixels per workgroup
 __global__ __launch_bounds__(256) void smm_memproj_kernel(const float* __restrict__ feat, long long fbs, const float* __restrict__ g1,
                                                           const float* __restrict__ b1, const float* __restrict__ wpk,
                                                           const float* __restrict__ bias, const float* __restrict__ g2,
-                                                          const float* __restrict__ b2, float* __restrict__ out, int C, int N, float eps) {
+                                                          const float* __restrict__ b2, float* __restrict__ out, int C, int N, float eps,
+                                                          int compact_cm) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xt = smem;                 // [C][64]
     float* part = smem + C * MP_PX;   // [4][64]
@@ -136,6 +137,36 @@ __global__ __launch_bounds__(256) void smm_memproj_kernel(const float* __restric
         const int p = n * 32 + l31;
         rstd2[n] = rsqrtf((part[p] + part[MP_PX + p] + part[2 * MP_PX + p] + part[3 * MP_PX + p]) / (float)MP_W + eps);
     }
+    if (compact_cm > 0) {
+        // Compact form for the folded cross-attention (idiff_smm_memproj_compact_fwd): the 256-wide projection is only
+        // needed for its per-pixel statistics; what is stored is [ xhat * rstd2 ; rstd2 ; 0.. ] = C+1 (-> compact_cm) rows.
+        float* rs = part;  // [64] rstd2 per pixel (part is free: all reads of it are done after the barrier below)
+        __syncthreads();
+        if (wave == 0 && half == 0) {
+            rs[l31] = rstd2[0];
+            rs[32 + l31] = rstd2[1];
+        }
+        __syncthreads();
+        float* ob = out + (long long)b * compact_cm * N;
+        const int nf = compact_cm * (MP_PX / 4);
+        for (int f = tid; f < nf; f += 256) {
+            const int c = f >> 4, j4 = (f & 15) * 4;
+            floatx4 v = {0.f, 0.f, 0.f, 0.f};
+            const floatx4 r4 = *reinterpret_cast<const floatx4*>(rs + j4);
+            if (c < C) {
+                const floatx4 x4 = *reinterpret_cast<const floatx4*>(xt + c * MP_PX + j4);
+                v = floatx4{x4.x * r4.x, x4.y * r4.y, x4.z * r4.z, x4.w * r4.w};
+            } else if (c == C) {
+                v = r4;
+            }
+            if (p0 + j4 + 3 < N)
+                *reinterpret_cast<floatx4*>(ob + (long long)c * N + p0 + j4) = v;
+            else
+                for (int e = 0; e < 4; ++e)
+                    if (p0 + j4 + e < N) ob[(long long)c * N + p0 + j4 + e] = v[e];
+        }
+        return;
+    }
     float* ob = out + (long long)b * MP_W * N;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
@@ -213,12 +244,14 @@ __global__ __launch_bounds__(256) void linear_t_kernel(const float* __restrict__
 
 }  // namespace
 
-extern "C" int idiff_smm_memproj_fwd(const float* feat, int64_t feat_bstride, const float* ln1_g, const float* ln1_b, const float* wpk,
-                                     const float* bias, const float* ln2_g, const float* ln2_b, float* out, int B, int C, int N, float eps,
-                                     idiff_stream_t stream) {
-    IDIFF_CHECK_ARG(feat && ln1_g && ln1_b && wpk && bias && ln2_g && ln2_b && out, "smm_memproj: null pointer");
+static int memproj_launch(const float* feat, int64_t feat_bstride, const float* ln1_g, const float* ln1_b, const float* wpk, const float* bias,
+                          const float* ln2_g, const float* ln2_b, float* out, int B, int C, int N, float eps, int compact_cm,
+                          idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(feat && ln1_g && ln1_b && wpk && bias && out, "smm_memproj: null pointer");
+    IDIFF_CHECK_ARG(compact_cm > 0 || (ln2_g && ln2_b), "smm_memproj: null pointer");
     IDIFF_CHECK_ARG(B > 0 && N > 0 && C >= 2 && C % 2 == 0 && C <= 512, "smm_memproj: C must be even and <= 512 (got %d)", C);
     IDIFF_CHECK_ARG(N % 4 == 0 && feat_bstride % 4 == 0, "smm_memproj: N and feat_bstride must be multiples of 4");
+    IDIFF_CHECK_ARG(compact_cm == 0 || compact_cm > C, "smm_memproj_compact: Cm must exceed C (got %d, C = %d)", compact_cm, C);
     const size_t lds = (size_t)(C * MP_PX + 4 * MP_PX + 2 * MP_PX) * sizeof(float);
     static size_t attr = 0;
     if (lds > attr) {
@@ -227,9 +260,20 @@ extern "C" int idiff_smm_memproj_fwd(const float* feat, int64_t feat_bstride, co
         attr = lds;
     }
     hipLaunchKernelGGL(smm_memproj_kernel, dim3((N + MP_PX - 1) / MP_PX, B), dim3(256), lds, (hipStream_t)stream, feat, (long long)feat_bstride,
-                       ln1_g, ln1_b, wpk, bias, ln2_g, ln2_b, out, C, N, eps);
+                       ln1_g, ln1_b, wpk, bias, compact_cm ? bias : ln2_g, compact_cm ? bias : ln2_b, out, C, N, eps, compact_cm);
     IDIFF_CHECK_LAUNCH("smm_memproj_fwd");
     return IDIFF_OK;
+}
+
+extern "C" int idiff_smm_memproj_fwd(const float* feat, int64_t feat_bstride, const float* ln1_g, const float* ln1_b, const float* wpk,
+                                     const float* bias, const float* ln2_g, const float* ln2_b, float* out, int B, int C, int N, float eps,
+                                     idiff_stream_t stream) {
+    return memproj_launch(feat, feat_bstride, ln1_g, ln1_b, wpk, bias, ln2_g, ln2_b, out, B, C, N, eps, 0, stream);
+}
+
+extern "C" int idiff_smm_memproj_compact_fwd(const float* feat, int64_t feat_bstride, const float* ln1_g, const float* ln1_b, const float* wpk,
+                                             const float* bias, float* out, int B, int C, int N, int Cm, float eps, idiff_stream_t stream) {
+    return memproj_launch(feat, feat_bstride, ln1_g, ln1_b, wpk, bias, nullptr, nullptr, out, B, C, N, eps, Cm, stream);
 }
 
 extern "C" int idiff_linear_t_fwd(const float* x, int64_t ldx, const float* wT, int64_t ldw, const float* bias, const float* res, int64_t ldr,

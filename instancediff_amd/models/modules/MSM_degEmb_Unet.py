@@ -178,7 +178,15 @@ class ScoreMapModule(nn.Module):
         mp = dec.memory_proj
         wmp = _PREP.get(("mp", mp[1]), (mp[1].weight,),
                         lambda: ops.pack_conv_weight(mp[1].weight.detach().reshape(Wd, C, 1, 1).contiguous()))
-        mem = ops.smm_memproj(feat, mp[0].weight, mp[0].bias, wmp, mp[1].bias, mp[2].weight, mp[2].bias, eps=mp[0].eps)
+        # Narrow feature maps: LN_256(W.xhat + b) = g2 * ((Wc.xhat + bc) * rstd) + b2 is an affine image of the (C+1)-vector
+        # m = [xhat*rstd ; rstd], so the cross-attention streams m (Cm = 96 / 160 rows) instead of the 256-row memory and
+        # g2.[Wc|bc] is folded into its query / value projections (b2 drops out of the softmax and returns as a bias).
+        Cm = Wd if C + 1 > 160 else (96 if C + 1 <= 96 else 160)
+        compact = Cm < Wd
+        if compact:
+            mem = ops.smm_memproj_compact(feat, mp[0].weight, mp[0].bias, wmp, mp[1].bias, Cm, eps=mp[0].eps)
+        else:
+            mem = ops.smm_memproj(feat, mp[0].weight, mp[0].bias, wmp, mp[1].bias, mp[2].weight, mp[2].bias, eps=mp[0].eps)
         tp = dec.text_proj
         x = ops.linear_t(ops.layernorm_rows(t2d, tp[0].weight, tp[0].bias), wT(tp[1]), tp[1].bias)  # [B*K, Wd]
         for li, layer in enumerate(dec.decoder):
@@ -193,14 +201,19 @@ class ScoreMapModule(nn.Module):
             #   qf[:, h, :] = q_h @ Wk[h*dh:(h+1)*dh, :]   (Wk's row block IS the transposed-weight form [K=dh][N=Wd])
             n2 = ops.layernorm_rows(x, layer.norm2.weight, layer.norm2.bias)
             qc = ops.linear_t(n2, wT(ca.q_proj))
-            qf = torch.empty((B * K, heads * Wd), device=feat.device, dtype=torch.float32)
+            if compact:
+                wkf, wvf, bvf = _PREP.get(("xfold", ca, Cm), (mp[1].weight, mp[1].bias, mp[2].weight, mp[2].bias, ca.k_proj.weight, ca.v_proj.weight),
+                                          lambda: _fold_memory_affine(mp[1], mp[2], ca, Cm))
+            else:
+                wkf, wvf, bvf = ca.k_proj.weight, wT(ca.v_proj), None  # [Wd(dh blocks), Wd], [Wd (c), Wd (n)]
+            qf = torch.empty((B * K, heads * Cm), device=feat.device, dtype=torch.float32)
             for h in range(heads):
-                ops.linear_t(qc[:, h * dh:(h + 1) * dh], ca.k_proj.weight[h * dh:(h + 1) * dh], out=qf[:, h * Wd:(h + 1) * Wd])
-            o = ops.smm_xattn(qf.reshape(B, K, heads, Wd), mem, ca.scale).reshape(B * K, heads * Wd)
-            wvT = wT(ca.v_proj)  # [Wd (c), Wd (n)]
+                ops.linear_t(qc[:, h * dh:(h + 1) * dh], wkf[h * dh:(h + 1) * dh], out=qf[:, h * Cm:(h + 1) * Cm])
+            o = ops.smm_xattn(qf.reshape(B, K, heads, Cm), mem, ca.scale).reshape(B * K, heads * Cm)
             av = torch.empty((B * K, Wd), device=feat.device, dtype=torch.float32)
             for h in range(heads):
-                ops.linear_t(o[:, h * Wd:(h + 1) * Wd], wvT[:, h * dh:(h + 1) * dh], out=av[:, h * dh:(h + 1) * dh])
+                ops.linear_t(o[:, h * Cm:(h + 1) * Cm], wvf[:, h * dh:(h + 1) * dh], None if bvf is None else bvf[h * dh:(h + 1) * dh],
+                             out=av[:, h * dh:(h + 1) * dh])
             x = ops.linear_t(av, wT(ca.proj), ca.proj.bias, res=x)
             n3 = ops.layernorm_rows(x, layer.norm3.weight, layer.norm3.bias)
             hm = ops.linear_t(n3, wT(layer.mlp[0]), layer.mlp[0].bias, act_out=ops.ACT_GELU)
@@ -209,6 +222,26 @@ class ScoreMapModule(nn.Module):
         t2v = ops.linear_t(t2d, wT(self.text_to_visual), self.text_to_visual.bias)
         tv = ops.linear_t(ops.layernorm_rows(x, op[0].weight, op[0].bias), wT(op[1]), op[1].bias, res=t2v, gscale=self.gamma)
         return ops.scoremap(feat, tv.reshape(B, K, C), idx)
+
+
+def _fold_memory_affine(lin, ln2, ca, Cm):
+    """Weights of the compact cross-attention (host-side weight preparation, fp64): with P = g2 * [Wc | bc | 0] ([Wd, Cm];
+    Wc, bc = the memory Linear's weight / bias centred over its Wd outputs)
+        wkf = Wk @ P            [Wd (dh row blocks), Cm]   query fold:  qf_h = q_h @ wkf[h-block]
+        wvf = P^T @ Wv^T        [Cm, Wd]                   value fold:  av_h = o_h @ wvf[:, h-block] + bvf[h-block]
+        bvf = b2 @ Wv^T         [Wd]                       (softmax weights sum to 1)"""
+    W = lin.weight.detach().double()
+    b = lin.bias.detach().double()
+    Wd, C = W.shape
+    P = torch.zeros((Wd, Cm), dtype=torch.float64, device=W.device)
+    P[:, :C] = W - W.mean(dim=0, keepdim=True)
+    P[:, C] = b - b.mean()
+    P *= ln2.weight.detach().double()[:, None]
+    WvT = ca.v_proj.weight.detach().double().t()
+    wkf = (ca.k_proj.weight.detach().double() @ P).float().contiguous()
+    wvf = (P.t() @ WvT).float().contiguous()
+    bvf = (ln2.bias.detach().double() @ WvT).float().contiguous()
+    return wkf, wvf, bvf
 
 
 class ResBlock(nn.Module):

@@ -131,7 +131,7 @@ def conv2d(src0, wpk, bias, ks, Cout, src1=None, mode=CONV_NORMAL, pro=None, out
         check(lib.idiff_conv2d_fwd(C.byref(d), _stream()), "conv2d_fwd")
         e1.record()
         Cin = (C0 * 4 if mode == CONV_UNSHUFFLE2 else C0) + (src1.shape[1] if src1 is not None else 0)
-        PROFILE.append(dict(ks=ks, mode=mode, Cin=Cin, Cout=Cout, B=B, Hout=Hout, Wout=Wout, e0=e0, e1=e1,
+        PROFILE.append(dict(ks=ks, mode=mode, Cin=Cin, Cout=Cout, B=B, Hout=Hout, Wout=Wout, e0=e0, e1=e1, algo=lib.idiff_conv2d_last_algo(),
                             flops=2.0 * Cin * Cout * ks * ks * Hout * Wout * B))
     else:
         check(lib.idiff_conv2d_fwd(C.byref(d), _stream()), "conv2d_fwd")
@@ -207,6 +207,16 @@ def smm_memproj(feat, ln1_g, ln1_b, wpk, bias, ln2_g, ln2_b, eps=1e-5):
     out = torch.empty((B, 256, H * W), device=feat.device, dtype=torch.float32)
     check(lib.idiff_smm_memproj_fwd(_p(feat), _bs(feat, "feat"), _p(_c(ln1_g)), _p(_c(ln1_b)), _p(_c(wpk)), _p(_c(bias)), _p(_c(ln2_g)),
                                     _p(_c(ln2_b)), _p(out), B, Cc, H * W, eps, _stream()), "smm_memproj_fwd")
+    return out
+
+
+def smm_memproj_compact(feat, ln1_g, ln1_b, wpk, bias, Cm, eps=1e-5):
+    """feat [B,C,H,W] -> [B,Cm,H*W] rows [xhat*rstd2 ; rstd2 ; 0]: the (C+1)-dim affine pre-image of the 256-wide memory."""
+    lib = _lib.load()
+    B, Cc, H, W = feat.shape
+    out = torch.empty((B, Cm, H * W), device=feat.device, dtype=torch.float32)
+    check(lib.idiff_smm_memproj_compact_fwd(_p(feat), _bs(feat, "feat"), _p(_c(ln1_g)), _p(_c(ln1_b)), _p(_c(wpk)), _p(_c(bias)), _p(out),
+                                            B, Cc, H * W, Cm, eps, _stream()), "smm_memproj_compact_fwd")
     return out
 
 

@@ -80,3 +80,68 @@ def test_attn_tokens_packed():
     s = torch.einsum('bnhd,bmhd->bhnm', q.reshape(B, N, heads, dh), k.reshape(B, N, heads, dh)) * dh ** -0.5
     ref = torch.einsum('bhnm,bmhd->bnhd', s.softmax(-1), v.reshape(B, N, heads, dh)).reshape(B, N, C)
     _close(ops.attn_tokens_packed(qkv.to(DEV), heads, dh ** -0.5), ref, 5e-6, "attn_tokens_packed")
+
+
+# ---------------------------------------------------------------------------------------------------
+# compact ScoreMapModule memory: [xhat*rstd ; rstd] + folded projections == attention over the 256-wide memory
+@pytest.mark.parametrize("Cm,N", [(96, 1024), (160, 256), (256, 512), (96, 36)])
+def test_smm_xattn_channel_widths(Cm, N):
+    g = torch.Generator().manual_seed(31)
+    B, Nq, heads = 2, 5, 4
+    qf = torch.randn(B, Nq, heads, Cm, generator=g) * 0.3
+    mem = torch.randn(B, Cm, N, generator=g)
+    scale = 0.125
+    S = torch.einsum("bqhc,bcn->bqhn", qf.double(), mem.double()) * scale
+    ref = torch.einsum("bqhn,bcn->bqhc", torch.softmax(S, -1), mem.double())
+    out = ops.smm_xattn(qf.to(DEV), mem.to(DEV), scale)
+    _close(out, ref, 1e-5, f"smm_xattn Cm={Cm}")
+
+
+@pytest.mark.parametrize("C,Cm,H,W", [(64, 96, 32, 32), (128, 160, 16, 16), (64, 96, 6, 10)])
+def test_smm_compact_memory_equals_full_memory_attention(C, Cm, H, W):
+    from instancediff_amd.models.modules import MSM_degEmb_Unet as M
+    g = torch.Generator().manual_seed(32)
+    B, Nq, heads, Wd = 2, 5, 4, 256
+    dh = Wd // heads
+    feat = torch.randn(B, C, H, W, generator=g) * 1.5 + 0.2
+    ln1 = torch.nn.LayerNorm(C)
+    lin = torch.nn.Linear(C, Wd)
+    ln2 = torch.nn.LayerNorm(Wd)
+    ca = type("CA", (), {})()
+    ca.k_proj, ca.v_proj = torch.nn.Linear(Wd, Wd, bias=False), torch.nn.Linear(Wd, Wd, bias=False)
+    with torch.no_grad():
+        for p_ in (ln1.weight, ln1.bias, ln2.weight, ln2.bias, lin.bias):
+            p_.copy_(torch.randn(p_.shape, generator=g) * 0.5 + (1.0 if p_ is ln1.weight or p_ is ln2.weight else 0.0))
+    qc = torch.randn(B * Nq, Wd, generator=g) * 0.5
+    scale = dh ** -0.5
+    # reference: attention over the full 256-wide memory (fp64)
+    tok = feat.double().reshape(B, C, H * W).permute(0, 2, 1)
+    mem = F.layer_norm(F.linear(F.layer_norm(tok, (C,), ln1.weight.double(), ln1.bias.double(), 1e-5), lin.weight.double(), lin.bias.double()),
+                       (Wd,), ln2.weight.double(), ln2.bias.double(), 1e-5)                      # [B, N, Wd]
+    q = qc.double().reshape(B, Nq, heads, dh)
+    k = (mem @ ca.k_proj.weight.double().T).reshape(B, -1, heads, dh)
+    v = (mem @ ca.v_proj.weight.double().T).reshape(B, -1, heads, dh)
+    att = torch.softmax(torch.einsum("bqhd,bnhd->bhqn", q, k) * scale, -1)
+    ref = torch.einsum("bhqn,bnhd->bqhd", att, v).reshape(B * Nq, Wd)
+    # compact path on the device
+    wpk = ops.pack_conv_weight(lin.weight.detach().reshape(Wd, C, 1, 1).contiguous().to(DEV))
+    m = ops.smm_memproj_compact(feat.to(DEV), ln1.weight.detach().to(DEV), ln1.bias.detach().to(DEV), wpk, lin.bias.detach().to(DEV), Cm)
+    assert m.shape == (B, Cm, H * W)
+    xhat = F.layer_norm(tok, (C,), ln1.weight.double(), ln1.bias.double(), 1e-5)
+    z = F.linear(xhat, lin.weight.double(), lin.bias.double())
+    rstd = 1.0 / torch.sqrt(z.var(-1, unbiased=False) + 1e-5)
+    _close(m[:, :C], (xhat * rstd[..., None]).permute(0, 2, 1), 1e-5, "compact rows")
+    _close(m[:, C], rstd, 1e-5, "rstd row")
+    assert float(m[:, C + 1:].abs().max()) == 0.0
+    lin_d, ln2_d = lin.to(DEV), ln2.to(DEV)
+    ca.k_proj, ca.v_proj = ca.k_proj.to(DEV), ca.v_proj.to(DEV)
+    wkf, wvf, bvf = M._fold_memory_affine(lin_d, ln2_d, ca, Cm)
+    qd = qc.to(DEV)
+    qf = torch.empty(B * Nq, heads * Cm, device=DEV)
+    for h in range(heads):
+        ops.linear_t(qd[:, h * dh:(h + 1) * dh], wkf[h * dh:(h + 1) * dh], out=qf[:, h * Cm:(h + 1) * Cm])
+    o = ops.smm_xattn(qf.reshape(B, Nq, heads, Cm), m, scale).reshape(B * Nq, heads * Cm)
+    av = torch.empty(B * Nq, Wd, device=DEV)
+    for h in range(heads):
+        ops.linear_t(o[:, h * Cm:(h + 1) * Cm], wvf[:, h * dh:(h + 1) * dh], bvf[h * dh:(h + 1) * dh], out=av[:, h * dh:(h + 1) * dh])
+    _close(av, ref, 2e-5, "compact-memory cross attention")

@@ -350,8 +350,11 @@ def test_conv_winograd_matches_direct_and_fp64(B, C0, C1, Cout, H, W, variant):
         ref = raw + res.double() + vec.double()[:, :, None, None] + silu64(aa.double()[:, :, None, None] * aux.double() + ab.double()[:, :, None, None])
         kw.update(res=res.to(DEV), vec=vec.to(DEV), aux=(aux.to(DEV), aa.to(DEV), ab.to(DEV)))
     wd = w.to(DEV)
+    lib = ops._lib.load()
     out_w, st_w = ops.conv2d(x0.to(DEV), _pack(wd, True), b.to(DEV), 3, Cout, want_stats=True, **kw)
+    assert lib.idiff_conv2d_last_algo() == 1, "the Winograd kernel did not run"
     out_d, st_d = ops.conv2d(x0.to(DEV), _pack(wd, False), b.to(DEV), 3, Cout, want_stats=True, **kw)
+    assert lib.idiff_conv2d_last_algo() == 0
     _close(out_d, ref, 2e-6, "direct")
     _close(out_w, ref, 6e-6, "winograd")          # a few ulps of reassociation more than the direct kernel
     assert st_w.shape == st_d.shape
