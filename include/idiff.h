@@ -131,6 +131,12 @@ int idiff_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, c
 int idiff_linear_t_fwd(const float* x, int64_t ldx, const float* wT, int64_t ldw, const float* bias, const float* res,
                        int64_t ldr, const float* gscale, float* out, int64_t ldo, int R, int K, int N, int act_in,
                        int act_out, idiff_stream_t stream);
+/* `heads` independent products of that form in ONE launch (no res / gscale / activation): head h uses x + h*x_hs,
+ * wT + h*w_hs, bias + h*b_hs, out + h*o_hs -- the per-head k/v folds of the ScoreMapModule cross-attention, whose
+ * operands are column / row blocks of shared matrices. */
+int idiff_linear_t_heads_fwd(const float* x, int64_t ldx, int64_t x_hs, const float* wT, int64_t ldw, int64_t w_hs,
+                             const float* bias, int64_t b_hs, float* out, int64_t ldo, int64_t o_hs, int R, int K, int N,
+                             int heads, idiff_stream_t stream);
 /* ScoreMapModule memory projection fused in one pass (ContextDecoder.memory_proj, _modified_BiomedCLIP.py:1205-1209):
  * out[b,:,p] = LayerNorm_256( wpk^T . LayerNorm_C(feat[b,:,p]) + bias );  feat [B,C,N] (feat_bstride), wpk [C][256]
  * (idiff_pack_conv_weight of the [256,C,1,1] view), out [B,256,N]. */

@@ -198,7 +198,13 @@ constexpr int LT_ROWS = 8;
 __global__ __launch_bounds__(256) void linear_t_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ wT, long long ldw,
                                                        const float* __restrict__ bias, const float* __restrict__ res, long long ldr,
                                                        const float* __restrict__ gscale, float* __restrict__ out, long long ldo, int R, int K,
-                                                       int N, int act_in, int act_out) {
+                                                       int N, int act_in, int act_out, long long x_hs, long long w_hs, long long b_hs,
+                                                       long long o_hs) {
+    // blockIdx.z = head of a per-head batch (idiff_linear_t_heads_fwd): operands advance by their head strides
+    x += blockIdx.z * x_hs;
+    wT += blockIdx.z * w_hs;
+    if (bias) bias += blockIdx.z * b_hs;
+    out += blockIdx.z * o_hs;
     extern __shared__ __attribute__((aligned(16))) float lt_smem[];
     float* xs = lt_smem;                                             // [LT_ROWS][K] activated input rows
     float(*red)[LT_ROWS][64] = reinterpret_cast<float(*)[LT_ROWS][64]>(lt_smem + LT_ROWS * K);  // [4][8][64]
@@ -276,13 +282,13 @@ extern "C" int idiff_smm_memproj_compact_fwd(const float* feat, int64_t feat_bst
     return memproj_launch(feat, feat_bstride, ln1_g, ln1_b, wpk, bias, nullptr, nullptr, out, B, C, N, eps, Cm, stream);
 }
 
-extern "C" int idiff_linear_t_fwd(const float* x, int64_t ldx, const float* wT, int64_t ldw, const float* bias, const float* res, int64_t ldr,
-                                  const float* gscale, float* out, int64_t ldo, int R, int K, int N, int act_in, int act_out,
-                                  idiff_stream_t stream) {
-    IDIFF_CHECK_ARG(x && wT && out && R > 0 && K > 0 && N > 0, "linear_t_fwd: bad args");
+static int linear_t_launch(const float* x, int64_t ldx, const float* wT, int64_t ldw, const float* bias, const float* res, int64_t ldr,
+                           const float* gscale, float* out, int64_t ldo, int R, int K, int N, int act_in, int act_out, int heads, int64_t x_hs,
+                           int64_t w_hs, int64_t b_hs, int64_t o_hs, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(x && wT && out && R > 0 && K > 0 && N > 0 && heads > 0, "linear_t_fwd: bad args");
     IDIFF_CHECK_ARG(ldx >= K && ldw >= N && ldo >= N, "linear_t_fwd: bad leading dims");
     IDIFF_CHECK_ARG(K <= 8192, "linear_t_fwd: K must be <= 8192 (got %d)", K);
-    dim3 grid((N + 63) / 64, (R + LT_ROWS - 1) / LT_ROWS);
+    dim3 grid((N + 63) / 64, (R + LT_ROWS - 1) / LT_ROWS, heads);
     const size_t lds = ((size_t)LT_ROWS * K + 4 * LT_ROWS * 64) * sizeof(float);
     static size_t attr = 0;
     if (lds > 64 * 1024 && lds > attr) {
@@ -291,7 +297,21 @@ extern "C" int idiff_linear_t_fwd(const float* x, int64_t ldx, const float* wT, 
         attr = lds;
     }
     hipLaunchKernelGGL(linear_t_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, (long long)ldx, wT, (long long)ldw, bias, res,
-                       (long long)ldr, gscale, out, (long long)ldo, R, K, N, act_in, act_out);
+                       (long long)ldr, gscale, out, (long long)ldo, R, K, N, act_in, act_out, (long long)x_hs, (long long)w_hs, (long long)b_hs,
+                       (long long)o_hs);
     IDIFF_CHECK_LAUNCH("linear_t_fwd");
     return IDIFF_OK;
+}
+
+extern "C" int idiff_linear_t_fwd(const float* x, int64_t ldx, const float* wT, int64_t ldw, const float* bias, const float* res, int64_t ldr,
+                                  const float* gscale, float* out, int64_t ldo, int R, int K, int N, int act_in, int act_out,
+                                  idiff_stream_t stream) {
+    return linear_t_launch(x, ldx, wT, ldw, bias, res, ldr, gscale, out, ldo, R, K, N, act_in, act_out, 1, 0, 0, 0, 0, stream);
+}
+
+extern "C" int idiff_linear_t_heads_fwd(const float* x, int64_t ldx, int64_t x_hs, const float* wT, int64_t ldw, int64_t w_hs, const float* bias,
+                                        int64_t b_hs, float* out, int64_t ldo, int64_t o_hs, int R, int K, int N, int heads,
+                                        idiff_stream_t stream) {
+    return linear_t_launch(x, ldx, wT, ldw, bias, nullptr, 0, nullptr, out, ldo, R, K, N, IDIFF_ACT_NONE, IDIFF_ACT_NONE, heads, x_hs, w_hs, b_hs,
+                           o_hs, stream);
 }

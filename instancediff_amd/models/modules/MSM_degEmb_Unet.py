@@ -206,14 +206,13 @@ class ScoreMapModule(nn.Module):
                                           lambda: _fold_memory_affine(mp[1], mp[2], ca, Cm))
             else:
                 wkf, wvf, bvf = ca.k_proj.weight, wT(ca.v_proj), None  # [Wd(dh blocks), Wd], [Wd (c), Wd (n)]
+            # per head: qf[:, h-block] = qc[:, h-block] @ wkf[h row block]  ([dh, Cm]);  one launch for all heads
             qf = torch.empty((B * K, heads * Cm), device=feat.device, dtype=torch.float32)
-            for h in range(heads):
-                ops.linear_t(qc[:, h * dh:(h + 1) * dh], wkf[h * dh:(h + 1) * dh], out=qf[:, h * Cm:(h + 1) * Cm])
+            ops.linear_t_heads(qc, wkf, None, qf, heads, dh, Cm, x_hs=dh, w_hs=dh * wkf.stride(0), b_hs=0, o_hs=Cm)
             o = ops.smm_xattn(qf.reshape(B, K, heads, Cm), mem, ca.scale).reshape(B * K, heads * Cm)
+            # per head: av[:, h-block] = o[:, h-block] @ wvf[:, h column block] (+ bvf[h-block])  ([Cm, dh])
             av = torch.empty((B * K, Wd), device=feat.device, dtype=torch.float32)
-            for h in range(heads):
-                ops.linear_t(o[:, h * Cm:(h + 1) * Cm], wvf[:, h * dh:(h + 1) * dh], None if bvf is None else bvf[h * dh:(h + 1) * dh],
-                             out=av[:, h * dh:(h + 1) * dh])
+            ops.linear_t_heads(o, wvf, bvf, av, heads, Cm, dh, x_hs=Cm, w_hs=dh, b_hs=dh, o_hs=dh)
             x = ops.linear_t(av, wT(ca.proj), ca.proj.bias, res=x)
             n3 = ops.layernorm_rows(x, layer.norm3.weight, layer.norm3.bias)
             hm = ops.linear_t(n3, wT(layer.mlp[0]), layer.mlp[0].bias, act_out=ops.ACT_GELU)

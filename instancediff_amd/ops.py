@@ -200,6 +200,20 @@ def linear_t(x, wT, bias=None, res=None, gscale=None, act_in=ACT_NONE, act_out=A
     return out
 
 
+def linear_t_heads(x, wT, bias, out, heads, K, N, x_hs, w_hs, b_hs, o_hs):
+    """heads independent [R,K] x [K,N] products in one launch: head h reads x[:, h*x_hs : h*x_hs+K], the [K,N] block of wT
+    starting w_hs elements further per head, bias[h*b_hs : h*b_hs+N], and writes out[:, h*o_hs : h*o_hs+N]."""
+    lib = _lib.load()
+    _chk(x, "x"), _chk(wT, "wT"), _chk(out, "out")
+    assert x.dim() == 2 and wT.dim() == 2 and out.dim() == 2 and x.stride(1) == 1 and wT.stride(1) == 1 and out.stride(1) == 1
+    R = x.shape[0]
+    assert out.shape[0] == R and (heads - 1) * x_hs + K <= x.shape[1] and (heads - 1) * o_hs + N <= out.shape[1]
+    assert (heads - 1) * w_hs + (K - 1) * wT.stride(0) + N <= wT.numel()
+    check(lib.idiff_linear_t_heads_fwd(_p(x), x.stride(0), x_hs, _p(wT), wT.stride(0), w_hs, _p(_c(bias)), b_hs, _p(out), out.stride(0), o_hs,
+                                       R, K, N, heads, _stream()), "linear_t_heads_fwd")
+    return out
+
+
 def smm_memproj(feat, ln1_g, ln1_b, wpk, bias, ln2_g, ln2_b, eps=1e-5):
     """feat [B,C,H,W] -> mem [B,256,H*W] = LN(Linear(LN(tokens)))"""
     lib = _lib.load()

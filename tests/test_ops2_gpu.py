@@ -145,3 +145,21 @@ def test_smm_compact_memory_equals_full_memory_attention(C, Cm, H, W):
     for h in range(heads):
         ops.linear_t(o[:, h * Cm:(h + 1) * Cm], wvf[:, h * dh:(h + 1) * dh], bvf[h * dh:(h + 1) * dh], out=av[:, h * dh:(h + 1) * dh])
     _close(av, ref, 2e-5, "compact-memory cross attention")
+
+
+def test_linear_t_heads_matches_per_head_calls():
+    g = torch.Generator().manual_seed(33)
+    R, heads, dh, Cm = 13, 4, 64, 96
+    qc = torch.randn(R, heads * dh, generator=g).to(DEV)
+    wkf = torch.randn(heads * dh, Cm, generator=g).to(DEV)          # row blocks = per-head [dh, Cm]
+    wvf = torch.randn(Cm, heads * dh, generator=g).to(DEV)          # column blocks = per-head [Cm, dh]
+    bvf = torch.randn(heads * dh, generator=g).to(DEV)
+    qf = torch.empty(R, heads * Cm, device=DEV)
+    ops.linear_t_heads(qc, wkf, None, qf, heads, dh, Cm, x_hs=dh, w_hs=dh * wkf.stride(0), b_hs=0, o_hs=Cm)
+    av = torch.empty(R, heads * dh, device=DEV)
+    ops.linear_t_heads(qf, wvf, bvf, av, heads, Cm, dh, x_hs=Cm, w_hs=dh, b_hs=dh, o_hs=dh)
+    for h in range(heads):
+        ref_q = qc[:, h * dh:(h + 1) * dh].double() @ wkf[h * dh:(h + 1) * dh].double()
+        _close(qf[:, h * Cm:(h + 1) * Cm], ref_q, 3e-6, f"head {h} query fold")
+        ref_v = qf[:, h * Cm:(h + 1) * Cm].double() @ wvf[:, h * dh:(h + 1) * dh].double() + bvf[h * dh:(h + 1) * dh].double()
+        _close(av[:, h * dh:(h + 1) * dh], ref_v, 3e-6, f"head {h} value fold")
