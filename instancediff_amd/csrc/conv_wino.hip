@@ -81,9 +81,9 @@ __device__ __forceinline__ float row_sum16(float v) {
 
 // SPEC: 1 = single source, no prologue; 2 = single source + GN/FiLM/SiLU prologue; 3 = two sources (virtual concat)
 //
-// Persistent: the grid is one workgroup per CU (the 155 KB of LDS allow one anyway); workgroup w walks the contiguous
-// item range [w*per, (w+1)*per) of (sample, patch, channel-block) items, channel block fastest, so the blocks of one
-// patch reuse its input from L2.  The first global loads of item i+1 are issued before the epilogue of item i.
+// Persistent: the grid is one workgroup per CU (the 156 KB of LDS allow one anyway); each walks a strided sequence
+// of (sample, patch, channel-block) items, channel block fastest.  The first global loads of a workgroup's next item
+// are issued before the last chunk of the current one.
 template <int MODE, int SPEC>
 __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a, const int per TRACE_PARAM) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -229,8 +229,13 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a, const i
     };
     auto clampc = [&](int c) { return c < nchunks ? c : nchunks - 1; };
 
-    const int first = blockIdx.x * per;
-    const int last = first + per < (int)a.total_wg ? first + per : (int)a.total_wg;
+    // Item order: workgroup v (XCD-contiguous numbering) takes items v, v+G, v+2G, ...; neighbours on one XCD thus work
+    // on neighbouring items at the same time -- the channel blocks of one patch, then the next patch -- and share the
+    // patch (and its halo) through that XCD's L2 instead of each fetching it from HBM at a different time.
+    (void)per;
+    const int G = gridDim.x;
+    const int first = (int)xcd_remap(blockIdx.x, G);
+    const int last = (int)a.total_wg;
     if (first >= last) return;
     setup_item(first);
     load_raw(rin, 0);
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a, const i
     int protab_b = -1;
     TRACE_INIT
 
-    for (int item = first; item < last; ++item) {
+    for (int item = first; item < last; item += G) {
         const int b = it_b, tile = it_tile, co0 = it_co0, y0 = it_y0, x0 = it_x0;  // the epilogue's view of this item
         TRACE_MARK(0)
 
@@ -337,8 +342,8 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a, const i
         for (int cc = 0; cc + 1 < nchunks; ++cc) chunk(cc, std::true_type{});
         // Nothing is staged in the last chunk, so the item state is free: switch it to the next item now (scalar
         // work, hidden under the MFMAs) and let its first two patches and weights travel during the last chunk and the epilogue.
-        if (item + 1 < last) {
-            setup_item(item + 1);
+        if (item + G < last) {
+            setup_item(item + G);
             load_raw(rin, 0);
             load_raw(rin1, clampc(1));
             load_u(0);
