@@ -466,11 +466,7 @@ int launch(const ConvArgs& a, hipStream_t st) {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
             IDIFF_FAIL(IDIFF_E_HIP, "conv2d(winograd): cannot query the CU count");
-        // IDIFF_WINO_RESERVE_CUS=n leaves n CUs to whatever else is running (the persistent workgroups hold a CU's whole
-        // register file and LDS for the duration of the launch, so a second stream's small kernels otherwise wait it out)
-        const char* e = getenv("IDIFF_WINO_RESERVE_CUS");
-        const int reserve = e ? atoi(e) : 0;
-        num_cu = n - reserve > 8 ? n - reserve : n;
+        num_cu = n;
     }
     const int total = (int)a.total_wg;
     const int per = (total + num_cu - 1) / num_cu;          // items per workgroup (contiguous range)
