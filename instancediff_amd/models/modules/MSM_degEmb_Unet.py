@@ -13,6 +13,7 @@ include/idiff.h via instancediff_amd.ops.  There is no ATen fallback: on a machi
 library or without a GPU, forward() raises.
 """
 import math
+import os
 import weakref
 
 import torch
@@ -61,6 +62,11 @@ class _Prepared:
 
 
 _PREP = _Prepared()
+
+# IDIFF_SMM_SIDE_STREAM=1 moves each net's ScoreMapModules to a side stream.  Off by default: with the two nets already on
+# two streams it measured slower (40.1 vs 38.2 ms/step at c2: four streams contend for the CUs the persistent conv
+# workgroups hold); it only pays when the nets share one stream (41.6 vs 42.3 ms/step).
+SMM_SIDE_STREAM = bool(int(os.environ.get("IDIFF_SMM_SIDE_STREAM", "0")))
 
 
 def packed(conv):
@@ -420,6 +426,7 @@ class LearnableForwardUNet_MultiScoreMap(nn.Module):
         self.final_res = ResBlock(nf * 2, nf, time_dim, gn_groups)
         self.final_conv = nn.Conv2d(nf, out_nc, 3, padding=1)
         self._ctx_cache = None
+        self._side_stream = None
         self._idx_cache = {}
 
     # ---- helpers ---------------------------------------------------------------------------------
@@ -514,6 +521,13 @@ class LearnableForwardUNet_MultiScoreMap(nn.Module):
         x_ = x
         hs, sms = [], []
         use_sm = self.CLIP_ScoreMapModule is not None
+        # A level's ScoreMapModule only feeds the skip connection (and the returned score maps), so its latency-bound token
+        # chain runs on a side stream while the conv path goes on down the encoder; joined before the decoder reads a skip.
+        side = None
+        if use_sm and SMM_SIDE_STREAM and x.is_cuda:
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream()
+            side, cur = self._side_stream, torch.cuda.current_stream()
         for i, lv in enumerate(self.downs):
             din, dout, smc = self.level_dims[i]
             Hi, Wi = x.shape[2], x.shape[3]
@@ -530,9 +544,17 @@ class LearnableForwardUNet_MultiScoreMap(nn.Module):
             if general:
                 x = lv.ca2.run(x, ctx, out=xo)
             if use_sm:
-                score, sel = self.CLIP_ScoreMapModule[i](x, text_encoder, idx)
+                if side is not None:
+                    side.wait_stream(cur)  # x (= skip[:, :din]) is complete
+                    with torch.cuda.stream(side):
+                        score, sel = self.CLIP_ScoreMapModule[i](x, text_encoder, idx)
+                        ops.conv2d(score, packed(self.sm_embed[i]), self.sm_embed[i].bias, 3, smc, out=skip[:, din:])
+                    if sel is not None:
+                        sel.record_stream(cur)
+                else:
+                    score, sel = self.CLIP_ScoreMapModule[i](x, text_encoder, idx)
+                    ops.conv2d(score, packed(self.sm_embed[i]), self.sm_embed[i].bias, 3, smc, out=skip[:, din:])
                 sms.append(sel)
-                ops.conv2d(score, packed(self.sm_embed[i]), self.sm_embed[i].bias, 3, smc, out=skip[:, din:])
                 hs.append(skip)
             else:
                 hs.append(x)
@@ -542,6 +564,8 @@ class LearnableForwardUNet_MultiScoreMap(nn.Module):
         if general:
             x = self.mid_ca.run(x, ctx)
         x = self.mid_res2.run(x, None, films[id(self.mid_res2)])
+        if side is not None:
+            cur.wait_stream(side)  # the skips carry the score-map embeddings from here on
         for up in self.ups:
             x = up.res1.run(x, hs.pop(), films[id(up.res1)], vec=ca_vec("ca1", up))
             if general:
