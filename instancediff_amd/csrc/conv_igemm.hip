@@ -115,7 +115,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         econst[tid] = v;
     }
 
-    float rin[NL];
+    // flattened 1x1 tiles are 256 contiguous pixels per channel: stage them with 16-byte loads / LDS writes
+    constexpr bool VIN = KS == 1 && TWL == 8 && MODE == IDIFF_CONV_NORMAL;
+    constexpr int NL4 = VIN ? NL / 4 : 1;
+    float rin[VIN ? 1 : NL];
+    floatx4 rin4[NL4];
     floatx4 rwv[VECW ? NW : 1];
     float rws[VECW ? 1 : NW];
 
@@ -127,7 +131,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     auto load_regs = [&](int cc) {
         const int cb = cc * CK;
         const float* base0 = sample0 + (long long)(MODE == IDIFF_CONV_UNSHUFFLE2 ? (cb >> 2) : cb) * HWin;
-        if (two_src) {
+        if (VIN) {
+            const float* base1 = two_src ? a.src1 + (long long)b * a.bs1 + (long long)(cb - a.C0v) * HWin : base0;
+#pragma unroll
+            for (int i = 0; i < NL4; ++i) {
+                const int e4 = tid + i * 256;  // float4 index in [CK][64]
+                const int ci = e4 >> 6, j4 = (e4 & 63) * 4;
+                const int ch = cb + ci;
+                const float* p = ch < a.Cin ? ((two_src && ch >= a.C0v) ? base1 : base0) + (long long)ci * HWin + x0 + j4 : sample0;
+                rin4[i] = *reinterpret_cast<const floatx4*>(p);
+            }
+        } else if (two_src) {
             const float* base1 = a.src1 + (long long)b * a.bs1 + (long long)(cb - a.C0v) * HWin;
 #pragma unroll
             for (int i = 0; i < NL; ++i) {
@@ -180,8 +194,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         const int cb = cc * CK;
         float* ib = smem + buf * BUF;
         float* wb = ib + IN_TILE;
+        if (VIN) {
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
+            for (int i = 0; i < NL4; ++i) {
+                const int e4 = tid + i * 256;
+                const int ch = cb + (e4 >> 6);
+                floatx4 x = rin4[i];
+                if (has_pro) {
+                    const int chc = ch < a.C0r ? ch : 0;
+                    const float pa = protab[chc], pb = protab[a.C0r + chc];
+                    x = floatx4{silu_fast(pa * x.x + pb), silu_fast(pa * x.y + pb), silu_fast(pa * x.z + pb), silu_fast(pa * x.w + pb)};
+                }
+                if (!(ch < a.Cin)) x = floatx4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<floatx4*>(ib + e4 * 4) = x;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < (VIN ? 0 : NL); ++i) {
             const int e = tid + i * 256;
             const int ch = cb + e / PS;
             const bool v = gval[i] && ch < a.Cin;
@@ -423,7 +452,8 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
 template <int KS, int CK, int MODE, int MB>
 int dispatch_tw(const ConvArgs& a, int twl, bool vecw, hipStream_t st) {
     if (twl == 8) {  // flattened 1x1: 256 consecutive pixels per tile (set up by idiff_conv2d_fwd, KS == 1 only)
-        if (KS == 1 && MODE == IDIFF_CONV_NORMAL && MB == 2 && vecw) {
+        if constexpr (KS == 1 && MODE == IDIFF_CONV_NORMAL && MB == 2) {
+            if (!vecw) IDIFF_FAIL(IDIFF_E_UNSUPPORTED, "conv2d: internal: flattened tile needs vector weights");
             if (a.pro_a) return launch_conv<1, CK, 8, IDIFF_CONV_NORMAL, true, 2, 2>(a, st);
             if (a.src1) return launch_conv<1, CK, 8, IDIFF_CONV_NORMAL, true, 2, 3>(a, st);
             return launch_conv<1, CK, 8, IDIFF_CONV_NORMAL, true, 2, 1>(a, st);
@@ -541,7 +571,9 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
     // A 1x1 conv has no halo, so its pixel tile may be any 256 pixels: flatten the image to one row and take 256
     // consecutive pixels per tile -- 1 KB contiguous per input channel instead of 8 rows of 128 B (HBM-bound layers).
     // Not when GroupNorm partials are requested: their layout is per 8x32 patch (idiff_conv2d_num_tiles).
-    if (d->ks == 1 && d->mode == IDIFF_CONV_NORMAL && !a.stats && mb == 2 && vecw && ((long long)a.Hout * a.Wout) % 256 == 0 &&
+    const bool in16 = (reinterpret_cast<uintptr_t>(a.src0) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.src1) & 15) == 0 && a.bs0 % 4 == 0 &&
+                      (!a.src1 || a.bs1 % 4 == 0);
+    if (d->ks == 1 && d->mode == IDIFF_CONV_NORMAL && !a.stats && mb == 2 && vecw && in16 && ((long long)a.Hout * a.Wout) % 256 == 0 &&
         a.Wout >= 32) {
         a.Win = a.Wout = a.Hout * a.Wout;
         a.Hin = a.Hout = 1;
