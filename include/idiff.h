@@ -233,6 +233,9 @@ int idiff_mix3_per_sample(const float* x0, const float* cond, const float* eps, 
 int64_t idiff_conv2d_wgrad_ws_floats(const idiff_conv_desc* d);
 int idiff_conv2d_wgrad(const idiff_conv_desc* d, const float* dy, int64_t dy_bstride, float* dw, int accumulate, float* ws,
                        idiff_stream_t stream);
+/* IDIFF_CONV_ALGO_* of the calling thread's last idiff_conv2d_wgrad: the Winograd form (conv_wino_wgrad.hip) takes 3x3
+ * layers with Cout % 64 == 0, Cin % 16 == 0 (C0 % 64 == 0 with a second source), Hout % 2 == 0, Wout % 16 == 0 */
+int idiff_conv2d_wgrad_last_algo(void);
 /* data-gradient helpers: the data gradient itself is idiff_conv2d_fwd on dy with idiff_pack_conv_weight_T weights */
 int idiff_sumpool2x2(const float* x, float* out, int64_t planes, int h, int w, idiff_stream_t stream);     /* upsample^T   */
 int idiff_pixel_shuffle2(const float* x, float* out, int B, int C, int h, int w, idiff_stream_t stream);    /* unshuffle^T  */

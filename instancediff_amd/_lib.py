@@ -72,6 +72,7 @@ SIGNATURES = {
     # ---- training path ----
     "idiff_conv2d_wgrad_ws_floats": (I64, [C.POINTER(ConvDesc)]),
     "idiff_conv2d_wgrad": (I, [C.POINTER(ConvDesc), P, I64, P, I, P, c_stream]),
+    "idiff_conv2d_wgrad_last_algo": (I, []),
     "idiff_sumpool2x2": (I, [P, P, I64, I, I, c_stream]),
     "idiff_pixel_shuffle2": (I, [P, P, I, I, I, I, c_stream]),
     "idiff_plane_sum": (I, [P, I64, P, I, I, I, c_stream]),

@@ -9,7 +9,7 @@
 //   padding), so the same fused forward needs no materialised im2col / activated tensor for its backward.
 //   Results go to a per-split partial buffer (plain coalesced stores, co fastest); a second kernel reduces the
 //   splits in a fixed order and writes torch layout [co][ci][ky][kx] -> bitwise reproducible (no atomics).
-#include "common.h"
+#include "conv_wgrad_args.h"
 
 namespace {
 
@@ -216,6 +216,9 @@ int launch_wg(const WgArgs& a, int twl, hipStream_t st) {
 
 }  // namespace
 
+static thread_local int g_last_wgrad_algo = IDIFF_CONV_ALGO_DIRECT;
+extern "C" int idiff_conv2d_wgrad_last_algo(void) { return g_last_wgrad_algo; }
+
 extern "C" int64_t idiff_conv2d_wgrad_ws_floats(const idiff_conv_desc* d) {
     if (!d) return -1;
     const int Cin = (d->mode == IDIFF_CONV_UNSHUFFLE2 ? d->C0 * 4 : d->C0) + d->C1;
@@ -223,6 +226,11 @@ extern "C" int64_t idiff_conv2d_wgrad_ws_floats(const idiff_conv_desc* d) {
     const int Wout = d->mode == IDIFF_CONV_UPSAMPLE2 ? d->Win * 2 : (d->mode == IDIFF_CONV_UNSHUFFLE2 ? d->Win / 2 : d->Win);
     int ck, nch, ncob, nt, tx, ns;
     wg_geometry(d->ks, Cin, d->Cout, d->B, Hout, Wout, &ck, &nch, &ncob, &nt, &tx, &ns);
+    if (d->ks == 3 && d->Cout % 64 == 0) {  // the Winograd kernel may take this shape with its own split count
+        int wcob, wcib, wns;
+        idiff_detail::wino_wgrad_geometry(Cin, d->Cout, d->B, Hout, Wout, &wcob, &wcib, &wns);
+        if (wns > ns) ns = wns;
+    }
     return (int64_t)ns * d->ks * d->ks * Cin * d->Cout;
 }
 
@@ -272,7 +280,18 @@ extern "C" int idiff_conv2d_wgrad(const idiff_conv_desc* d, const float* dy, int
     const int twl = wg_pick_twl(a.Wout);
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (d->ks == 3) {
+    idiff_detail::WwArgs w;
+    w.src0 = a.src0, w.src1 = a.src1, w.bs0 = a.bs0, w.bs1 = a.bs1;
+    w.C0v = a.C0v, w.C1v = a.C1v, w.C0r = a.C0r, w.Cin = a.Cin;
+    w.B = a.B, w.Hin = a.Hin, w.Win = a.Win, w.Hout = a.Hout, w.Wout = a.Wout, w.Cout = a.Cout;
+    w.pro_a = a.pro_a, w.pro_b = a.pro_b, w.dy = a.dy, w.dybs = a.dybs, w.ws = a.ws;
+    g_last_wgrad_algo = IDIFF_CONV_ALGO_DIRECT;
+    if (idiff_detail::wino_wgrad_eligible(w, d->ks, d->mode)) {
+        g_last_wgrad_algo = IDIFF_CONV_ALGO_WINOGRAD;
+        idiff_detail::wino_wgrad_geometry(w.Cin, w.Cout, w.B, w.Hout, w.Wout, &w.ncob, &w.ncib, &w.nsplit);
+        a.nsplit = w.nsplit;  // for the reduction below
+        rc = idiff_detail::launch_wino_wgrad(w, d->mode, st);
+    } else if (d->ks == 3) {
         IDIFF_CHECK_ARG(d->mode != IDIFF_CONV_UNSHUFFLE2, "conv2d_wgrad: unshuffle needs ks=1");
         rc = d->mode == IDIFF_CONV_NORMAL ? launch_wg<3, 16, IDIFF_CONV_NORMAL>(a, twl, st) : launch_wg<3, 16, IDIFF_CONV_UPSAMPLE2>(a, twl, st);
     } else if (d->ks == 1) {

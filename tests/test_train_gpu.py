@@ -287,3 +287,40 @@ def test_unet_param_gradients_and_train_steps_vs_oracle():
     with torch.no_grad():
         p_ref = rd.eval()(x_t - batch['input'], batch['input'], t.reshape(-1), batch['names'], te, image_context=batch['A_emb'])[0]
     assert _rel(p_inf, p_ref) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------
+# Winograd weight gradient (conv_wino_wgrad.hip): every eligible gather variant against fp64 autograd
+@pytest.mark.parametrize("B,C0,C1,Cout,H,W,variant", [
+    (2, 64, 0, 64, 16, 16, "plain"),
+    (3, 80, 0, 128, 8, 48, "plain"),          # partial last 64-channel block, several samples per split
+    (2, 64, 80, 64, 32, 32, "concat"),        # second source starts on a 64-channel block boundary
+    (2, 32, 0, 64, 16, 32, "prologue"),
+    (2, 32, 0, 64, 8, 16, "upsample"),        # out 16x32
+    (1, 16, 0, 64, 2, 16, "plain"),           # a single chunk: every edge at once
+])
+def test_conv_wgrad_winograd_vs_fp64(B, C0, C1, Cout, H, W, variant):
+    g = _g(41)
+    Cin = C0 + C1
+    x0 = torch.randn(B, C0, H, W, generator=g)
+    x1 = torch.randn(B, C1, H, W, generator=g) if C1 else None
+    xin = x0.double() if x1 is None else torch.cat([x0, x1], 1).double()
+    pro, mode = None, ops.CONV_NORMAL
+    if variant == "prologue":
+        pa, pb = torch.randn(B, C0, generator=g), torch.randn(B, C0, generator=g)
+        xin = xin * pa.double()[:, :, None, None] + pb.double()[:, :, None, None]
+        xin = xin / (1 + torch.exp(-xin))
+        pro = (pa.to(DEV), pb.to(DEV))
+    if variant == "upsample":
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+        mode = ops.CONV_UPSAMPLE2
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(xin, w, None, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    dw = T.conv2d_wgrad(x0.to(DEV), None if x1 is None else x1.to(DEV), mode, 3, dy.to(DEV), Cin, pro=pro)
+    assert ops._lib.load().idiff_conv2d_wgrad_last_algo() == 1, "the Winograd weight-gradient kernel did not run"
+    assert _rel(dw, w.grad) < 1e-5, "winograd wgrad"
+    # accumulate form
+    dw2 = T.conv2d_wgrad(x0.to(DEV), None if x1 is None else x1.to(DEV), mode, 3, dy.to(DEV), Cin, pro=pro, dw=dw.clone(), accumulate=True)
+    assert _rel(dw2, 2 * w.grad) < 1e-5
