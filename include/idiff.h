@@ -83,6 +83,7 @@ int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream);
 /* which kernel the calling thread's last idiff_conv2d_fwd launched (profiling / tests) */
 #define IDIFF_CONV_ALGO_DIRECT 0   /* implicit GEMM, conv_igemm.hip  */
 #define IDIFF_CONV_ALGO_WINOGRAD 1 /* F(2x2,3x3),   conv_wino.hip   */
+#define IDIFF_CONV_ALGO_STREAM1X1 2 /* weight gradient only: streaming 1x1 product */
 int idiff_conv2d_last_algo(void);
 /* w [Cout][Cin][ks][ks] (torch layout) -> wpk [ks*ks][Cin][Cout] */
 int idiff_pack_conv_weight(const float* w, float* wpk, int Cout, int Cin, int ks, idiff_stream_t stream);

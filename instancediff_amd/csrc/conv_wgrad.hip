@@ -155,6 +155,114 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 1x1 weight gradient as a streaming NT product:  dW[co][ci] = sum_{b,p} dY[b,co,p] * X[b,ci,p]   (plain gather:
+// NORMAL mode, no prologue).  HBM-bound (two reads per multiply-add pair of rows), so the kernel is organised around
+// wide loads: a workgroup owns a 64 co x 64 ci block and a contiguous share of the (sample, 128-pixel run) list; each run
+// is fetched with 16-byte loads one unit ahead (register-staged), written to LDS as [row][128 + 4] (the +4 keeps rows
+// 16-byte aligned and makes both MFMA operand reads bank-conflict free), and multiplied on v_mfma_f32_16x16x4_f32 with
+// the pixels as the K dimension.  Two workgroups per CU keep ~128 KB of loads in flight per CU.
+constexpr int W1_PX = 128, W1_LD = W1_PX + 4;
+__global__ __launch_bounds__(256) void wgrad1x1_kernel(const WgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const xt = smem;                 // [64 ci][W1_LD]
+    float* const dyt = smem + 64 * W1_LD;   // [64 co][W1_LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int cob = blockIdx.x % a.ncob;
+    const int cib = (blockIdx.x / a.ncob) % a.nchunks;   // nchunks = 64-channel input blocks here
+    const int sp = blockIdx.x / (a.ncob * a.nchunks);
+    const int co0 = cob * 64, ci0 = cib * 64;
+    const int HW = a.Hout * a.Wout;
+    const int runs = HW / W1_PX;                          // per sample
+    const int total = a.B * runs;
+    const int per = (total + a.nsplit - 1) / a.nsplit;
+    const int u_begin = sp * per, u_end = u_begin + per < total ? u_begin + per : total;
+    // the block's 64 input channels come from one source (C0 % 64 == 0 when there are two)
+    const bool from1 = a.src1 != nullptr && ci0 >= a.C0v;
+    const float* const srcb = from1 ? a.src1 : a.src0;
+    const long long sbs = from1 ? a.bs1 : a.bs0;
+    const int chan0 = from1 ? ci0 - a.C0v : ci0;
+    const int nci = a.Cin - ci0 < 64 ? a.Cin - ci0 : 64;  // valid rows of this block
+
+    // staging map: 64 rows x 32 float4 = 2048 float4 per operand, 8 per thread; row = f >> 5, float4 column = f & 31
+    floatx4 rx[8], ry[8];
+    auto load_unit = [&](int u) {
+        const int b = u / runs, p0 = (u - b * runs) * W1_PX;
+        const float* xb = srcb + (long long)b * sbs + (long long)chan0 * HW + p0;
+        const float* yb = a.dy + (long long)b * a.dybs + (long long)co0 * HW + p0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = tid + i * 256;
+            const int row = f >> 5, c4 = (f & 31) * 4;
+            rx[i] = row < nci ? *reinterpret_cast<const floatx4*>(xb + (long long)row * HW + c4) : floatx4{0.f, 0.f, 0.f, 0.f};
+            ry[i] = *reinterpret_cast<const floatx4*>(yb + (long long)row * HW + c4);
+        }
+    };
+    auto store_unit = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = tid + i * 256;
+            const int row = f >> 5, c4 = (f & 31) * 4;
+            *reinterpret_cast<floatx4*>(xt + row * W1_LD + c4) = rx[i];
+            *reinterpret_cast<floatx4*>(dyt + row * W1_LD + c4) = ry[i];
+        }
+    };
+    // wave (wm, wn) owns 32 co x 32 ci = 2 x 2 blocks of 16 x 16
+    const int wm = wave & 1, wn = wave >> 1;
+    floatx4 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const float* ar = dyt + (wm * 32 + l15) * W1_LD + kq;
+    const float* br = xt + (wn * 32 + l15) * W1_LD + kq;
+    if (u_begin < u_end) load_unit(u_begin);
+    for (int u = u_begin; u < u_end; ++u) {
+        __syncthreads();  // the previous unit's operand reads are done
+        store_unit();
+        __syncthreads();
+        if (u + 1 < u_end) load_unit(u + 1);  // in flight during the MFMAs below
+#pragma unroll 8
+        for (int s = 0; s < W1_PX / 4; ++s) {
+            const float a0 = ar[4 * s], a1 = ar[16 * W1_LD + 4 * s];
+            const float b0 = br[4 * s], b1 = br[16 * W1_LD + 4 * s];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    // C layout: lane holds column l15 (ci) and rows 4*kq + r (co): ws[sp][0][ci][co], co fastest -> float4 stores
+    float* const wsp = a.ws + (long long)sp * a.Cin * a.Cout;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int ci = ci0 + wn * 32 + n * 16 + l15;
+        if (ci < a.Cin) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) *reinterpret_cast<floatx4*>(wsp + (long long)ci * a.Cout + co0 + wm * 32 + m * 16 + 4 * kq) = acc[m][n];
+        }
+    }
+}
+
+inline bool wgrad1x1_eligible(const WgArgs& a, int ks, int mode) {
+    if (ks != 1 || mode != IDIFF_CONV_NORMAL || a.pro_a) return false;
+    if (a.Cout % 64 || ((long long)a.Hout * a.Wout) % W1_PX) return false;
+    if (a.src1 && a.C0v % 64) return false;
+    if ((reinterpret_cast<uintptr_t>(a.src0) & 15) || (reinterpret_cast<uintptr_t>(a.src1) & 15) || (reinterpret_cast<uintptr_t>(a.dy) & 15)) return false;
+    if (a.bs0 % 4 || (a.src1 && a.bs1 % 4) || a.dybs % 4) return false;
+    return true;
+}
+inline void wgrad1x1_geometry(int Cin, int Cout, int B, int HW, int* ncob, int* ncib, int* nsplit) {
+    *ncob = Cout / 64;
+    *ncib = (Cin + 63) / 64;
+    const int total = B * (HW / W1_PX);
+    int s = 1024 / (*ncob * *ncib);  // ~2 resident workgroups per CU, two rounds
+    if (s < 1) s = 1;
+    if (s > total) s = total;
+    *nsplit = s;
+}
+
 // dW[co][ci][tap] (+)= sum_s ws[s][tap][ci][co]   (fixed order -> deterministic)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int taps, int Cin, int Cout, int accumulate) {
     const long long n = (long long)taps * Cin * Cout;
@@ -226,6 +334,11 @@ extern "C" int64_t idiff_conv2d_wgrad_ws_floats(const idiff_conv_desc* d) {
     const int Wout = d->mode == IDIFF_CONV_UPSAMPLE2 ? d->Win * 2 : (d->mode == IDIFF_CONV_UNSHUFFLE2 ? d->Win / 2 : d->Win);
     int ck, nch, ncob, nt, tx, ns;
     wg_geometry(d->ks, Cin, d->Cout, d->B, Hout, Wout, &ck, &nch, &ncob, &nt, &tx, &ns);
+    if (d->ks == 1 && d->Cout % 64 == 0 && ((long long)Hout * Wout) % W1_PX == 0) {  // the streaming 1x1 kernel's split count
+        int wcob, wcib, wns;
+        wgrad1x1_geometry(Cin, d->Cout, d->B, Hout * Wout, &wcob, &wcib, &wns);
+        if (wns > ns) ns = wns;
+    }
     if (d->ks == 3 && d->Cout % 64 == 0) {  // the Winograd kernel may take this shape with its own split count
         int wcob, wcib, wns;
         idiff_detail::wino_wgrad_geometry(Cin, d->Cout, d->B, Hout, Wout, &wcob, &wcib, &wns);
@@ -291,6 +404,20 @@ extern "C" int idiff_conv2d_wgrad(const idiff_conv_desc* d, const float* dy, int
         idiff_detail::wino_wgrad_geometry(w.Cin, w.Cout, w.B, w.Hout, w.Wout, &w.ncob, &w.ncib, &w.nsplit);
         a.nsplit = w.nsplit;  // for the reduction below
         rc = idiff_detail::launch_wino_wgrad(w, d->mode, st);
+    } else if (wgrad1x1_eligible(a, d->ks, d->mode)) {
+        g_last_wgrad_algo = IDIFF_CONV_ALGO_STREAM1X1;
+        wgrad1x1_geometry(a.Cin, a.Cout, a.B, a.Hout * a.Wout, &a.ncob, &a.nchunks, &a.nsplit);
+        const size_t lds = (size_t)2 * 64 * W1_LD * sizeof(float);
+        static bool attr = false;
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad1x1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "conv2d_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr = true;
+        }
+        hipLaunchKernelGGL(wgrad1x1_kernel, dim3(a.ncob * a.nchunks * a.nsplit), dim3(256), lds, st, a);
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "conv2d_wgrad(1x1): %s", hipGetErrorString(le));
+        rc = IDIFF_OK;
     } else if (d->ks == 3) {
         IDIFF_CHECK_ARG(d->mode != IDIFF_CONV_UNSHUFFLE2, "conv2d_wgrad: unshuffle needs ks=1");
         rc = d->mode == IDIFF_CONV_NORMAL ? launch_wg<3, 16, IDIFF_CONV_NORMAL>(a, twl, st) : launch_wg<3, 16, IDIFF_CONV_UPSAMPLE2>(a, twl, st);

@@ -324,3 +324,17 @@ def test_conv_wgrad_winograd_vs_fp64(B, C0, C1, Cout, H, W, variant):
     # accumulate form
     dw2 = T.conv2d_wgrad(x0.to(DEV), None if x1 is None else x1.to(DEV), mode, 3, dy.to(DEV), Cin, pro=pro, dw=dw.clone(), accumulate=True)
     assert _rel(dw2, 2 * w.grad) < 1e-5
+
+
+@pytest.mark.parametrize("B,C0,C1,Cout,H,W", [(2, 64, 80, 64, 16, 16), (3, 128, 0, 128, 8, 16), (1, 48, 0, 64, 16, 32), (2, 256, 0, 192, 16, 8)])
+def test_conv_wgrad_streaming_1x1_vs_fp64(B, C0, C1, Cout, H, W):
+    g = _g(42)
+    Cin = C0 + C1
+    x0 = torch.randn(B, C0, H, W, generator=g)
+    x1 = torch.randn(B, C1, H, W, generator=g) if C1 else None
+    xin = x0.double() if x1 is None else torch.cat([x0, x1], 1).double()
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    ref = torch.einsum("bohw,bihw->oi", dy.double(), xin).reshape(Cout, Cin, 1, 1)
+    dw = T.conv2d_wgrad(x0.to(DEV), None if x1 is None else x1.to(DEV), ops.CONV_NORMAL, 1, dy.to(DEV), Cin)
+    assert ops._lib.load().idiff_conv2d_wgrad_last_algo() == 2, "the streaming 1x1 weight-gradient kernel did not run"
+    assert _rel(dw, ref) < 5e-6
