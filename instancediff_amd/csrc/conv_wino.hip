@@ -91,7 +91,7 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a, const i
     float* const Vb = smem + 2 * R_FLOATS;
     float* const Ub = Vb + 2 * V_FLOATS;
     float* const econst = Ub + 2 * U_FLOATS;  // [4][64] bias, vec, aux_a, aux_b of the item's 64 output channels
-    float* const protab = econst + 256;       // [2][C0r] (SPEC 2)
+    float* const protab = econst + 256;       // [2 item parities][2][C0r] (SPEC 2)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -150,6 +150,7 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a, const i
     const int ustride_b = a.ncob * U_FLOATS * 4;  // bytes between chunks of one channel block (whole U < 2^31 bytes)
 
     float rin[NL], rin1[NL];
+    const float* ptab = protab;  // this item's prologue table (parity buffer)
     floatx4 ru[NU];
 
     // ---- the pieces of one chunk's staging work; the main loop deals them out between the MFMA groups ------------
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a, const i
         if (SPEC == 2) {
             const int cil = (tid + i * NT) / PSP;
             const int chc = cc * CK + (cil < CK ? cil : 0);
-            x = silu_fast(protab[chc] * x + protab[a.C0r + chc]);
+            x = silu_fast(ptab[chc] * x + ptab[a.C0r + chc]);
         }
         Rb[rbuf * R_FLOATS + tid + i * NT] = (SPEC == 2 && goff[i] < 0) ? 0.f : x;  // padding is zero AFTER the activation
     };
@@ -237,11 +238,28 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a, const i
     const int first = (int)xcd_remap(blockIdx.x, G);
     const int last = (int)a.total_wg;
     if (first >= last) return;
+    // Per-item constants (epilogue table: bias, vec, aux affine of the 64 output channels; prologue table: the sample's
+    // GroupNorm/FiLM affine) are fetched one item ahead into one register each and land in LDS without anybody waiting
+    // on a global load: the prologue table is double-buffered by item parity and written during the previous epilogue.
+    float pre_e = 0.f, pre_p = 0.f;
+    auto fetch_consts = [&]() {  // for the item setup_item() just selected
+        if (tid < 256) {
+            const int which = tid >> 6, co = it_co0 + (tid & 63);
+            pre_e = 0.f;
+            if (which == 0 && a.bias) pre_e = a.bias[co];
+            if (which == 1 && a.vec) pre_e = a.vec[(long long)it_b * a.Cout + co];
+            if (which == 2 && a.aux) pre_e = a.aux_a[(long long)it_b * a.Cout + co];
+            if (which == 3 && a.aux) pre_e = a.aux_b[(long long)it_b * a.Cout + co];
+        }
+        if (SPEC == 2 && tid < 2 * a.C0r) pre_p = (tid < a.C0r ? a.pro_a : a.pro_b - a.C0r)[(long long)it_b * a.C0r + tid];
+    };
     setup_item(first);
     load_raw(rin, 0);
     load_raw(rin1, clampc(1));
     load_u(0);
-    int protab_b = -1;
+    fetch_consts();
+    if (SPEC == 2 && tid < 2 * a.C0r) protab[tid] = pre_p;  // parity 0; visible after the first item's top barrier
+    int parity = 0;
     TRACE_INIT
 
     for (int item = first; item < last; item += G) {
@@ -250,24 +268,9 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a, const i
 
         // ---- pipeline fill: V[0], U[0] hold chunk 0, R[1] chunk 1; raw(2) and U(1) are in registers ------------------
         __syncthreads();  // every wave is done with the previous item's LDS (last chunk's operands, stats scratch)
-        if (SPEC == 2 && protab_b != b) {
-            for (int i = tid; i < a.C0r; i += NT) {
-                protab[i] = a.pro_a[(long long)b * a.C0r + i];
-                protab[a.C0r + i] = a.pro_b[(long long)b * a.C0r + i];
-            }
-            protab_b = b;
-            __syncthreads();
-        }
+        ptab = protab + parity * 2 * a.C0r;
         {
-            if (tid < 256) {  // per-channel epilogue constants -> LDS: the epilogue proper must not wait on global loads
-                const int which = tid >> 6, co = co0 + (tid & 63);
-                float v = 0.f;
-                if (which == 0 && a.bias) v = a.bias[co];
-                if (which == 1 && a.vec) v = a.vec[(long long)b * a.Cout + co];
-                if (which == 2 && a.aux) v = a.aux_a[(long long)b * a.Cout + co];
-                if (which == 3 && a.aux) v = a.aux_b[(long long)b * a.Cout + co];
-                econst[tid] = v;
-            }
+            if (tid < 256) econst[tid] = pre_e;  // read in the epilogue only, many barriers from here
 #pragma unroll
             for (int i = 0; i < NL; ++i) stage_raw(rin, i, 0, 0);
 #pragma unroll
@@ -347,8 +350,11 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a, const i
             load_raw(rin, 0);
             load_raw(rin1, clampc(1));
             load_u(0);
+            fetch_consts();
         }
         chunk(nchunks - 1, std::false_type{});
+        parity ^= 1;
+        if (SPEC == 2 && item + G < last && tid < 2 * a.C0r) protab[parity * 2 * a.C0r + tid] = pre_p;  // the other parity is idle
         TRACE_MARK(2)
 
         TRACE_MARK(3)
@@ -452,7 +458,7 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a, const i
 
 template <int MODE, int SPEC>
 int launch(const ConvArgs& a, hipStream_t st) {
-    const size_t lds = ((size_t)2 * R_FLOATS + 2 * V_FLOATS + 2 * U_FLOATS + 256 + (SPEC == 2 ? 2 * (size_t)a.C0r : 0)) * sizeof(float);
+    const size_t lds = ((size_t)2 * R_FLOATS + 2 * V_FLOATS + 2 * U_FLOATS + 256 + (SPEC == 2 ? 4 * (size_t)a.C0r : 0)) * sizeof(float);
     if (lds > 160 * 1024) IDIFF_FAIL(IDIFF_E_UNSUPPORTED, "conv2d(winograd): LDS budget exceeded (%zu bytes)", lds);
     static size_t attr_set = 0;
     auto kern = conv_wino_kernel<MODE, SPEC>;
