@@ -73,7 +73,7 @@ typedef struct {
     float* stats;           /* optional GroupNorm partials [B][ntiles][Cout][2] (sum, sumsq) of the value
                                acc+bias, ntiles = idiff_conv2d_num_tiles(Hout,Wout)                     */
     const float* wwino;     /* optional Winograd-domain copy of the same 3x3 weights (idiff_pack_conv_weight_wino):
-                               when set and the shape tiles exactly (Cin % 8 == 0 per source, Cout % 64 == 0,
+                               when set and the shape tiles exactly (Cin % 8 == 0 per source, Cout % 16 == 0,
                                Hout % 8 == 0, Wout % 32 == 0, NORMAL / UPSAMPLE2) the F(2x2,3x3) kernel runs
                                (2.25x fewer matrix-core flops, same epilogue); otherwise wpk is used       */
 } idiff_conv_desc;
@@ -90,7 +90,8 @@ int idiff_pack_conv_weight(const float* w, float* wpk, int Cout, int Cin, int ks
 /* same, but spatially flipped and in/out swapped: wpk_T [ks*ks][Cout][Cin] for the data-gradient conv */
 int idiff_pack_conv_weight_T(const float* w, float* wpk, int Cout, int Cin, int ks, idiff_stream_t stream);
 /* 3x3 weights -> Winograd F(2x2,3x3) domain U = G g G^T, laid out as the kernel stages it:
- * [Cin/8][Cout/64][16 xi][4 co-blocks][4 k][16 co][2]  (16*Cin*Cout floats; Cin % 8 == 0, Cout % 64 == 0), Winograd rows
+ * [Cin/8][ceil(Cout/64)][16 xi][4 co-blocks][4 k][16 co][2]  (16*Cin*ceil(Cout/64)*64 floats; Cin % 8 == 0,
+ * Cout % 16 == 0: a partial last block is zero-filled), Winograd rows
  * in the kernel's order (u0, u1, -u3, u2) -- an opaque image, only idiff_conv2d_fwd reads it.
  * transpose != 0: the flipped, in/out-swapped weights of the data-gradient conv (then the conv has Cin' = Cout, Cout' = Cin). */
 int idiff_pack_conv_weight_wino(const float* w, float* wwino, int Cout, int Cin, int transpose, idiff_stream_t stream);

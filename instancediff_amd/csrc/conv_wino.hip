@@ -246,10 +246,12 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a, const i
         if (tid < 256) {
             const int which = tid >> 6, co = it_co0 + (tid & 63);
             pre_e = 0.f;
-            if (which == 0 && a.bias) pre_e = a.bias[co];
-            if (which == 1 && a.vec) pre_e = a.vec[(long long)it_b * a.Cout + co];
-            if (which == 2 && a.aux) pre_e = a.aux_a[(long long)it_b * a.Cout + co];
-            if (which == 3 && a.aux) pre_e = a.aux_b[(long long)it_b * a.Cout + co];
+            if (co < a.Cout) {  // Cout % 16 == 0: the last 64-channel block may be partial
+                if (which == 0 && a.bias) pre_e = a.bias[co];
+                if (which == 1 && a.vec) pre_e = a.vec[(long long)it_b * a.Cout + co];
+                if (which == 2 && a.aux) pre_e = a.aux_a[(long long)it_b * a.Cout + co];
+                if (which == 3 && a.aux) pre_e = a.aux_b[(long long)it_b * a.Cout + co];
+            }
         }
         if (SPEC == 2 && tid < 2 * a.C0r) pre_p = (tid < a.C0r ? a.pro_a : a.pro_b - a.C0r)[(long long)it_b * a.C0r + tid];
     };
@@ -385,6 +387,7 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a, const i
             constexpr bool RES = decltype(res_tag)::value, AUX = decltype(aux_tag)::value;
             floatx2 nres[2], naux[2];
             auto fetch = [&](int i) {
+                if (co0 + ch * 32 + (i >> 2) * 16 >= a.Cout) return;  // uniform
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy) {
                     const long long so = (long long)((i >> 2) * 16 + (i & 3)) * HWo + dy * a.Wout;  // uniform
@@ -396,6 +399,7 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a, const i
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int mb = i >> 2, r = i & 3;
+                if (co0 + ch * 32 + mb * 16 >= a.Cout) continue;  // uniform: a 16-channel block beyond a partial Cout
                 const floatx2 cres[2] = {nres[0], nres[1]}, caux[2] = {naux[0], naux[1]};
                 if (i + 1 < 8) fetch(i + 1);
                 float z[4][2];
@@ -448,7 +452,7 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a, const i
             if (tid < 128) {
                 const float t = (Rb[tid] + Rb[128 + tid]) + (Rb[256 + tid] + Rb[384 + tid]);
                 const int col = tid >> 1, w = tid & 1;
-                a.stats[(((long long)b * a.ntiles + tile) * a.Cout + co0 + col) * 2 + w] = t;
+                if (co0 + col < a.Cout) a.stats[(((long long)b * a.ntiles + tile) * a.Cout + co0 + col) * 2 + w] = t;
             }
         }
         TRACE_MARK(7)
@@ -498,7 +502,7 @@ int launch(const ConvArgs& a, hipStream_t st) {
 __global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int transpose) {
     // conv seen by the kernel: Co x Ci (swapped when transpose)
     const int Co = transpose ? Cin : Cout, Ci = transpose ? Cout : Cin;
-    const int ncob = Co / 64;
+    const int ncob = (Co + 63) / 64;         // the last block may be partial: its missing rows stay zero (caller clears)
     const long long n = (long long)Co * Ci;  // one thread per (co, ci): writes its 16 xi values
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int co = i % Co, ci = i / Co;
@@ -547,7 +551,7 @@ namespace idiff_detail {
 bool conv_wino_eligible(const ConvArgs& a, int ks, int mode) {
     if (ks != 3 || !a.wwino || wino_disabled()) return false;
     if (mode != IDIFF_CONV_NORMAL && mode != IDIFF_CONV_UPSAMPLE2) return false;
-    if (a.Cout % 64 || a.Cin % CK || a.C0v % CK || a.Hout % TH || a.Wout % TW) return false;
+    if (a.Cout % 16 || a.Cin % CK || a.C0v % CK || a.Hout % TH || a.Wout % TW) return false;
     if (mode == IDIFF_CONV_UPSAMPLE2 && (a.pro_a || a.src1)) return false;
     if (a.pro_a && a.src1) return false;
     if ((reinterpret_cast<uintptr_t>(a.wwino) & 15) != 0) return false;
@@ -569,7 +573,11 @@ int launch_conv_wino(const ConvArgs& a, int mode, hipStream_t st) {
 extern "C" int idiff_pack_conv_weight_wino(const float* w, float* wwino, int Cout, int Cin, int transpose, idiff_stream_t stream) {
     IDIFF_CHECK_ARG(w && wwino && Cout > 0 && Cin > 0, "pack_conv_weight_wino: bad args");
     const int Co = transpose ? Cin : Cout, Ci = transpose ? Cout : Cin;
-    IDIFF_CHECK_ARG(Co % 64 == 0 && Ci % 8 == 0, "pack_conv_weight_wino: needs conv Cout %% 64 == 0 and Cin %% 8 == 0 (got %d, %d)", Co, Ci);
+    IDIFF_CHECK_ARG(Co % 16 == 0 && Ci % 8 == 0, "pack_conv_weight_wino: needs conv Cout %% 16 == 0 and Cin %% 8 == 0 (got %d, %d)", Co, Ci);
+    if (Co % 64) {  // partial last 64-channel block: its unused rows must read as zero
+        hipError_t e = hipMemsetAsync(wwino, 0, (size_t)16 * Ci * ((Co + 63) / 64) * 64 * sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "pack_conv_weight_wino: hipMemsetAsync: %s", hipGetErrorString(e));
+    }
     const long long n = (long long)Cout * Cin;
     const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
     hipLaunchKernelGGL(pack_wino_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wwino, Cout, Cin, transpose);

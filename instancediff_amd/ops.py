@@ -65,9 +65,10 @@ def pack_conv_weight(w, transpose=False):
     out = torch.empty((k * k, co, ci) if transpose else (k * k, ci, co), device=w.device, dtype=torch.float32)
     fn = lib.idiff_pack_conv_weight_T if transpose else lib.idiff_pack_conv_weight
     check(fn(_p(w), _p(out), co, ci, k, _stream()), "pack_conv_weight")
-    if k == 3 and WINOGRAD and co % 8 == 0 and ci % 8 == 0 and (ci if transpose else co) % 64 == 0:
+    if k == 3 and WINOGRAD and co % 8 == 0 and ci % 8 == 0 and (ci if transpose else co) % 16 == 0:
         # Winograd-domain copy rides along as an attribute; conv2d hands it to the C ABI (idiff_conv_desc.wwino)
-        wino = torch.empty((16 * co * ci,), device=w.device, dtype=torch.float32)
+        cconv, kconv = (ci, co) if transpose else (co, ci)  # the conv's (Cout, Cin); Cout is padded to whole 64-blocks
+        wino = torch.empty((16 * kconv * ((cconv + 63) // 64) * 64,), device=w.device, dtype=torch.float32)
         check(lib.idiff_pack_conv_weight_wino(_p(w), _p(wino), co, ci, 1 if transpose else 0, _stream()), "pack_conv_weight_wino")
         out.wino = wino
     return out

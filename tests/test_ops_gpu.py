@@ -320,6 +320,8 @@ def _pack(w, wino, transpose=False):
     (1, 24, 40, 192, 24, 32, "concat"),
     (2, 32, 0, 64, 16, 16, "upsample"),     # out 32x32
     (1, 128, 0, 256, 64, 64, "epilogue"),
+    (2, 32, 0, 80, 8, 32, "plain"),         # Cout % 64 = 16: partial last channel block
+    (1, 64, 0, 144, 16, 32, "epilogue"),    # partial block with residual / aux / stats
 ])
 def test_conv_winograd_matches_direct_and_fp64(B, C0, C1, Cout, H, W, variant):
     g = _g(11)
