@@ -182,7 +182,7 @@ int idiff_attn_tokens_fwd(const float* q, const float* k, const float* v, float*
                           int heads, float scale, int64_t ldq, int64_t ldkv, idiff_stream_t stream);
 /* ScoreMapModule cross-attention, K/V projections folded onto the query side:
  *   S[b,h,q,n] = scale * sum_c qf[b,q,h,c] * mem[b,c,n];  P = softmax_n(S);  o[b,q,h,c] = sum_n P * mem[b,c,n]
- * qf, o: [B, Nq, heads, Cm];  mem: [B, Cm, N] channel-major;  Nq*heads <= 32, Cm in {96, 160, 256}.
+ * qf, o: [B, Nq, heads, Cm];  mem: [B, Cm, N] channel-major;  Nq*heads <= 32, Cm in {72, 136, 256}.
  * ws: workspace of idiff_smm_xattn_ws_floats(B,Nq,heads,Cm,N) floats. */
 int64_t idiff_smm_xattn_ws_floats(int B, int Nq, int heads, int Cm, int N);
 int idiff_smm_xattn_fwd(const float* qf, const float* mem, float* o, float* ws, int B, int Nq, int heads, int Cm,

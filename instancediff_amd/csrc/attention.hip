@@ -213,8 +213,8 @@ __global__ __launch_bounds__(64) void attn_tokens_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------
-// ScoreMapModule cross attention, Cm = 4*XCW in {96, 160, 256}, rows = Nq*heads <= 32.  XCW = channels per wave
-// (multiple of 8); the P.V product runs on whole 32-channel blocks, so a wave's LDS slice is padded to XCB*32 rows
+// ScoreMapModule cross attention, Cm = 4*XCW in {72, 136, 256}, rows = Nq*heads <= 32.  XCW = channels per wave
+// (even); the P.V product runs on whole 32-channel blocks, so a wave's LDS slice is padded to XCB*32 rows
 // (the padding rows produce accumulator rows that are never stored).
 template <int XCW>
 __global__ __launch_bounds__(256) void smm_xattn_kernel(const float* __restrict__ qf, const float* __restrict__ mem, float* __restrict__ ws,
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void smm_xattn_kernel(const float* __restrict_
     constexpr int XCM = 4 * XCW;
     constexpr int XCB = (XCW + 31) / 32;      // 32-channel blocks per wave in the P.V product
     constexpr int XTILE = XCB * 32 * 33;      // per-wave mem slice [XCB*32 c][33]
-    constexpr int NF4 = XCW / 8;              // float4 loads per lane per 32-key block
+    constexpr int NF4 = (XCW * 8 + 63) / 64;  // float4 loads per lane per 32-key block (the last one partial unless XCW % 8 == 0)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tile = smem + (threadIdx.x >> 6) * XTILE;  // private per wave
     float* xch = smem + 4 * XTILE;                    // [4][16][64]
@@ -254,7 +254,8 @@ __global__ __launch_bounds__(256) void smm_xattn_kernel(const float* __restrict_
             const int f = lane + i * 64;  // float4 index in [XCW][8]
             const int c = f >> 3, j4 = (f & 7) * 4;
             floatx4 z = {0.f, 0.f, 0.f, 0.f};
-            if (key0 + j4 + 3 < N)
+            if (XCW % 8 != 0 && f >= XCW * 8) {
+            } else if (key0 + j4 + 3 < N)
                 z = *reinterpret_cast<const floatx4*>(memb + (long long)c * N + key0 + j4);
             else
                 for (int e = 0; e < 4; ++e)
@@ -267,6 +268,7 @@ __global__ __launch_bounds__(256) void smm_xattn_kernel(const float* __restrict_
         for (int i = 0; i < NF4; ++i) {
             const int f = lane + i * 64;
             const int c = f >> 3, j4 = (f & 7) * 4;
+            if (XCW % 8 != 0 && f >= XCW * 8) continue;
 #pragma unroll
             for (int e = 0; e < 4; ++e) tile[c * 33 + j4 + e] = rt[i][e];
         }
@@ -427,7 +429,7 @@ extern "C" int64_t idiff_smm_xattn_ws_floats(int B, int Nq, int heads, int Cm, i
 extern "C" int idiff_smm_xattn_fwd(const float* qf, const float* mem, float* o, float* ws, int B, int Nq, int heads, int Cm, int N, float scale,
                                    idiff_stream_t stream) {
     IDIFF_CHECK_ARG(qf && mem && o && ws && B > 0 && Nq > 0 && heads > 0 && N > 0, "smm_xattn: bad args");
-    IDIFF_CHECK_ARG(Cm == 256 || Cm == 160 || Cm == 96, "smm_xattn: Cm must be 96, 160 or 256 (got %d)", Cm);
+    IDIFF_CHECK_ARG(Cm == 256 || Cm == 136 || Cm == 72, "smm_xattn: Cm must be 72, 136 or 256 (got %d)", Cm);
     IDIFF_CHECK_ARG(Nq * heads <= 32, "smm_xattn: Nq*heads must be <= 32 (got %d)", Nq * heads);
     IDIFF_CHECK_ARG(N % 4 == 0, "smm_xattn: N must be a multiple of 4");
     int ns, kps;
@@ -438,10 +440,10 @@ extern "C" int idiff_smm_xattn_fwd(const float* qf, const float* mem, float* o, 
     const size_t lds = (size_t)(4 * xcb * 32 * 33 + 4 * 16 * 64) * sizeof(float);
     if (Cm == 256)
         hipLaunchKernelGGL(smm_xattn_kernel<64>, dim3(ns, B), dim3(256), lds, st, qf, mem, ws, rows, N, ns, kps, scale);
-    else if (Cm == 160)
-        hipLaunchKernelGGL(smm_xattn_kernel<40>, dim3(ns, B), dim3(256), lds, st, qf, mem, ws, rows, N, ns, kps, scale);
+    else if (Cm == 136)
+        hipLaunchKernelGGL(smm_xattn_kernel<34>, dim3(ns, B), dim3(256), lds, st, qf, mem, ws, rows, N, ns, kps, scale);
     else
-        hipLaunchKernelGGL(smm_xattn_kernel<24>, dim3(ns, B), dim3(256), lds, st, qf, mem, ws, rows, N, ns, kps, scale);
+        hipLaunchKernelGGL(smm_xattn_kernel<18>, dim3(ns, B), dim3(256), lds, st, qf, mem, ws, rows, N, ns, kps, scale);
     IDIFF_CHECK_LAUNCH("smm_xattn_fwd");
     hipLaunchKernelGGL(smm_xattn_combine_kernel, dim3((rows * Cm + 255) / 256, B), dim3(256), 0, st, ws, o, rows, ns, Cm);
     IDIFF_CHECK_LAUNCH("smm_xattn_combine");

@@ -185,9 +185,9 @@ class ScoreMapModule(nn.Module):
         wmp = _PREP.get(("mp", mp[1]), (mp[1].weight,),
                         lambda: ops.pack_conv_weight(mp[1].weight.detach().reshape(Wd, C, 1, 1).contiguous()))
         # Narrow feature maps: LN_256(W.xhat + b) = g2 * ((Wc.xhat + bc) * rstd) + b2 is an affine image of the (C+1)-vector
-        # m = [xhat*rstd ; rstd], so the cross-attention streams m (Cm = 96 / 160 rows) instead of the 256-row memory and
+        # m = [xhat*rstd ; rstd], so the cross-attention streams m (Cm = 72 / 136 rows) instead of the 256-row memory and
         # g2.[Wc|bc] is folded into its query / value projections (b2 drops out of the softmax and returns as a bias).
-        Cm = Wd if C + 1 > 160 else (96 if C + 1 <= 96 else 160)
+        Cm = Wd if C + 1 > 136 else (72 if C + 1 <= 72 else 136)
         compact = Cm < Wd
         if compact:
             mem = ops.smm_memproj_compact(feat, mp[0].weight, mp[0].bias, wmp, mp[1].bias, Cm, eps=mp[0].eps)

@@ -84,7 +84,7 @@ def test_attn_tokens_packed():
 
 # ---------------------------------------------------------------------------------------------------
 # compact ScoreMapModule memory: [xhat*rstd ; rstd] + folded projections == attention over the 256-wide memory
-@pytest.mark.parametrize("Cm,N", [(96, 1024), (160, 256), (256, 512), (96, 36)])
+@pytest.mark.parametrize("Cm,N", [(72, 1024), (136, 256), (256, 512), (72, 36)])
 def test_smm_xattn_channel_widths(Cm, N):
     g = torch.Generator().manual_seed(31)
     B, Nq, heads = 2, 5, 4
@@ -97,7 +97,7 @@ def test_smm_xattn_channel_widths(Cm, N):
     _close(out, ref, 1e-5, f"smm_xattn Cm={Cm}")
 
 
-@pytest.mark.parametrize("C,Cm,H,W", [(64, 96, 32, 32), (128, 160, 16, 16), (64, 96, 6, 10)])
+@pytest.mark.parametrize("C,Cm,H,W", [(64, 72, 32, 32), (128, 136, 16, 16), (64, 72, 6, 10)])
 def test_smm_compact_memory_equals_full_memory_attention(C, Cm, H, W):
     from instancediff_amd.models.modules import MSM_degEmb_Unet as M
     g = torch.Generator().manual_seed(32)
@@ -149,7 +149,7 @@ def test_smm_compact_memory_equals_full_memory_attention(C, Cm, H, W):
 
 def test_linear_t_heads_matches_per_head_calls():
     g = torch.Generator().manual_seed(33)
-    R, heads, dh, Cm = 13, 4, 64, 96
+    R, heads, dh, Cm = 13, 4, 64, 72
     qc = torch.randn(R, heads * dh, generator=g).to(DEV)
     wkf = torch.randn(heads * dh, Cm, generator=g).to(DEV)          # row blocks = per-head [dh, Cm]
     wvf = torch.randn(Cm, heads * dh, generator=g).to(DEV)          # column blocks = per-head [Cm, dh]
