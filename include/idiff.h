@@ -146,14 +146,17 @@ int idiff_smm_memproj_fwd(const float* feat, int64_t feat_bstride, const float* 
                           const float* wpk, const float* bias, const float* ln2_g, const float* ln2_b, float* out, int B,
                           int C, int N, float eps, idiff_stream_t stream);
 /* Compact form of the same memory for narrow feature maps (C + 1 <= Cm < 256).  With xhat = LayerNorm_C(feat[b,:,p]),
- * z = wpk^T.xhat + bias, mu = mean(z), rstd = 1/sqrt(var(z)+eps):   LayerNorm_256(z) = g2 * ((Wc.xhat + bc) * rstd) + b2
+ * z = W.xhat + bias, rstd = 1/sqrt(var(z)+eps2):   LayerNorm_256(z) = g2 * ((Wc.xhat + bc) * rstd) + b2
  * (Wc, bc = W and bias centred over the 256 outputs), i.e. the 256-wide memory is an affine image of the (C+1)-vector
  * [xhat*rstd ; rstd].  out [B,Cm,N] = rows [xhat*rstd (C) ; rstd (1) ; zeros]; the host folds g2.[Wc|bc] into the query
  * and value projections of the cross-attention (b2 cancels in the softmax and re-enters as a bias), so
- * idiff_smm_xattn_fwd streams (C+1)/256 of the bytes.  Same arithmetic as idiff_smm_memproj_fwd up to fp32 rounding. */
+ * idiff_smm_xattn_fwd streams (C+1)/256 of the bytes.  The variance itself is evaluated as the quadratic form
+ * var = xhat^T G xhat + 2 h.xhat + e with  gram = Wc^T Wc / 256  [C][C],  hvec = Wc^T bc / 256  [C],  evar = |bc|^2 / 256
+ * (host-prepared in fp64): a C -> C product instead of C -> 256.  Same arithmetic as idiff_smm_memproj_fwd up to fp32
+ * rounding.  C % 32 == 0. */
 int idiff_smm_memproj_compact_fwd(const float* feat, int64_t feat_bstride, const float* ln1_g, const float* ln1_b,
-                                  const float* wpk, const float* bias, float* out, int B, int C, int N, int Cm, float eps,
-                                  idiff_stream_t stream);
+                                  const float* gram, const float* hvec, float evar, float* out, int B, int C, int N, int Cm,
+                                  float eps1, float eps2, idiff_stream_t stream);
 int idiff_layernorm_rows_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out,
                              int64_t ldo, int R, int C, float eps, float* mean_rstd, idiff_stream_t stream);
 /* sinusoidal embedding, [sin | cos] halves; freqs [dim/2] = host-built table exp(-ln(1e4) * i/(half-1))

@@ -52,7 +52,7 @@ SIGNATURES = {
     "idiff_linear_t_fwd": (I, [P, I64, P, I64, P, P, I64, P, P, I64, I, I, I, I, I, c_stream]),
     "idiff_linear_t_heads_fwd": (I, [P, I64, I64, P, I64, I64, P, I64, P, I64, I64, I, I, I, I, c_stream]),
     "idiff_smm_memproj_fwd": (I, [P, I64, P, P, P, P, P, P, P, I, I, I, F, c_stream]),
-    "idiff_smm_memproj_compact_fwd": (I, [P, I64, P, P, P, P, P, I, I, I, I, F, c_stream]),
+    "idiff_smm_memproj_compact_fwd": (I, [P, I64, P, P, P, P, F, P, I, I, I, I, F, F, c_stream]),
     "idiff_layernorm_rows_fwd": (I, [P, I64, P, P, P, I64, I, I, F, P, c_stream]),
     "idiff_time_embed_fwd": (I, [P, P, I, I, P, c_stream]),
     "idiff_chan_layernorm_fwd": (I, [P, I64, P, P, P, I64, I, I, I, F, P, c_stream]),

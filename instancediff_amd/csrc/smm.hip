@@ -17,8 +17,7 @@ constexpr int MP_PX = 64;   // pixels per workgroup
 __global__ __launch_bounds__(256) void smm_memproj_kernel(const float* __restrict__ feat, long long fbs, const float* __restrict__ g1,
                                                           const float* __restrict__ b1, const float* __restrict__ wpk,
                                                           const float* __restrict__ bias, const float* __restrict__ g2,
-                                                          const float* __restrict__ b2, float* __restrict__ out, int C, int N, float eps,
-                                                          int compact_cm) {
+                                                          const float* __restrict__ b2, float* __restrict__ out, int C, int N, float eps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xt = smem;                 // [C][64]
     float* part = smem + C * MP_PX;   // [4][64]
@@ -137,36 +136,6 @@ __global__ __launch_bounds__(256) void smm_memproj_kernel(const float* __restric
         const int p = n * 32 + l31;
         rstd2[n] = rsqrtf((part[p] + part[MP_PX + p] + part[2 * MP_PX + p] + part[3 * MP_PX + p]) / (float)MP_W + eps);
     }
-    if (compact_cm > 0) {
-        // Compact form for the folded cross-attention (idiff_smm_memproj_compact_fwd): the 256-wide projection is only
-        // needed for its per-pixel statistics; what is stored is [ xhat * rstd2 ; rstd2 ; 0.. ] = C+1 (-> compact_cm) rows.
-        float* rs = part;  // [64] rstd2 per pixel (part is free: all reads of it are done after the barrier below)
-        __syncthreads();
-        if (wave == 0 && half == 0) {
-            rs[l31] = rstd2[0];
-            rs[32 + l31] = rstd2[1];
-        }
-        __syncthreads();
-        float* ob = out + (long long)b * compact_cm * N;
-        const int nf = compact_cm * (MP_PX / 4);
-        for (int f = tid; f < nf; f += 256) {
-            const int c = f >> 4, j4 = (f & 15) * 4;
-            floatx4 v = {0.f, 0.f, 0.f, 0.f};
-            const floatx4 r4 = *reinterpret_cast<const floatx4*>(rs + j4);
-            if (c < C) {
-                const floatx4 x4 = *reinterpret_cast<const floatx4*>(xt + c * MP_PX + j4);
-                v = floatx4{x4.x * r4.x, x4.y * r4.y, x4.z * r4.z, x4.w * r4.w};
-            } else if (c == C) {
-                v = r4;
-            }
-            if (p0 + j4 + 3 < N)
-                *reinterpret_cast<floatx4*>(ob + (long long)c * N + p0 + j4) = v;
-            else
-                for (int e = 0; e < 4; ++e)
-                    if (p0 + j4 + e < N) ob[(long long)c * N + p0 + j4 + e] = v[e];
-        }
-        return;
-    }
     float* ob = out + (long long)b * MP_W * N;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
@@ -180,6 +149,104 @@ __global__ __launch_bounds__(256) void smm_memproj_kernel(const float* __restric
                     ob[(long long)co * N + p] = (acc[m][n][r] - mean2[n]) * rstd2[n] * gv[m][r] + ov[m][r];
                 }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Compact memory for the folded cross-attention (idiff_smm_memproj_compact_fwd):  out = [ xhat * rstd ; rstd ; 0.. ]
+// with xhat = LayerNorm_C(feature token) and rstd = 1/sqrt(var_256(W xhat + b) + eps).  The 256-wide projection is only
+// needed for that variance, and   var = |Wc xhat + bc|^2 / 256 = xhat^T G xhat + 2 h.xhat + e   with the centred
+// Wc, bc and G = Wc^T Wc / 256 (C x C), h = Wc^T bc / 256, e = |bc|^2 / 256 prepared on the host (fp64): a C -> C product
+// on the matrix cores instead of C -> 256 (4x fewer flops at C = 64), which leaves the kernel bandwidth-bound.
+// One workgroup = 64 pixels; 32 x 32 output tiles of y = G xhat are dealt to the 4 waves; sum_c' xhat[c'] (y[c'] + 2 h[c'])
+// is reduced over a lane's 16 rows, the two half-waves and the tiles through LDS.
+__global__ __launch_bounds__(256) void smm_memproj_gram_kernel(const float* __restrict__ feat, long long fbs, const float* __restrict__ g1,
+                                                               const float* __restrict__ b1, const float* __restrict__ gram,
+                                                               const float* __restrict__ hvec, float evar, float* __restrict__ out, int C,
+                                                               int N, int Cm, float eps1, float eps2) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xt = smem;                 // [C][64]
+    float* part = smem + C * MP_PX;   // [8][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * MP_PX;
+    const float* fb = feat + (long long)b * fbs;
+    const int nf4 = C * (MP_PX / 4);
+    for (int f = tid; f < nf4; f += 256) {
+        const int c = f >> 4, j4 = (f & 15) * 4;
+        floatx4 v = {0.f, 0.f, 0.f, 0.f};
+        if (p0 + j4 + 3 < N)
+            v = *reinterpret_cast<const floatx4*>(fb + (long long)c * N + p0 + j4);
+        else
+            for (int e = 0; e < 4; ++e)
+                if (p0 + j4 + e < N) v[e] = fb[(long long)c * N + p0 + j4 + e];
+        *reinterpret_cast<floatx4*>(xt + c * MP_PX + j4) = v;
+    }
+    __syncthreads();
+    // ---- LayerNorm over C per pixel (two-pass; wave q covers channels q, q+4, ...; lane = pixel) ------------------
+    float s = 0.f;
+    for (int c = wave; c < C; c += 4) s += xt[c * MP_PX + lane];
+    part[wave * MP_PX + lane] = s;
+    __syncthreads();
+    const float mean1 = (part[lane] + part[MP_PX + lane] + part[2 * MP_PX + lane] + part[3 * MP_PX + lane]) / (float)C;
+    __syncthreads();
+    float q = 0.f;
+    for (int c = wave; c < C; c += 4) {
+        const float d = xt[c * MP_PX + lane] - mean1;
+        q += d * d;
+    }
+    part[wave * MP_PX + lane] = q;
+    __syncthreads();
+    const float rstd1 = rsqrtf((part[lane] + part[MP_PX + lane] + part[2 * MP_PX + lane] + part[3 * MP_PX + lane]) / (float)C + eps1);
+    __syncthreads();
+    for (int c = wave; c < C; c += 4) xt[c * MP_PX + lane] = (xt[c * MP_PX + lane] - mean1) * rstd1 * g1[c] + b1[c];
+    __syncthreads();
+    // ---- quadratic form: tiles (m: 32 rows c', n: 32 pixels) of y = G xhat, folded with xhat on the spot -----------
+    const int mt = C / 32, ntiles = mt * 2;
+    float pv[2] = {0.f, 0.f};  // per pixel block n
+    for (int t = wave; t < ntiles; t += 4) {
+        const int m = t % mt, n = t / mt;
+        floatx16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* wl = gram + (long long)half * C + m * 32 + l31;
+        const float* xl = xt + half * MP_PX + n * 32 + l31;
+#pragma unroll 4
+        for (int st = 0; st < C / 2; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(long long)(2 * st) * C], xl[2 * st * MP_PX], acc, 0, 0, 0);
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cp = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            sum += xt[cp * MP_PX + n * 32 + l31] * (acc[r] + 2.f * hvec[cp]);
+        }
+        pv[n & 1] += sum;  // n is 0 or 1
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        pv[n] += __shfl_xor(pv[n], 32, 64);
+        if (half == 0) part[wave * MP_PX + n * 32 + l31] = pv[n];
+    }
+    __syncthreads();
+    float* rs = part + 4 * MP_PX;  // [64] rstd per pixel
+    if (tid < MP_PX) rs[tid] = rsqrtf(part[tid] + part[MP_PX + tid] + part[2 * MP_PX + tid] + part[3 * MP_PX + tid] + evar + eps2);
+    __syncthreads();
+    float* ob = out + (long long)b * Cm * N;
+    const int nf = Cm * (MP_PX / 4);
+    for (int f = tid; f < nf; f += 256) {
+        const int c = f >> 4, j4 = (f & 15) * 4;
+        floatx4 v = {0.f, 0.f, 0.f, 0.f};
+        const floatx4 r4 = *reinterpret_cast<const floatx4*>(rs + j4);
+        if (c < C) {
+            const floatx4 x4 = *reinterpret_cast<const floatx4*>(xt + c * MP_PX + j4);
+            v = floatx4{x4.x * r4.x, x4.y * r4.y, x4.z * r4.z, x4.w * r4.w};
+        } else if (c == C) {
+            v = r4;
+        }
+        if (p0 + j4 + 3 < N)
+            *reinterpret_cast<floatx4*>(ob + (long long)c * N + p0 + j4) = v;
+        else
+            for (int e = 0; e < 4; ++e)
+                if (p0 + j4 + e < N) ob[(long long)c * N + p0 + j4 + e] = v[e];
     }
 }
 
@@ -250,14 +317,12 @@ __global__ __launch_bounds__(256) void linear_t_kernel(const float* __restrict__
 
 }  // namespace
 
-static int memproj_launch(const float* feat, int64_t feat_bstride, const float* ln1_g, const float* ln1_b, const float* wpk, const float* bias,
-                          const float* ln2_g, const float* ln2_b, float* out, int B, int C, int N, float eps, int compact_cm,
-                          idiff_stream_t stream) {
-    IDIFF_CHECK_ARG(feat && ln1_g && ln1_b && wpk && bias && out, "smm_memproj: null pointer");
-    IDIFF_CHECK_ARG(compact_cm > 0 || (ln2_g && ln2_b), "smm_memproj: null pointer");
+extern "C" int idiff_smm_memproj_fwd(const float* feat, int64_t feat_bstride, const float* ln1_g, const float* ln1_b, const float* wpk,
+                                     const float* bias, const float* ln2_g, const float* ln2_b, float* out, int B, int C, int N, float eps,
+                                     idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(feat && ln1_g && ln1_b && wpk && bias && ln2_g && ln2_b && out, "smm_memproj: null pointer");
     IDIFF_CHECK_ARG(B > 0 && N > 0 && C >= 2 && C % 2 == 0 && C <= 512, "smm_memproj: C must be even and <= 512 (got %d)", C);
     IDIFF_CHECK_ARG(N % 4 == 0 && feat_bstride % 4 == 0, "smm_memproj: N and feat_bstride must be multiples of 4");
-    IDIFF_CHECK_ARG(compact_cm == 0 || compact_cm > C, "smm_memproj_compact: Cm must exceed C (got %d, C = %d)", compact_cm, C);
     const size_t lds = (size_t)(C * MP_PX + 4 * MP_PX + 2 * MP_PX) * sizeof(float);
     static size_t attr = 0;
     if (lds > attr) {
@@ -266,20 +331,29 @@ static int memproj_launch(const float* feat, int64_t feat_bstride, const float* 
         attr = lds;
     }
     hipLaunchKernelGGL(smm_memproj_kernel, dim3((N + MP_PX - 1) / MP_PX, B), dim3(256), lds, (hipStream_t)stream, feat, (long long)feat_bstride,
-                       ln1_g, ln1_b, wpk, bias, compact_cm ? bias : ln2_g, compact_cm ? bias : ln2_b, out, C, N, eps, compact_cm);
+                       ln1_g, ln1_b, wpk, bias, ln2_g, ln2_b, out, C, N, eps);
     IDIFF_CHECK_LAUNCH("smm_memproj_fwd");
     return IDIFF_OK;
 }
 
-extern "C" int idiff_smm_memproj_fwd(const float* feat, int64_t feat_bstride, const float* ln1_g, const float* ln1_b, const float* wpk,
-                                     const float* bias, const float* ln2_g, const float* ln2_b, float* out, int B, int C, int N, float eps,
-                                     idiff_stream_t stream) {
-    return memproj_launch(feat, feat_bstride, ln1_g, ln1_b, wpk, bias, ln2_g, ln2_b, out, B, C, N, eps, 0, stream);
-}
-
-extern "C" int idiff_smm_memproj_compact_fwd(const float* feat, int64_t feat_bstride, const float* ln1_g, const float* ln1_b, const float* wpk,
-                                             const float* bias, float* out, int B, int C, int N, int Cm, float eps, idiff_stream_t stream) {
-    return memproj_launch(feat, feat_bstride, ln1_g, ln1_b, wpk, bias, nullptr, nullptr, out, B, C, N, eps, Cm, stream);
+extern "C" int idiff_smm_memproj_compact_fwd(const float* feat, int64_t feat_bstride, const float* ln1_g, const float* ln1_b, const float* gram,
+                                             const float* hvec, float evar, float* out, int B, int C, int N, int Cm, float eps1, float eps2,
+                                             idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(feat && ln1_g && ln1_b && gram && hvec && out, "smm_memproj_compact: null pointer");
+    IDIFF_CHECK_ARG(B > 0 && N > 0 && C >= 32 && C % 32 == 0 && C <= 512, "smm_memproj_compact: C must be a multiple of 32, <= 512 (got %d)", C);
+    IDIFF_CHECK_ARG(N % 4 == 0 && feat_bstride % 4 == 0, "smm_memproj_compact: N and feat_bstride must be multiples of 4");
+    IDIFF_CHECK_ARG(Cm > C, "smm_memproj_compact: Cm must exceed C (got %d, C = %d)", Cm, C);
+    const size_t lds = (size_t)(C * MP_PX + 5 * MP_PX) * sizeof(float);
+    static size_t attr = 0;
+    if (lds > attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(smm_memproj_gram_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "smm_memproj_compact: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr = lds;
+    }
+    hipLaunchKernelGGL(smm_memproj_gram_kernel, dim3((N + MP_PX - 1) / MP_PX, B), dim3(256), lds, (hipStream_t)stream, feat, (long long)feat_bstride,
+                       ln1_g, ln1_b, gram, hvec, evar, out, C, N, Cm, eps1, eps2);
+    IDIFF_CHECK_LAUNCH("smm_memproj_compact_fwd");
+    return IDIFF_OK;
 }
 
 static int linear_t_launch(const float* x, int64_t ldx, const float* wT, int64_t ldw, const float* bias, const float* res, int64_t ldr,

@@ -190,7 +190,8 @@ class ScoreMapModule(nn.Module):
         Cm = Wd if C + 1 > 136 else (72 if C + 1 <= 72 else 136)
         compact = Cm < Wd
         if compact:
-            mem = ops.smm_memproj_compact(feat, mp[0].weight, mp[0].bias, wmp, mp[1].bias, Cm, eps=mp[0].eps)
+            gram, hvec, evar = _PREP.get(("mpvar", mp[1]), (mp[1].weight, mp[1].bias), lambda: ops.memory_variance_form(mp[1].weight, mp[1].bias))
+            mem = ops.smm_memproj_compact(feat, mp[0].weight, mp[0].bias, gram, hvec, evar, Cm, eps1=mp[0].eps, eps2=mp[2].eps)
         else:
             mem = ops.smm_memproj(feat, mp[0].weight, mp[0].bias, wmp, mp[1].bias, mp[2].weight, mp[2].bias, eps=mp[0].eps)
         tp = dec.text_proj

@@ -225,14 +225,25 @@ def smm_memproj(feat, ln1_g, ln1_b, wpk, bias, ln2_g, ln2_b, eps=1e-5):
     return out
 
 
-def smm_memproj_compact(feat, ln1_g, ln1_b, wpk, bias, Cm, eps=1e-5):
-    """feat [B,C,H,W] -> [B,Cm,H*W] rows [xhat*rstd2 ; rstd2 ; 0]: the (C+1)-dim affine pre-image of the 256-wide memory."""
+def smm_memproj_compact(feat, ln1_g, ln1_b, gram, hvec, evar, Cm, eps1=1e-5, eps2=1e-5):
+    """feat [B,C,H,W] -> [B,Cm,H*W] rows [xhat*rstd2 ; rstd2 ; 0]: the (C+1)-dim affine pre-image of the 256-wide memory.
+    gram [C,C], hvec [C], evar: the quadratic form of the 256-wide variance (memory_variance_form)."""
     lib = _lib.load()
     B, Cc, H, W = feat.shape
     out = torch.empty((B, Cm, H * W), device=feat.device, dtype=torch.float32)
-    check(lib.idiff_smm_memproj_compact_fwd(_p(feat), _bs(feat, "feat"), _p(_c(ln1_g)), _p(_c(ln1_b)), _p(_c(wpk)), _p(_c(bias)), _p(out),
-                                            B, Cc, H * W, Cm, eps, _stream()), "smm_memproj_compact_fwd")
+    check(lib.idiff_smm_memproj_compact_fwd(_p(feat), _bs(feat, "feat"), _p(_c(ln1_g)), _p(_c(ln1_b)), _p(_c(gram)), _p(_c(hvec)), float(evar),
+                                            _p(out), B, Cc, H * W, Cm, eps1, eps2, _stream()), "smm_memproj_compact_fwd")
     return out
+
+
+def memory_variance_form(lin_weight, lin_bias):
+    """(gram [C,C], hvec [C], evar) with var_256(W x + b) = x^T gram x + 2 hvec.x + evar  (host-side weight preparation, fp64)."""
+    W = lin_weight.detach().double()
+    b = lin_bias.detach().double()
+    Wc = W - W.mean(dim=0, keepdim=True)
+    bc = b - b.mean()
+    n = W.shape[0]
+    return (Wc.t() @ Wc / n).float().contiguous(), (Wc.t() @ bc / n).float().contiguous(), float(bc.dot(bc) / n)
 
 
 def layernorm_rows(x, gamma, beta, eps=1e-5, want_mean_rstd=False):

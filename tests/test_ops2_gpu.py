@@ -124,8 +124,8 @@ def test_smm_compact_memory_equals_full_memory_attention(C, Cm, H, W):
     att = torch.softmax(torch.einsum("bqhd,bnhd->bhqn", q, k) * scale, -1)
     ref = torch.einsum("bhqn,bnhd->bqhd", att, v).reshape(B * Nq, Wd)
     # compact path on the device
-    wpk = ops.pack_conv_weight(lin.weight.detach().reshape(Wd, C, 1, 1).contiguous().to(DEV))
-    m = ops.smm_memproj_compact(feat.to(DEV), ln1.weight.detach().to(DEV), ln1.bias.detach().to(DEV), wpk, lin.bias.detach().to(DEV), Cm)
+    gram, hvec, evar = ops.memory_variance_form(lin.weight.to(DEV), lin.bias.to(DEV))
+    m = ops.smm_memproj_compact(feat.to(DEV), ln1.weight.detach().to(DEV), ln1.bias.detach().to(DEV), gram, hvec, evar, Cm)
     assert m.shape == (B, Cm, H * W)
     xhat = F.layer_norm(tok, (C,), ln1.weight.double(), ln1.bias.double(), 1e-5)
     z = F.linear(xhat, lin.weight.double(), lin.bias.double())
