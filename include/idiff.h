@@ -194,6 +194,11 @@ int idiff_smm_xattn_fwd(const float* qf, const float* mem, float* o, float* ws, 
  * sel (optional) [B, HW] = out[b, idx[b], :]  (idx int32 [B]) */
 int idiff_scoremap_fwd(const float* feat, int64_t feat_bstride, const float* tv, float* out, const int32_t* idx,
                        float* sel, int B, int C, int HW, int K, idiff_stream_t stream);
+/* Output layer fused with the class gather (replaces the UNet's final 3x3 conv to out_nc channels followed by the
+ * per-sample channel pick): out[b,0,y,x] = bias[idx[b]] + sum_{ci,ky,kx} w[idx[b],ci,ky,kx] * x[b,ci,y+ky-1,x+kx-1]
+ * w [K,C,3,3] (torch layout), bias [K] or NULL, idx int32 [B] in [0,K), out [B,1,H,W]. */
+int idiff_conv3x3_select_fwd(const float* x, int64_t x_bstride, const float* w, const float* bias, const int32_t* idx, float* out,
+                             int B, int C, int K, int H, int W, idiff_stream_t stream);
 /* out[b,0,p] = x[b, idx[b], p] */
 int idiff_gather_channel(const float* x, const int32_t* idx, float* out, int B, int C, int HW, idiff_stream_t stream);
 

@@ -63,6 +63,7 @@ SIGNATURES = {
     "idiff_smm_xattn_fwd": (I, [P, P, P, P, I, I, I, I, I, F, c_stream]),
     "idiff_scoremap_fwd": (I, [P, I64, P, P, P, P, I, I, I, I, c_stream]),
     "idiff_gather_channel": (I, [P, P, P, I, I, I, c_stream]),
+    "idiff_conv3x3_select_fwd": (I, [P, I64, P, P, P, P, I, I, I, I, I, c_stream]),
     "idiff_irsde_reverse_step": (I, [P, P, P, P, P, I64, F, F, F, F, F, I, U64, U64, c_stream]),
     "idiff_drift_reverse_step": (I, [P, P, P, P, P, P, P, I64, F, F, F, U64, U64, c_stream]),
     "idiff_randn": (I, [P, I64, U64, U64, c_stream]),

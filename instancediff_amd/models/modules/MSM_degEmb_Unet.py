@@ -576,8 +576,8 @@ class LearnableForwardUNet_MultiScoreMap(nn.Module):
                 x = up.ca2.run(x, ctx)
             x = up.up.run(x)
         x = self.final_res.run(x, x_, films[id(self.final_res)])
-        out = ops.conv2d(x, packed(self.final_conv), self.final_conv.bias, 3, self.out_nc)
-        pred = ops.gather_channel(out, idx)
+        # final 3x3 conv to out_nc channels + per-sample class pick, computed as ONE channel per sample
+        pred = ops.conv3x3_select(x, self.final_conv.weight.detach(), self.final_conv.bias, idx)
         if self.text_module == "scoremap":
             return pred, sms
         return pred

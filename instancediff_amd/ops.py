@@ -337,6 +337,18 @@ def smm_xattn(qf, mem, scale):
     return o
 
 
+def conv3x3_select(x, weight, bias, idx):
+    """final 3x3 conv + class gather in one pass: x [B,C,H,W], weight [K,C,3,3] (torch layout), idx int32 [B] -> [B,1,H,W]."""
+    lib = _lib.load()
+    B, Cc, H, W = x.shape
+    K = weight.shape[0]
+    assert tuple(weight.shape) == (K, Cc, 3, 3) and idx.dtype == torch.int32 and idx.numel() == B
+    out = torch.empty((B, 1, H, W), device=x.device, dtype=torch.float32)
+    check(lib.idiff_conv3x3_select_fwd(_p(x), _bs(x, "x"), _p(_c(weight)), _p(_c(bias)), C.c_void_p(idx.contiguous().data_ptr()), _p(out), B, Cc, K, H, W,
+                                       _stream()), "conv3x3_select_fwd")
+    return out
+
+
 def scoremap(feat, tv, idx=None):
     """feat [B,C,H,W], tv [B,K,C] -> score [B,K,H,W] (+ sel [B,1,H,W] = score[b, idx[b]])."""
     lib = _lib.load()

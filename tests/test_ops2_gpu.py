@@ -163,3 +163,16 @@ def test_linear_t_heads_matches_per_head_calls():
         _close(qf[:, h * Cm:(h + 1) * Cm], ref_q, 3e-6, f"head {h} query fold")
         ref_v = qf[:, h * Cm:(h + 1) * Cm].double() @ wvf[:, h * dh:(h + 1) * dh].double() + bvf[h * dh:(h + 1) * dh].double()
         _close(av[:, h * dh:(h + 1) * dh], ref_v, 3e-6, f"head {h} value fold")
+
+
+@pytest.mark.parametrize("B,C,K,H,W", [(3, 64, 5, 32, 32), (2, 12, 5, 13, 40), (1, 64, 5, 8, 64)])
+def test_conv3x3_select_equals_conv_then_gather(B, C, K, H, W):
+    g = torch.Generator().manual_seed(51)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) / math.sqrt(9 * C)
+    bias = torch.randn(K, generator=g)
+    idx = torch.randint(0, K, (B,), generator=g).to(torch.int32)
+    full = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    ref = full[torch.arange(B), idx.long()][:, None]
+    out = ops.conv3x3_select(x.to(DEV), w.to(DEV), bias.to(DEV), idx.to(DEV))
+    _close(out, ref, 3e-6, "conv3x3_select")
