@@ -133,6 +133,11 @@ int idiff_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, c
 int idiff_linear_t_fwd(const float* x, int64_t ldx, const float* wT, int64_t ldw, const float* bias, const float* res,
                        int64_t ldr, const float* gscale, float* out, int64_t ldo, int R, int K, int N, int act_in,
                        int act_out, idiff_stream_t stream);
+/* idiff_linear_t_fwd on LayerNorm(x) (per row over K, parameters ln_g / ln_b [K]): the LayerNorm runs on the rows the
+ * kernel has staged anyway -- the LayerNorm -> Linear pairs of the ScoreMapModule decoder in one launch each. */
+int idiff_linear_t_ln_fwd(const float* x, int64_t ldx, const float* ln_g, const float* ln_b, float ln_eps, const float* wT,
+                          int64_t ldw, const float* bias, const float* res, int64_t ldr, const float* gscale, float* out,
+                          int64_t ldo, int R, int K, int N, int act_out, idiff_stream_t stream);
 /* `heads` independent products of that form in ONE launch (no res / gscale / activation): head h uses x + h*x_hs,
  * wT + h*w_hs, bias + h*b_hs, out + h*o_hs -- the per-head k/v folds of the ScoreMapModule cross-attention, whose
  * operands are column / row blocks of shared matrices. */

@@ -50,6 +50,7 @@ SIGNATURES = {
     "idiff_affine_silu_add": (I, [P, I64, P, P, P, I64, P, P, I64, I, I, I, c_stream]),
     "idiff_linear_fwd": (I, [P, I64, P, I64, P, P, I64, P, P, I64, I, I, I, I, I, c_stream]),
     "idiff_linear_t_fwd": (I, [P, I64, P, I64, P, P, I64, P, P, I64, I, I, I, I, I, c_stream]),
+    "idiff_linear_t_ln_fwd": (I, [P, I64, P, P, F, P, I64, P, P, I64, P, P, I64, I, I, I, I, c_stream]),
     "idiff_linear_t_heads_fwd": (I, [P, I64, I64, P, I64, I64, P, I64, P, I64, I64, I, I, I, I, c_stream]),
     "idiff_smm_memproj_fwd": (I, [P, I64, P, P, P, P, P, P, P, I, I, I, F, c_stream]),
     "idiff_smm_memproj_compact_fwd": (I, [P, I64, P, P, P, P, F, P, I, I, I, I, F, F, c_stream]),

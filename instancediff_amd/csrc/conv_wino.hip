@@ -85,7 +85,7 @@ __device__ __forceinline__ float row_sum16(float v) {
 // of (sample, patch, channel-block) items, channel block fastest.  The first global loads of a workgroup's next item
 // are issued before the last chunk of the current one.
 template <int MODE, int SPEC>
-__global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a, const int per TRACE_PARAM) {
+__global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a TRACE_PARAM) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const Rb = smem;                   // [2][R_FLOATS]
     float* const Vb = smem + 2 * R_FLOATS;
@@ -233,7 +233,6 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a, const i
     // Item order: workgroup v (XCD-contiguous numbering) takes items v, v+G, v+2G, ...; neighbours on one XCD thus work
     // on neighbouring items at the same time -- the channel blocks of one patch, then the next patch -- and share the
     // patch (and its halo) through that XCD's L2 instead of each fetching it from HBM at a different time.
-    (void)per;
     const int G = gridDim.x;
     const int first = (int)xcd_remap(blockIdx.x, G);
     const int last = (int)a.total_wg;
@@ -479,20 +478,20 @@ int launch(const ConvArgs& a, hipStream_t st) {
         num_cu = n;
     }
     const int total = (int)a.total_wg;
-    const int per = (total + num_cu - 1) / num_cu;          // items per workgroup (contiguous range)
-    const int grid = (total + per - 1) / per;               // <= one workgroup per CU, none empty
+    const int per = (total + num_cu - 1) / num_cu;          // items per workgroup
+    const int grid = (total + per - 1) / per;               // <= one workgroup per CU, none empty, strided item order
 #ifdef IDIFF_WINO_TRACE
     static long long* tr = nullptr;
     if (!tr) (void)hipMalloc(&tr, 8 * sizeof(long long));
     (void)hipMemsetAsync(tr, 0, 8 * sizeof(long long), st);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, a, per, tr);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, a, tr);
     long long h[8];
     (void)hipMemcpyAsync(h, tr, sizeof(h), hipMemcpyDeviceToHost, st);
     (void)hipStreamSynchronize(st);
     fprintf(stderr, "[wino trace] Cin=%d Cout=%d H=%d items=%d per=%d | fill %lld  loop %lld  prefetch %lld  outsteps %lld  butterfly %lld  barrier %lld  statstore %lld (cycles/item, wave 0)\n", a.Cin,
             a.Cout, a.Hout, total, per, h[0] / total, h[1] / total, h[2] / total, h[3] / total, h[4] / total, h[5] / total, h[6] / total);
 #else
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, a, per);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, a);
 #endif
     IDIFF_CHECK_LAUNCH("conv2d_fwd(winograd)");
     return IDIFF_OK;

@@ -266,7 +266,8 @@ __global__ __launch_bounds__(256) void linear_t_kernel(const float* __restrict__
                                                        const float* __restrict__ bias, const float* __restrict__ res, long long ldr,
                                                        const float* __restrict__ gscale, float* __restrict__ out, long long ldo, int R, int K,
                                                        int N, int act_in, int act_out, long long x_hs, long long w_hs, long long b_hs,
-                                                       long long o_hs) {
+                                                       long long o_hs, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                       float ln_eps) {
     // blockIdx.z = head of a per-head batch (idiff_linear_t_heads_fwd): operands advance by their head strides
     x += blockIdx.z * x_hs;
     wT += blockIdx.z * w_hs;
@@ -284,6 +285,22 @@ __global__ __launch_bounds__(256) void linear_t_kernel(const float* __restrict__
         xs[i] = act_apply_t(x[(long long)rr * ldx + k], act_in);
     }
     __syncthreads();
+    if (ln_g) {
+        // fused LayerNorm of the staged rows (idiff_linear_t_ln_fwd): one 32-lane half-wave per row, two-pass statistics
+        const int row = threadIdx.x >> 5, l = threadIdx.x & 31;
+        float* xr = xs + row * K;
+        float sum = 0.f;
+        for (int k = l; k < K; k += 32) sum += xr[k];
+        const float mean = half_sum(sum) / (float)K;
+        float sq = 0.f;
+        for (int k = l; k < K; k += 32) {
+            const float d = xr[k] - mean;
+            sq += d * d;
+        }
+        const float rstd = rsqrtf(half_sum(sq) / (float)K + ln_eps);
+        for (int k = l; k < K; k += 32) xr[k] = (xr[k] - mean) * rstd * ln_g[k] + ln_b[k];
+        __syncthreads();
+    }
     const int kq = (K + 3) / 4;
     const int k0 = wave * kq, k1 = min(K, k0 + kq);
     float acc[LT_ROWS];
@@ -358,7 +375,7 @@ extern "C" int idiff_smm_memproj_compact_fwd(const float* feat, int64_t feat_bst
 
 static int linear_t_launch(const float* x, int64_t ldx, const float* wT, int64_t ldw, const float* bias, const float* res, int64_t ldr,
                            const float* gscale, float* out, int64_t ldo, int R, int K, int N, int act_in, int act_out, int heads, int64_t x_hs,
-                           int64_t w_hs, int64_t b_hs, int64_t o_hs, idiff_stream_t stream) {
+                           int64_t w_hs, int64_t b_hs, int64_t o_hs, const float* ln_g, const float* ln_b, float ln_eps, idiff_stream_t stream) {
     IDIFF_CHECK_ARG(x && wT && out && R > 0 && K > 0 && N > 0 && heads > 0, "linear_t_fwd: bad args");
     IDIFF_CHECK_ARG(ldx >= K && ldw >= N && ldo >= N, "linear_t_fwd: bad leading dims");
     IDIFF_CHECK_ARG(K <= 8192, "linear_t_fwd: K must be <= 8192 (got %d)", K);
@@ -372,7 +389,7 @@ static int linear_t_launch(const float* x, int64_t ldx, const float* wT, int64_t
     }
     hipLaunchKernelGGL(linear_t_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, (long long)ldx, wT, (long long)ldw, bias, res,
                        (long long)ldr, gscale, out, (long long)ldo, R, K, N, act_in, act_out, (long long)x_hs, (long long)w_hs, (long long)b_hs,
-                       (long long)o_hs);
+                       (long long)o_hs, ln_g, ln_b, ln_eps);
     IDIFF_CHECK_LAUNCH("linear_t_fwd");
     return IDIFF_OK;
 }
@@ -380,12 +397,19 @@ static int linear_t_launch(const float* x, int64_t ldx, const float* wT, int64_t
 extern "C" int idiff_linear_t_fwd(const float* x, int64_t ldx, const float* wT, int64_t ldw, const float* bias, const float* res, int64_t ldr,
                                   const float* gscale, float* out, int64_t ldo, int R, int K, int N, int act_in, int act_out,
                                   idiff_stream_t stream) {
-    return linear_t_launch(x, ldx, wT, ldw, bias, res, ldr, gscale, out, ldo, R, K, N, act_in, act_out, 1, 0, 0, 0, 0, stream);
+    return linear_t_launch(x, ldx, wT, ldw, bias, res, ldr, gscale, out, ldo, R, K, N, act_in, act_out, 1, 0, 0, 0, 0, nullptr, nullptr, 0.f, stream);
+}
+
+extern "C" int idiff_linear_t_ln_fwd(const float* x, int64_t ldx, const float* ln_g, const float* ln_b, float ln_eps, const float* wT, int64_t ldw,
+                                     const float* bias, const float* res, int64_t ldr, const float* gscale, float* out, int64_t ldo, int R, int K,
+                                     int N, int act_out, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(ln_g && ln_b, "linear_t_ln_fwd: null LayerNorm parameters");
+    return linear_t_launch(x, ldx, wT, ldw, bias, res, ldr, gscale, out, ldo, R, K, N, IDIFF_ACT_NONE, act_out, 1, 0, 0, 0, 0, ln_g, ln_b, ln_eps, stream);
 }
 
 extern "C" int idiff_linear_t_heads_fwd(const float* x, int64_t ldx, int64_t x_hs, const float* wT, int64_t ldw, int64_t w_hs, const float* bias,
                                         int64_t b_hs, float* out, int64_t ldo, int64_t o_hs, int R, int K, int N, int heads,
                                         idiff_stream_t stream) {
     return linear_t_launch(x, ldx, wT, ldw, bias, nullptr, 0, nullptr, out, ldo, R, K, N, IDIFF_ACT_NONE, IDIFF_ACT_NONE, heads, x_hs, w_hs, b_hs,
-                           o_hs, stream);
+                           o_hs, nullptr, nullptr, 0.f, stream);
 }

@@ -195,19 +195,17 @@ class ScoreMapModule(nn.Module):
         else:
             mem = ops.smm_memproj(feat, mp[0].weight, mp[0].bias, wmp, mp[1].bias, mp[2].weight, mp[2].bias, eps=mp[0].eps)
         tp = dec.text_proj
-        x = ops.linear_t(ops.layernorm_rows(t2d, tp[0].weight, tp[0].bias), wT(tp[1]), tp[1].bias)  # [B*K, Wd]
+        x = ops.linear_t(t2d, wT(tp[1]), tp[1].bias, ln=(tp[0].weight, tp[0].bias, tp[0].eps))  # LayerNorm fused; [B*K, Wd]
         for li, layer in enumerate(dec.decoder):
             sa, ca = layer.self_attn, layer.cross_attn
             wqkvT = _PREP.get(("qkvT", sa), (sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight),
                               lambda: torch.cat([sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight], 0).detach().t().contiguous())
-            n1 = ops.layernorm_rows(x, layer.norm1.weight, layer.norm1.bias)
-            qkv = ops.linear_t(n1, wqkvT).reshape(B, K, 3 * Wd)
+            qkv = ops.linear_t(x, wqkvT, ln=(layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)).reshape(B, K, 3 * Wd)
             a = ops.attn_tokens_packed(qkv, heads, sa.scale)
             x = ops.linear_t(a.reshape(B * K, Wd), wT(sa.proj), sa.proj.bias, res=x)
             # cross attention, k/v projections folded onto the (few) queries:
             #   qf[:, h, :] = q_h @ Wk[h*dh:(h+1)*dh, :]   (Wk's row block IS the transposed-weight form [K=dh][N=Wd])
-            n2 = ops.layernorm_rows(x, layer.norm2.weight, layer.norm2.bias)
-            qc = ops.linear_t(n2, wT(ca.q_proj))
+            qc = ops.linear_t(x, wT(ca.q_proj), ln=(layer.norm2.weight, layer.norm2.bias, layer.norm2.eps))
             if compact:
                 wkf, wvf, bvf = _PREP.get(("xfold", ca, Cm), (mp[1].weight, mp[1].bias, mp[2].weight, mp[2].bias, ca.k_proj.weight, ca.v_proj.weight),
                                           lambda: _fold_memory_affine(mp[1], mp[2], ca, Cm))
@@ -221,12 +219,11 @@ class ScoreMapModule(nn.Module):
             av = torch.empty((B * K, Wd), device=feat.device, dtype=torch.float32)
             ops.linear_t_heads(o, wvf, bvf, av, heads, Cm, dh, x_hs=Cm, w_hs=dh, b_hs=dh, o_hs=dh)
             x = ops.linear_t(av, wT(ca.proj), ca.proj.bias, res=x)
-            n3 = ops.layernorm_rows(x, layer.norm3.weight, layer.norm3.bias)
-            hm = ops.linear_t(n3, wT(layer.mlp[0]), layer.mlp[0].bias, act_out=ops.ACT_GELU)
+            hm = ops.linear_t(x, wT(layer.mlp[0]), layer.mlp[0].bias, act_out=ops.ACT_GELU, ln=(layer.norm3.weight, layer.norm3.bias, layer.norm3.eps))
             x = ops.linear_t(hm, wT(layer.mlp[3]), layer.mlp[3].bias, res=x)
         op = dec.out_proj
         t2v = ops.linear_t(t2d, wT(self.text_to_visual), self.text_to_visual.bias)
-        tv = ops.linear_t(ops.layernorm_rows(x, op[0].weight, op[0].bias), wT(op[1]), op[1].bias, res=t2v, gscale=self.gamma)
+        tv = ops.linear_t(x, wT(op[1]), op[1].bias, res=t2v, gscale=self.gamma, ln=(op[0].weight, op[0].bias, op[0].eps))
         return ops.scoremap(feat, tv.reshape(B, K, C), idx)
 
 

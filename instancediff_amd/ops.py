@@ -184,8 +184,9 @@ def linear(x, w, bias=None, res=None, gscale=None, act_in=ACT_NONE, act_out=ACT_
     return out
 
 
-def linear_t(x, wT, bias=None, res=None, gscale=None, act_in=ACT_NONE, act_out=ACT_NONE, out=None):
-    """x [R,K] (row-strided ok), wT [K,N] PRE-TRANSPOSED weight (row-strided ok) -> [R,N]."""
+def linear_t(x, wT, bias=None, res=None, gscale=None, act_in=ACT_NONE, act_out=ACT_NONE, out=None, ln=None):
+    """x [R,K] (row-strided ok), wT [K,N] PRE-TRANSPOSED weight (row-strided ok) -> [R,N].
+    ln = (gamma, beta, eps): LayerNorm(x) over K fused in front of the product (no act_in then)."""
     lib = _lib.load()
     _chk(x, "x"), _chk(wT, "wT")
     assert x.dim() == 2 and wT.dim() == 2 and x.stride(1) == 1 and wT.stride(1) == 1 and x.shape[1] == wT.shape[0]
@@ -196,6 +197,12 @@ def linear_t(x, wT, bias=None, res=None, gscale=None, act_in=ACT_NONE, act_out=A
     assert out.stride(1) == 1 and tuple(out.shape) == (R, N)
     if res is not None:
         assert res.stride(1) == 1 and tuple(res.shape) == (R, N)
+    if ln is not None:
+        assert act_in == ACT_NONE
+        check(lib.idiff_linear_t_ln_fwd(_p(x), x.stride(0), _p(_c(ln[0])), _p(_c(ln[1])), float(ln[2]), _p(wT), wT.stride(0), _p(_c(bias)), _p(res),
+                                        res.stride(0) if res is not None else 0, _p(_c(gscale)), _p(out), out.stride(0), R, K, N, act_out,
+                                        _stream()), "linear_t_ln_fwd")
+        return out
     check(lib.idiff_linear_t_fwd(_p(x), x.stride(0), _p(wT), wT.stride(0), _p(_c(bias)), _p(res), res.stride(0) if res is not None else 0,
                                  _p(_c(gscale)), _p(out), out.stride(0), R, K, N, act_in, act_out, _stream()), "linear_t_fwd")
     return out

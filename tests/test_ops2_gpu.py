@@ -176,3 +176,17 @@ def test_conv3x3_select_equals_conv_then_gather(B, C, K, H, W):
     ref = full[torch.arange(B), idx.long()][:, None]
     out = ops.conv3x3_select(x.to(DEV), w.to(DEV), bias.to(DEV), idx.to(DEV))
     _close(out, ref, 3e-6, "conv3x3_select")
+
+
+@pytest.mark.parametrize("R,K,N", [(80, 256, 768), (13, 512, 256), (5, 64, 72)])
+def test_linear_t_fused_layernorm(R, K, N):
+    g = torch.Generator().manual_seed(52)
+    x = torch.randn(R, K, generator=g) * 2 + 0.5
+    gam, bet = torch.randn(K, generator=g), torch.randn(K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    res = torch.randn(R, N, generator=g)
+    ref = F.gelu(res.double() + F.layer_norm(x.double(), (K,), gam.double(), bet.double(), 1e-5) @ w.double().T + b.double())
+    out = ops.linear_t(x.to(DEV), w.t().contiguous().to(DEV), b.to(DEV), res=res.to(DEV), act_out=ops.ACT_GELU,
+                       ln=(gam.to(DEV), bet.to(DEV), 1e-5))
+    _close(out, ref, 5e-6, "linear_t + LayerNorm")
