@@ -6,15 +6,19 @@
 //   subtract (the 0.5 factors live in the pre-transformed weights), so the result differs from the direct kernel by
 //   a few ulps of reassociation, the same class of difference as cuDNN's fp32 Winograd algorithms.
 //
-//   Workgroup = 512 threads (8 waves, 2 per SIMD), one 8x32-pixel output patch (4x16 tiles of 2x2) x 64 output
-//   channels of one sample.  Per chunk of 8 input channels:
-//     R  [8][10x34 (+pad)]            activated, zero-padded input patch with halo           (LDS, single buffer)
+//   Persistent workgroups of 512 threads (8 waves, 2 per SIMD), one per CU; an item = one 8x32-pixel output patch
+//   (4x16 tiles of 2x2) x 64 output channels of one sample (a partial last channel block when Cout % 64 = 16..48).
+//   Per chunk of 8 input channels:
+//     R  [8][10x34 (+pad)]            activated, zero-padded input patch with halo           (LDS, double buffer)
 //     V  [16 xi][4 tile-rows][4 k][16 tiles][2]   B^T d B of that patch                      (LDS, double buffer)
 //     U  [16 xi][4 co-blocks][4 k][16 co][2]      pre-transformed weights, copied verbatim   (LDS, double buffer)
 //   wave (ch, tb) owns 32 output channels x the 16 tiles of tile-row tb x all 16 xi = 128 accumulator registers, so
-//   the output transform A^T m A is purely in-lane.  Two barriers per chunk: [MFMA xi 0..7 | stage R,U of chunk c+1]
-//   barrier [MFMA xi 8..15 | transform R -> V of chunk c+1, issue global loads of chunk c+2] barrier.
-//   Every LDS access of the MFMA phase is a unit-stride ds_read_b64 (512 contiguous bytes per wave).
+//   the output transform A^T m A is purely in-lane.  ONE barrier per chunk: while the 16 positions of chunk c run on
+//   the matrix cores, the raw patch of chunk c+2 is staged, the weights of chunk c+1 copied, the patch of chunk c+1
+//   transformed and the loads of chunks c+3 / c+2 issued -- one slice per position, fenced with sched_barrier.
+//   Every LDS access of the MFMA phase is a unit-stride ds_read_b64 (512 contiguous bytes per wave).  The f32 MFMA
+//   shares the vector ALU, so the loop is kept nearly VALU-free (raw buffer loads, immediate LDS offsets, uniform
+//   transform roles); see DESIGN.md 5a.
 //
 //   Same fused gather (virtual concat, nearest x2 upsample, GroupNorm/FiLM affine + SiLU prologue) and the same
 //   epilogue contract (bias, residual, per-(b,c) vector, "+silu(a*aux+b)", GroupNorm partials per 8x32 patch) as
