@@ -41,8 +41,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=1)
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--mode", choices=["sample", "train"], default="sample",
-                    help="sample = headline denoising-steps/s metric; train = secondary training-iterations/s line")
+    ap.add_argument("--mode", choices=["sample", "train", "irsde"], default="sample",
+                    help="sample = headline denoising-steps/s metric (driftSDE: 2 UNet forwards + update per step); train = secondary "
+                         "training-iterations/s line; irsde = secondary line for the IRSDE single-network loop (1 UNet forward + reverse_sde_step)")
     return ap.parse_args()
 
 
@@ -209,6 +210,65 @@ def train_bench(args, world, rank, dev):
         dist.destroy_process_group()
 
 
+def irsde_bench(args, world, rank, dev):
+    """IRSDE single-network mode (utils/sde_utils.py:244-261): one step = noise_net forward (as IRSDE's `model(x, mu, t)`) +
+    the fused reverse_sde_step; same synthetic batch, T and batch as the headline line.  Secondary line."""
+    import torch.distributed as dist
+    from instancediff_amd import pipeline
+    from instancediff_amd.utils.sde_utils import IRSDE
+    from instancediff_amd.utils.synthetic import make_batch
+    model, _ = pipeline.build(phase="test", device=dev, T=args.T, seed=0)
+    model.set_eval()
+    batch = make_batch(args.batch, args.size, seed=1234 + rank, mixed=True)
+    lq = batch['input'].to(dev).contiguous()
+    ctx = batch['A_emb'].to(dev).contiguous()
+    sde = IRSDE(max_sigma=0.4, T=args.T, schedule='cosine', device=dev)
+    sde.set_mu(lq)
+    net = model.noise_net
+    sde.set_model(lambda x, mu, t, **kw: net(x, mu, torch.full((x.shape[0],), float(t), device=dev), batch['names'], model.text_encoder,
+                                             image_context=ctx))
+    state = {"x": sde.noise_state(lq), "t": args.T}
+
+    @torch.no_grad()
+    def step():
+        t = state["t"]
+        noise = sde.noise_fn(state["x"], t, sde.sample_scale)
+        noise = noise[0] if isinstance(noise, tuple) else noise
+        state["x"] = sde.reverse_sde_step(state["x"], noise, t)
+        state["t"] = t - 1 if t > 1 else args.T
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        el = float(tmax.item())
+    assert torch.isfinite(state["x"]).all()
+    if rank == 0:
+        value = world * args.steps / el
+        print(json.dumps({"metric": "IRSDE denoising steps/sec (%dx%d bs%d)" % (args.size, args.size, args.batch), "value": round(value, 4),
+                          "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "%dx%d 1-ch synthetic, IRSDE reverse_sde, batch %d per GPU, 1 UNet fwd + reverse_sde_step per step"
+                                                 % (args.size, args.size, args.batch),
+                                     "global_batch": args.batch * world, "parallelism": "replicas x%d (no collective)" % world}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -229,6 +289,8 @@ def main():
 
     if args.mode == "train":
         return train_bench(args, world, rank, dev)
+    if args.mode == "irsde":
+        return irsde_bench(args, world, rank, dev)
 
     model, sde = pipeline.build(phase="test", device=dev, T=args.T, seed=0)
     model.set_eval()
