@@ -365,7 +365,7 @@ def main():
 
     if rank == 0:
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only: the other ranks of a multi-GPU run must not wait on it
             log("cpu baseline (oracle) ...")
             try:
                 cpu = cpu_baseline(args, batch)
