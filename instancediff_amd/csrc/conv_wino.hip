@@ -557,7 +557,7 @@ bool conv_wino_eligible(const ConvArgs& a, int ks, int mode) {
     if (a.Cout % 16 || a.Cin % CK || a.C0v % CK || a.Hout % TH || a.Wout % TW) return false;
     if (mode == IDIFF_CONV_UPSAMPLE2 && (a.pro_a || a.src1)) return false;
     if (a.pro_a && a.src1) return false;
-    if (a.pro_a && a.C0r > 512) return false;  // two prologue tables of 2*C0r floats must fit beside the 156 KB of tiles
+    if (a.pro_a && ((size_t)2 * R_FLOATS + 2 * V_FLOATS + 2 * U_FLOATS + 256 + 4 * (size_t)a.C0r) * sizeof(float) > 160 * 1024) return false;  // LDS
     if ((reinterpret_cast<uintptr_t>(a.wwino) & 15) != 0) return false;
     // float2 epilogue accesses: even row pitch is implied by Wout % 32; batch strides must keep 8-byte alignment
     if ((a.obs & 1) || (a.res && (a.rbs & 1)) || (a.aux && (a.abs_ & 1))) return false;
