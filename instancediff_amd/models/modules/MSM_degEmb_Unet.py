@@ -194,9 +194,14 @@ class ScoreMapModule(nn.Module):
             mem = ops.smm_memproj_compact(feat, mp[0].weight, mp[0].bias, gram, hvec, evar, Cm, eps1=mp[0].eps, eps2=mp[2].eps)
         else:
             mem = ops.smm_memproj(feat, mp[0].weight, mp[0].bias, wmp, mp[1].bias, mp[2].weight, mp[2].bias, eps=mp[0].eps)
-        tp = dec.text_proj
-        x = ops.linear_t(t2d, wT(tp[1]), tp[1].bias, ln=(tp[0].weight, tp[0].bias, tp[0].eps))  # LayerNorm fused; [B*K, Wd]
-        for li, layer in enumerate(dec.decoder):
+        def fold_weights(ca):
+            if compact:
+                return _PREP.get(("xfold", ca, Cm), (mp[1].weight, mp[1].bias, mp[2].weight, mp[2].bias, ca.k_proj.weight, ca.v_proj.weight),
+                                 lambda: _fold_memory_affine(mp[1], mp[2], ca, Cm))
+            return ca.k_proj.weight, wT(ca.v_proj), None  # [Wd(dh blocks), Wd], [Wd (c), Wd (n)]
+
+        def self_attn_and_query(x, layer):
+            """x -> (x + self-attention, folded cross-attention queries qf [B*K, heads*Cm]); nothing here sees the image"""
             sa, ca = layer.self_attn, layer.cross_attn
             wqkvT = _PREP.get(("qkvT", sa), (sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight),
                               lambda: torch.cat([sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight], 0).detach().t().contiguous())
@@ -206,14 +211,34 @@ class ScoreMapModule(nn.Module):
             # cross attention, k/v projections folded onto the (few) queries:
             #   qf[:, h, :] = q_h @ Wk[h*dh:(h+1)*dh, :]   (Wk's row block IS the transposed-weight form [K=dh][N=Wd])
             qc = ops.linear_t(x, wT(ca.q_proj), ln=(layer.norm2.weight, layer.norm2.bias, layer.norm2.eps))
-            if compact:
-                wkf, wvf, bvf = _PREP.get(("xfold", ca, Cm), (mp[1].weight, mp[1].bias, mp[2].weight, mp[2].bias, ca.k_proj.weight, ca.v_proj.weight),
-                                          lambda: _fold_memory_affine(mp[1], mp[2], ca, Cm))
-            else:
-                wkf, wvf, bvf = ca.k_proj.weight, wT(ca.v_proj), None  # [Wd(dh blocks), Wd], [Wd (c), Wd (n)]
+            wkf = fold_weights(ca)[0]
             # per head: qf[:, h-block] = qc[:, h-block] @ wkf[h row block]  ([dh, Cm]);  one launch for all heads
             qf = torch.empty((B * K, heads * Cm), device=feat.device, dtype=torch.float32)
             ops.linear_t_heads(qc, wkf, None, qf, heads, dh, Cm, x_hs=dh, w_hs=dh * wkf.stride(0), b_hs=0, o_hs=Cm)
+            return x, qf
+
+        def text_prefix():
+            """Everything up to the first cross-attention depends on the text embeddings and weights only: text_proj, the
+            first layer's self-attention and folded queries, and text_to_visual.  Cached across denoising steps."""
+            tp = dec.text_proj
+            x0 = ops.linear_t(t2d, wT(tp[1]), tp[1].bias, ln=(tp[0].weight, tp[0].bias, tp[0].eps))  # LayerNorm fused; [B*K, Wd]
+            x1, qf1 = self_attn_and_query(x0, dec.decoder[0])
+            return x1, qf1, ops.linear_t(t2d, wT(self.text_to_visual), self.text_to_visual.bias)
+
+        l0 = dec.decoder[0]
+        prefix_params = [text, dec.text_proj[0].weight, dec.text_proj[0].bias, dec.text_proj[1].weight, dec.text_proj[1].bias,
+                         l0.norm1.weight, l0.norm1.bias, l0.self_attn.q_proj.weight, l0.self_attn.k_proj.weight, l0.self_attn.v_proj.weight,
+                         l0.self_attn.proj.weight, l0.self_attn.proj.bias, l0.norm2.weight, l0.norm2.bias, l0.cross_attn.q_proj.weight,
+                         l0.cross_attn.k_proj.weight, mp[1].weight, mp[1].bias, mp[2].weight, self.text_to_visual.weight, self.text_to_visual.bias]
+        if torch.is_grad_enabled():
+            x, qf, t2v = text_prefix()
+        else:
+            x, qf, t2v = _PREP.get(("prefix", self, Cm), prefix_params, text_prefix)
+        for li, layer in enumerate(dec.decoder):
+            ca = layer.cross_attn
+            if li > 0:
+                x, qf = self_attn_and_query(x, layer)
+            _, wvf, bvf = fold_weights(ca)
             o = ops.smm_xattn(qf.reshape(B, K, heads, Cm), mem, ca.scale).reshape(B * K, heads * Cm)
             # per head: av[:, h-block] = o[:, h-block] @ wvf[:, h column block] (+ bvf[h-block])  ([Cm, dh])
             av = torch.empty((B * K, Wd), device=feat.device, dtype=torch.float32)
@@ -222,7 +247,6 @@ class ScoreMapModule(nn.Module):
             hm = ops.linear_t(x, wT(layer.mlp[0]), layer.mlp[0].bias, act_out=ops.ACT_GELU, ln=(layer.norm3.weight, layer.norm3.bias, layer.norm3.eps))
             x = ops.linear_t(hm, wT(layer.mlp[3]), layer.mlp[3].bias, res=x)
         op = dec.out_proj
-        t2v = ops.linear_t(t2d, wT(self.text_to_visual), self.text_to_visual.bias)
         tv = ops.linear_t(x, wT(op[1]), op[1].bias, res=t2v, gscale=self.gamma, ln=(op[0].weight, op[0].bias, op[0].eps))
         return ops.scoremap(feat, tv.reshape(B, K, C), idx)
 
