@@ -377,3 +377,37 @@ def test_conv_winograd_data_gradient_pack():
     dx_d = ops.conv2d(dy.to(DEV), _pack(wd, False, transpose=True), None, 3, Cin)
     _close(dx_d, ref, 2e-6, "direct dgrad")
     _close(dx_w, ref, 6e-6, "winograd dgrad")
+
+
+def test_conv_winograd_random_shapes_match_direct():
+    """Seeded sweep over the Winograd kernel's eligibility lattice (channel blocks, patch grid, gather variants, epilogue
+    terms): the two kernels behind idiff_conv2d_fwd must agree everywhere."""
+    rng = np.random.RandomState(7)
+    lib = ops._lib.load()
+    for case in range(24):
+        B = int(rng.randint(1, 4))
+        C0 = 8 * int(rng.randint(1, 13))
+        two = bool(rng.randint(0, 2)) and case % 3 == 1
+        C1 = 8 * int(rng.randint(1, 7)) if two else 0
+        Cout = 16 * int(rng.randint(1, 13))
+        H = 8 * int(rng.randint(1, 4))
+        W = 32 * int(rng.randint(1, 4))
+        pro = (not two) and case % 3 == 2
+        g = _g(100 + case)
+        x0 = torch.randn(B, C0, H, W, generator=g).to(DEV)
+        x1 = torch.randn(B, C1, H, W, generator=g).to(DEV) if two else None
+        w = (torch.randn(Cout, C0 + C1, 3, 3, generator=g) / math.sqrt(9 * (C0 + C1))).to(DEV)
+        bias = torch.randn(Cout, generator=g).to(DEV)
+        kw = {}
+        if pro:
+            kw["pro"] = (torch.randn(B, C0, generator=g).to(DEV), torch.randn(B, C0, generator=g).to(DEV))
+        if case % 2:
+            kw["res"] = torch.randn(B, Cout, H, W, generator=g).to(DEV)
+            kw["vec"] = torch.randn(B, Cout, generator=g).to(DEV)
+        if case % 4 == 0:
+            kw["aux"] = (torch.randn(B, Cout, H, W, generator=g).to(DEV), torch.randn(B, Cout, generator=g).to(DEV), torch.randn(B, Cout, generator=g).to(DEV))
+        ow, sw = ops.conv2d(x0, _pack(w, True), bias, 3, Cout, src1=x1, want_stats=True, **kw)
+        assert lib.idiff_conv2d_last_algo() == 1, (case, B, C0, C1, Cout, H, W)
+        od, sd = ops.conv2d(x0, _pack(w, False), bias, 3, Cout, src1=x1, want_stats=True, **kw)
+        _close(ow, od.cpu(), 8e-6, f"case {case}: B={B} C0={C0} C1={C1} Cout={Cout} H={H} W={W} pro={pro}")
+        _close(sw, sd.cpu(), 3e-5, f"case {case}: stats")

@@ -338,3 +338,26 @@ def test_conv_wgrad_streaming_1x1_vs_fp64(B, C0, C1, Cout, H, W):
     dw = T.conv2d_wgrad(x0.to(DEV), None if x1 is None else x1.to(DEV), ops.CONV_NORMAL, 1, dy.to(DEV), Cin)
     assert ops._lib.load().idiff_conv2d_wgrad_last_algo() == 2, "the streaming 1x1 weight-gradient kernel did not run"
     assert _rel(dw, ref) < 5e-6
+
+
+def test_conv_wgrad_winograd_random_shapes_vs_fp64():
+    rng = __import__("numpy").random.RandomState(9)
+    lib = ops._lib.load()
+    for case in range(10):
+        B = int(rng.randint(1, 4))
+        two = case % 3 == 1
+        C0 = 64 * int(rng.randint(1, 3)) if two else 16 * int(rng.randint(1, 9))
+        C1 = 16 * int(rng.randint(1, 5)) if two else 0
+        Cout = 64 * int(rng.randint(1, 3))
+        H, W = 2 * int(rng.randint(1, 9)), 16 * int(rng.randint(1, 4))
+        g = _g(200 + case)
+        x0 = torch.randn(B, C0, H, W, generator=g)
+        x1 = torch.randn(B, C1, H, W, generator=g) if two else None
+        xin = x0.double() if x1 is None else torch.cat([x0, x1], 1).double()
+        w = torch.zeros(Cout, C0 + C1, 3, 3, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(xin, w, None, padding=1)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy.double())
+        dw = T.conv2d_wgrad(x0.to(DEV), None if x1 is None else x1.to(DEV), ops.CONV_NORMAL, 3, dy.to(DEV), C0 + C1)
+        assert lib.idiff_conv2d_wgrad_last_algo() == 1, (case, B, C0, C1, Cout, H, W)
+        assert _rel(dw, w.grad) < 1e-5, (case, B, C0, C1, Cout, H, W)
