@@ -53,6 +53,30 @@ def test_c1_drift_chain_psnr_parity():
         assert abs(sde_ref.psnr(out[b], batch['target'][b]) - sde_ref.psnr(ref[b], batch['target'][b])) < 1e-3
 
 
+def test_c2_shape_short_chain_psnr_parity():
+    """The headline shape itself (256x256: Winograd convs at all four levels, compact ScoreMapModule memory at two, flattened
+    1x1 convs, fused output layer, two streams) on one image and a 3-step chain -- what the oracle finishes in seconds."""
+    T, B, H = 3, 1, 256
+    model, sde = pipeline.build(phase="test", device=torch.device(DEV), T=T, seed=0)
+    model.set_eval()
+    batch = make_batch(B, H, seed=77)
+    g = torch.Generator().manual_seed(78)
+    x_T = batch['input'] + 0.4 * torch.randn(batch['input'].shape, generator=g)
+    noises = torch.randn((T,) + tuple(batch['input'].shape), generator=g)
+    model.feed_data(batch)
+    model.test(x_T=x_T.to(DEV), noises=noises.to(DEV))
+    out = torch.from_numpy(model.get_visuals())
+    refs = oracle_nets(model)
+    rsde = sde_ref.DriftSDERef(T, refs[0], refs[1], max_sigma=0.4)
+    with torch.no_grad():
+        ref = rsde.reverse_ddpm(batch['input'], batch['names'], unet_ref.StubTextEncoder(), x_T, noises, image_context=batch['A_emb'])
+    p_hip, p_ref = sde_ref.psnr(out, batch['target']), sde_ref.psnr(ref, batch['target'])
+    err = float((out - ref).abs().max())
+    print(f"c2 shape: PSNR hip {p_hip:.6f} dB, oracle {p_ref:.6f} dB, max|diff| {err:.3e}")
+    assert abs(p_hip - p_ref) < 1e-3
+    assert err < 5e-4
+
+
 def test_irsde_single_network_mode_parity():
     """utils/sde_utils.py:244-261 loop with the noise network as `model(x, mu, t, **kw)` (t arrives as a python
     float = t*sample_scale), sample_T < T fast sampling, injected noise."""
