@@ -48,35 +48,34 @@ def parse():
 
 
 class StepRunner:
-    """The body of driftSDE.reverse_ddpm's loop, one iteration per call (same kernels, same order)."""
+    """The product's loop body -- driftSDE.Stepper, the object reverse_ddpm itself runs: two UNet forwards on two HIP streams, the
+    fused update and the device-side state advance, replayed as one captured HIP graph per step (IDIFF_HIP_GRAPH=0: eager)."""
 
     def __init__(self, model, sde, batch):
         from instancediff_amd import ops
+        from instancediff_amd.models.SDEs.driftSDE import driftSDE
         self.ops, self.model, self.sde = ops, model, sde
         dev = model.device
-        self.cond = batch['input'].to(dev).contiguous()
-        self.names = batch['names']
-        self.ctx = batch['A_emb'].to(dev).contiguous()
-        self.x = ops.axpby(self.cond, ops.randn(self.cond.shape, dev, 4321, 0), 1.0, sde.max_sigma)
-        self.xa = ops.axpby(self.x, self.cond, 1.0, -1.0)
-        self.x2, self.xa2 = torch.empty_like(self.x), torch.empty_like(self.x)
-        self.tdev = torch.empty((self.cond.shape[0],), dtype=torch.float32, device=dev)
-        self.t = sde.T
-        self.calls = 1
+        cond = batch['input'].to(dev).contiguous()
+        ctx = batch['A_emb'].to(dev).contiguous()
+        sde.set_seed(4321)
+        x = ops.axpby(cond, sde._randn_like(cond), 1.0, sde.max_sigma)
+        self.stepper = driftSDE.Stepper(sde, x, cond, batch['names'], model.text_encoder, ctx)
+
+    @property
+    def x(self):
+        return self.stepper.x
+
+    def prepare(self):
+        return self.stepper.prepare()
+
+    def run(self, n):
+        return self.stepper.run(n)
 
     @torch.no_grad()
     def step(self):
-        sde, m, ops = self.sde, self.model, self.ops
-        t = self.t
-        self.tdev.fill_(float(t))
-        r_hat, e_hat = sde.predict(self.xa, self.x, self.cond, self.tdev, self.names, m.text_encoder, self.ctx)
-        off = self.calls * ((self.x.numel() + 3) // 4)
-        self.calls += 1
-        ops.drift_reverse_step(self.x, r_hat, e_hat, None, float(sde._a[t]), float(sde._b[t]), float(sde._c[t]), cond=self.cond, seed=4321,
-                               offset=off, out=self.x2, xa_out=self.xa2)
-        self.x, self.x2 = self.x2, self.x
-        self.xa, self.xa2 = self.xa2, self.xa
-        self.t = t - 1 if t > 1 else sde.T
+        """one eager step (profiling passes)"""
+        self.stepper._body()
 
 
 def host_cores():
@@ -304,14 +303,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    log("model built; warmup")
-    for _ in range(args.warmup):
-        run.step()
+    log("model built; graph capture + warmup")
+    run.prepare()  # one eager step + HIP-graph capture of the step (untimed)
+    if args.warmup:
+        run.run(args.warmup)
     barrier()
     log("warmup done; timing %d steps" % args.steps)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run.step()
+    run.run(args.steps)
     barrier()
     el = time.perf_counter() - t0
     if world > 1:
@@ -329,9 +328,8 @@ def main():
         two = sde.two_streams
         sde.two_streams = False
         ops.PROFILE = []
-        run.t = sde.T - args.warmup if sde.T > args.warmup else sde.T
         for _ in range(args.steps):
-            run.step()
+            run.step()  # eager: per-launch events cannot be recorded inside a graph replay
         torch.cuda.synchronize()
         sde.two_streams = two
         # dominant kernel = conv_wino_kernel: every 3x3 conv whose shape tiles exactly (idiff_conv2d_last_algo() == 1)

@@ -225,6 +225,16 @@ int idiff_irsde_reverse_step(const float* x, const float* mu, const float* noise
 int idiff_drift_reverse_step(const float* x, const float* r_hat, const float* e_hat, const float* z, const float* cond,
                              float* x_out, float* xa_out, int64_t n, float a, float b, float c, uint64_t seed,
                              uint64_t offset, idiff_stream_t stream);
+/* Graph-replayable drift step: all per-step scalars live in device memory, so ONE captured HIP graph of a denoising step
+ * (two UNet forwards + this update + idiff_step_state_advance) replays for every t with no host input in between.
+ *   state int32[3] = {t, Philox call count, step index of this run};  coef float[3][Tp1] = tables of (a_t, b_t, c_t);
+ *   a, b, c = coef[.][t];  Philox offset = state[1]*nper;  z_base (optional, parity runs) [steps][n] indexed by state[2].
+ * In place:  x <- ((x - a*r_hat) - b*e_hat) + c*z ;  xa <- x - cond.   Same fp32 operation order as idiff_drift_reverse_step. */
+int idiff_drift_reverse_step_dev(float* x, const float* r_hat, const float* e_hat, const float* z_base, const float* cond,
+                                 float* xa, int64_t n, const float* coef, int Tp1, const int32_t* state, uint64_t seed,
+                                 uint64_t nper, idiff_stream_t stream);
+/* t <- t-1 (back to T once t <= t_stop), both counters += 1, tdev[0..B) = (float)t   (the UNets' timestep input) */
+int idiff_step_state_advance(int32_t* state, float* tdev, int B, int T, int t_stop, idiff_stream_t stream);
 /* standard normals (Philox4x32-10, Box-Muller), element i uses counter (offset + i/4) lane i%4 */
 int idiff_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, idiff_stream_t stream);
 /* raw Philox4x32-10 words for tests: out[4*i..4*i+3] = philox(counter = offset+i, key = seed) */

@@ -124,6 +124,53 @@ __global__ __launch_bounds__(256) void drift_step_kernel(const float* __restrict
     }
 }
 
+// Graph-replayable form of the drift step: every per-step scalar comes from device memory, so ONE captured HIP graph of a
+// denoising step replays for every t.  state = {t, Philox call count, step index of this run}; coef = [3][Tp1] tables of
+// (a_t, b_t, c_t); injected noise (parity runs) is indexed by the step index.  In place: x <- update, xa <- x - cond
+// (element-wise, each thread reads before it writes its own element).  Same fp32 operation order as drift_step_kernel.
+__global__ __launch_bounds__(256) void drift_step_dev_kernel(float* x, const float* __restrict__ rh, const float* __restrict__ eh,
+                                                             const float* __restrict__ zbase, const float* __restrict__ cond, float* xa, long long n,
+                                                             const float* __restrict__ coef, int Tp1, const int* __restrict__ state, uint64_t seed,
+                                                             uint64_t nper) {
+    const int t = state[0];
+    const float a = coef[t], b = coef[Tp1 + t], c = coef[2 * Tp1 + t];
+    const uint64_t offset = (uint64_t)(unsigned)state[1] * nper;
+    const float* z = zbase ? zbase + (long long)state[2] * n : nullptr;
+    const long long nv = (n + 3) / 4;
+    for (long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x; v < nv; v += (long long)gridDim.x * blockDim.x) {
+        const long long i = v * 4;
+        const floatx4 xv = ld4(x, i, n), rv = ld4(rh, i, n), ev = ld4(eh, i, n);
+        floatx4 zv = {0.f, 0.f, 0.f, 0.f};
+        if (c != 0.f) zv = z ? ld4(z, i, n) : philox_normal4(offset + (uint64_t)v, seed);
+        const floatx4 cv = ld4(cond, i, n);
+        floatx4 o, oa;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float r = __fsub_rn(xv[k], __fmul_rn(a, rv[k]));
+            r = __fsub_rn(r, __fmul_rn(b, ev[k]));
+            r = __fadd_rn(r, __fmul_rn(c, zv[k]));
+            o[k] = r;
+            oa[k] = __fsub_rn(r, cv[k]);
+        }
+        st4(x, i, n, o);
+        st4(xa, i, n, oa);
+    }
+}
+
+// t <- t-1 (wrapping to T below t_stop+1, for benchmark loops), counters += 1, tdev[:] = t  -- the host never touches a
+// per-step scalar between graph replays
+__global__ void step_state_advance_kernel(int* state, float* tdev, int B, int T, int t_stop) {
+    int t = state[0] - 1;
+    if (t <= t_stop) t = T;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) tdev[i] = (float)t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        state[0] = t;
+        state[1] += 1;
+        state[2] += 1;
+    }
+}
+
 __global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, long long n, uint64_t seed, uint64_t offset) {
     const long long nv = (n + 3) / 4;
     for (long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x; v < nv; v += (long long)gridDim.x * blockDim.x)
@@ -203,6 +250,23 @@ extern "C" int idiff_drift_reverse_step(const float* x, const float* r_hat, cons
     hipLaunchKernelGGL(drift_step_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, r_hat, e_hat, z, cond, x_out,
                        xa_out, (long long)n, a, b, c, seed, offset);
     IDIFF_CHECK_LAUNCH("drift_reverse_step");
+    return IDIFF_OK;
+}
+
+extern "C" int idiff_drift_reverse_step_dev(float* x, const float* r_hat, const float* e_hat, const float* z_base, const float* cond, float* xa,
+                                            int64_t n, const float* coef, int Tp1, const int32_t* state, uint64_t seed, uint64_t nper,
+                                            idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(x && r_hat && e_hat && cond && xa && coef && state && n > 0 && Tp1 > 1, "drift_reverse_step_dev: bad args");
+    hipLaunchKernelGGL(drift_step_dev_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, r_hat, e_hat, z_base, cond, xa,
+                       (long long)n, coef, Tp1, state, seed, nper);
+    IDIFF_CHECK_LAUNCH("drift_reverse_step_dev");
+    return IDIFF_OK;
+}
+
+extern "C" int idiff_step_state_advance(int32_t* state, float* tdev, int B, int T, int t_stop, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(state && tdev && B > 0 && T > 0 && t_stop >= 0 && t_stop < T, "step_state_advance: bad args");
+    hipLaunchKernelGGL(step_state_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, tdev, B, T, t_stop);
+    IDIFF_CHECK_LAUNCH("step_state_advance");
     return IDIFF_OK;
 }
 

@@ -73,6 +73,7 @@ class driftSDE:
         self.seed = 0
         self._calls = 0
         self.two_streams = bool(int(os.environ.get("IDIFF_TWO_STREAMS", "1")))
+        self.hip_graph = bool(int(os.environ.get("IDIFF_HIP_GRAPH", "1")))
         self._streams = None
 
     def set_gpu(self, device):
@@ -140,6 +141,88 @@ class driftSDE:
         e_hat.record_stream(main)
         return r_hat, e_hat
 
+    # ---- one denoising step as a replayable unit ----------------------------------------------------
+    class Stepper:
+        """The body of the reverse loop with every per-step scalar in device memory (timestep vector, (a_t, b_t, c_t) tables,
+        Philox call count, step index), so the same launches serve every t -- eagerly, or as ONE captured HIP graph that is
+        replayed per step (`IDIFF_HIP_GRAPH=0` disables the capture).  The graph holds the two UNet forwards on their two
+        streams, the fused update and the state advance; the host does not touch the loop between replays."""
+
+        def __init__(self, sde, x, cond, names, text_encoder, image_context, noises=None, t_start=None, t_stop=0):
+            self.sde, self.names, self.text_encoder, self.ctx = sde, names, text_encoder, image_context
+            dev = x.device
+            self.x, self.cond = x, cond
+            self.xa = ops.axpby(x, cond, 1.0, -1.0)
+            self.T, self.t_stop = sde.T, int(t_stop)
+            t0 = sde.T if t_start is None else int(t_start)
+            self.tdev = torch.full((x.shape[0],), float(t0), dtype=torch.float32, device=dev)
+            self.coef = torch.stack([sde._a, sde._b, sde._c]).to(device=dev, dtype=torch.float32).contiguous()
+            self.state = torch.tensor([t0, sde._calls, 0], dtype=torch.int32, device=dev)
+            self.noises = None if noises is None else noises.contiguous()
+            self.nper = (x.numel() + 3) // 4
+            self.graph = None
+            self.steps_done = 0
+
+        def _body(self):
+            sde = self.sde
+            r_hat, e_hat = sde.predict(self.xa, self.x, self.cond, self.tdev, self.names, self.text_encoder, self.ctx)
+            ops.drift_reverse_step_dev(self.x, r_hat, e_hat, self.noises, self.cond, self.xa, self.coef, self.state, sde.seed, self.nper)
+            ops.step_state_advance(self.state, self.tdev, self.T, self.t_stop)
+
+        def _capture(self):
+            """first step eagerly on a side stream (fills every weight / text cache outside the graph's memory pool), then
+            capture the second; returns the number of steps it executed (1)"""
+            main = torch.cuda.current_stream()
+            self.stream = torch.cuda.Stream()
+            self.stream.wait_stream(main)
+            with torch.cuda.stream(self.stream):
+                self._body()
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=self.stream):
+                    self._body()
+            main.wait_stream(self.stream)
+            self.graph = g
+            return 1
+
+        @torch.no_grad()
+        def prepare(self):
+            """capture the graph now (costs one eager step, counted in steps_done); no-op when capture is off / done"""
+            sde = self.sde
+            if not (sde.hip_graph and self.x.is_cuda and self.graph is None):
+                return 0
+            try:
+                done = self._capture()
+            except Exception as e:  # stay on the eager HIP path (same kernels), say why once
+                self.graph = False
+                print(f"[instancediff_amd] HIP graph capture unavailable ({e!r}); running the step eagerly")
+                return 0
+            self.steps_done += done
+            sde._calls += done
+            return done
+
+        @torch.no_grad()
+        def run(self, nsteps):
+            sde = self.sde
+            done = self.prepare() if nsteps >= 3 else 0
+            nsteps_all = nsteps
+            nsteps -= done
+            done = 0
+            if self.graph:
+                main = torch.cuda.current_stream()
+                self.stream.wait_stream(main)
+                with torch.cuda.stream(self.stream):
+                    for _ in range(nsteps - done):
+                        self.graph.replay()
+                main.wait_stream(self.stream)
+            else:
+                for _ in range(nsteps - done):
+                    self._body()
+            self.steps_done += nsteps
+            sde._calls += nsteps
+            assert nsteps_all >= nsteps
+            return self.x
+
     @torch.no_grad()
     def reverse_ddpm(self, cond, names, text_encoder, reverse_type="std", optimize_type="inputRes", image_context=None, x_T=None,
                      noises=None, T_stop=0):
@@ -153,18 +236,5 @@ class driftSDE:
         if x_T is None:
             x_T = ops.axpby(cond, self._randn_like(cond), 1.0, self.max_sigma)
         x = x_T.contiguous().clone()
-        xa = ops.axpby(x, cond, 1.0, -1.0)
-        x2, xa2 = torch.empty_like(x), torch.empty_like(x)
-        tdev = torch.empty((B,), dtype=torch.float32, device=cond.device)
-        nper = (x.numel() + 3) // 4
-        for i, t in enumerate(range(self.T, T_stop, -1)):
-            tdev.fill_(float(t))
-            r_hat, e_hat = self.predict(xa, x, cond, tdev, names, text_encoder, image_context)
-            z = None if noises is None else noises[i].contiguous()
-            off = self._calls * nper
-            self._calls += 1
-            ops.drift_reverse_step(x, r_hat, e_hat, z, float(self._a[t]), float(self._b[t]), float(self._c[t]), cond=cond, seed=self.seed,
-                                   offset=off, out=x2, xa_out=xa2)
-            x, x2 = x2, x
-            xa, xa2 = xa2, xa
-        return x
+        stepper = driftSDE.Stepper(self, x, cond, names, text_encoder, image_context, noises=noises, t_stop=T_stop)
+        return stepper.run(self.T - T_stop)

@@ -415,6 +415,21 @@ def drift_reverse_step(x, r_hat, e_hat, z, a, b, c, cond=None, seed=0, offset=0,
     return (out, xa_out) if cond is not None else out
 
 
+def drift_reverse_step_dev(x, r_hat, e_hat, z_base, cond, xa, coef, state, seed, nper):
+    """in-place, graph-replayable drift step: per-step scalars from `coef` [3, T+1] and `state` int32 [3] on the device"""
+    lib = _lib.load()
+    _c(x, "x"), _c(r_hat, "r_hat"), _c(e_hat, "e_hat"), _c(z_base, "z"), _c(cond, "cond"), _c(xa, "xa"), _c(coef, "coef")
+    assert state.dtype == torch.int32 and state.is_cuda and state.numel() == 3 and coef.dim() == 2 and coef.shape[0] == 3
+    check(lib.idiff_drift_reverse_step_dev(_p(x), _p(r_hat), _p(e_hat), _p(z_base), _p(cond), _p(xa), x.numel(), _p(coef), coef.shape[1],
+                                           C.c_void_p(state.data_ptr()), seed, nper, _stream()), "drift_reverse_step_dev")
+
+
+def step_state_advance(state, tdev, T, t_stop=0):
+    lib = _lib.load()
+    _c(tdev, "tdev")
+    check(lib.idiff_step_state_advance(C.c_void_p(state.data_ptr()), _p(tdev), tdev.numel(), T, t_stop, _stream()), "step_state_advance")
+
+
 def randn(shape, device, seed, offset=0):
     lib = _lib.load()
     out = torch.empty(shape, device=device, dtype=torch.float32)
