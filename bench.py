@@ -276,12 +276,20 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU: the hot path has no CPU fallback", file=sys.stderr)
         sys.exit(2)
+    # IDIFF_BENCH_REHEARSAL=1: several ranks share the one GPU of a development box over gloo -- exercises the N>1 code path
+    # (rendezvous, barriers, max-over-ranks timing, rank-0 reporting); its numbers mean nothing.
+    rehearsal = bool(int(os.environ.get("IDIFF_BENCH_REHEARSAL", "0")))
+    if rehearsal:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     from instancediff_amd import ops, pipeline
     from instancediff_amd.utils.synthetic import make_batch
