@@ -179,7 +179,9 @@ class driftSDE:
                 self._body()
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=self.stream):
+                # thread-local capture mode: a polling thread of the process (e.g. the RCCL watchdog of a multi-GPU job) must
+                # not invalidate the capture
+                with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
                     self._body()
             main.wait_stream(self.stream)
             self.graph = g
