@@ -338,16 +338,19 @@ __global__ __launch_bounds__(256) void smm_xattn_kernel(const float* __restrict_
 }
 
 __global__ __launch_bounds__(256) void smm_xattn_combine_kernel(const float* __restrict__ ws, float* __restrict__ o, int rows, int nsplit, int XCM) {
+    // thread = (channel c, row): the partials are laid out [c][32 rows], so a wave reads two full 128-byte lines per split
     const int b = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over rows*XCM
-    if (i >= rows * XCM) return;
-    const int row = i / XCM, c = i % XCM;
-    const float* wb = ws + (long long)b * nsplit * (XCM + 2) * 32;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over XCM * 32
+    if (i >= XCM * 32) return;
+    const int c = i >> 5, row = i & 31;
+    if (row >= rows) return;
+    const long long ss = (long long)(XCM + 2) * 32;  // floats per split
+    const float* wb = ws + (long long)b * nsplit * ss;
     float M = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, wb[(long long)s * (XCM + 2) * 32 + XCM * 32 + row]);
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, wb[s * ss + XCM * 32 + row]);
     float L = 0.f, acc = 0.f;
     for (int s = 0; s < nsplit; ++s) {
-        const float* w = wb + (long long)s * (XCM + 2) * 32;
+        const float* w = wb + s * ss;
         const float ms = w[XCM * 32 + row];
         const float f = ms == -INFINITY ? 0.f : __expf(ms - M);
         L += w[(XCM + 1) * 32 + row] * f;
@@ -360,6 +363,7 @@ inline void smm_split(int B, int N, int* nsplit, int* kps) {
     const int nkb = (N + 31) / 32;
     int target = 1024 / (B > 0 ? B : 1);
     if (target < 1) target = 1;
+    if (target > 256) target = 256;  // one workgroup per CU is enough; every extra split is serial work for the combine
     int k = (nkb + target - 1) / target;
     if (k < 2) k = 2;
     if (k > nkb) k = nkb;
@@ -445,7 +449,7 @@ extern "C" int idiff_smm_xattn_fwd(const float* qf, const float* mem, float* o, 
     else
         hipLaunchKernelGGL(smm_xattn_kernel<18>, dim3(ns, B), dim3(256), lds, st, qf, mem, ws, rows, N, ns, kps, scale);
     IDIFF_CHECK_LAUNCH("smm_xattn_fwd");
-    hipLaunchKernelGGL(smm_xattn_combine_kernel, dim3((rows * Cm + 255) / 256, B), dim3(256), 0, st, ws, o, rows, ns, Cm);
+    hipLaunchKernelGGL(smm_xattn_combine_kernel, dim3((32 * Cm + 255) / 256, B), dim3(256), 0, st, ws, o, rows, ns, Cm);
     IDIFF_CHECK_LAUNCH("smm_xattn_combine");
     return IDIFF_OK;
 }
