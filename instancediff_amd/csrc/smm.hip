@@ -21,7 +21,6 @@ __global__ __launch_bounds__(256) void smm_memproj_kernel(const float* __restric
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xt = smem;                 // [C][64]
     float* part = smem + C * MP_PX;   // [4][64]
-    float* stat = part + 4 * MP_PX;   // [2][64] mean, rstd
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.y;
@@ -70,7 +69,6 @@ __global__ __launch_bounds__(256) void smm_memproj_kernel(const float* __restric
     const float* wl = wpk + (long long)half * MP_W + wave * 64 + l31;
     const float* xl = xt + half * MP_PX + l31;
     const int nsteps = C / 2;
-#pragma unroll 4
     for (int st = 0; st < nsteps; ++st) {
         const float a0 = wl[(long long)(2 * st) * MP_W];
         const float a1 = wl[(long long)(2 * st) * MP_W + 32];
@@ -211,7 +209,6 @@ __global__ __launch_bounds__(256) void smm_memproj_gram_kernel(const float* __re
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const float* wl = gram + (long long)half * C + m * 32 + l31;
         const float* xl = xt + half * MP_PX + n * 32 + l31;
-#pragma unroll 4
         for (int st = 0; st < C / 2; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(long long)(2 * st) * C], xl[2 * st * MP_PX], acc, 0, 0, 0);
         float sum = 0.f;
 #pragma unroll
