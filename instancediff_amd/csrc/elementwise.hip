@@ -198,29 +198,39 @@ __global__ void time_embed_kernel(const float* __restrict__ t, const float* __re
     out[i] = j < half ? sinf(arg) : cosf(arg);
 }
 
-// LayerNorm across channels of an NCHW map: thread = pixel, coalesced along p; two-pass
+// LayerNorm across channels of an NCHW map, two-pass.  Workgroup = 64 pixels; lane = pixel (coalesced along p), the four
+// waves split the channels and combine their per-pixel partial sums through LDS (a thread-per-pixel layout leaves a 32x32
+// map with 64 workgroups for the whole chip).
 __global__ __launch_bounds__(256) void chan_layernorm_kernel(const float* __restrict__ x, long long xbs, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ out, long long obs, int C,
                                                              int HW, float eps, float* __restrict__ mean_rstd) {
+    __shared__ float part[4][64];
     const int b = blockIdx.y;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= HW) return;
-    const float* xb = x + (long long)b * xbs + p;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + lane;
+    const bool ok = p < HW;
+    const float* xb = x + (long long)b * xbs + (ok ? p : 0);
     float s = 0.f;
-    for (int c = 0; c < C; ++c) s += xb[(long long)c * HW];
-    const float mean = s / (float)C;
+    for (int c = wave; c < C; c += 4) s += xb[(long long)c * HW];
+    part[wave][lane] = s;
+    __syncthreads();
+    const float mean = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) / (float)C;
+    __syncthreads();
     float q = 0.f;
-    for (int c = 0; c < C; ++c) {
+    for (int c = wave; c < C; c += 4) {
         const float d = xb[(long long)c * HW] - mean;
         q += d * d;
     }
-    const float rstd = rsqrtf(q / (float)C + eps);
-    if (mean_rstd) {
+    part[wave][lane] = q;
+    __syncthreads();
+    const float rstd = rsqrtf(((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) / (float)C + eps);
+    if (!ok) return;
+    if (mean_rstd && wave == 0) {
         mean_rstd[((long long)b * HW + p) * 2] = mean;
         mean_rstd[((long long)b * HW + p) * 2 + 1] = rstd;
     }
     float* ob = out + (long long)b * obs + p;
-    for (int c = 0; c < C; ++c) ob[(long long)c * HW] = (xb[(long long)c * HW] - mean) * rstd * gamma[c] + beta[c];
+    for (int c = wave; c < C; c += 4) ob[(long long)c * HW] = (xb[(long long)c * HW] - mean) * rstd * gamma[c] + beta[c];
 }
 
 // score map: normalized feature (per pixel over C) . normalized text vectors
@@ -336,7 +346,7 @@ extern "C" int idiff_time_embed_fwd(const float* t, const float* freqs, int B, i
 extern "C" int idiff_chan_layernorm_fwd(const float* x, int64_t x_bstride, const float* gamma, const float* beta, float* out,
                                         int64_t out_bstride, int B, int C, int HW, float eps, float* mean_rstd, idiff_stream_t stream) {
     IDIFF_CHECK_ARG(x && out && gamma && beta && B > 0 && C > 0 && HW > 0, "chan_layernorm: bad args");
-    hipLaunchKernelGGL(chan_layernorm_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, (long long)x_bstride, gamma,
+    hipLaunchKernelGGL(chan_layernorm_kernel, dim3((HW + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, x, (long long)x_bstride, gamma,
                        beta, out, (long long)out_bstride, C, HW, eps, mean_rstd);
     IDIFF_CHECK_LAUNCH("chan_layernorm");
     return IDIFF_OK;
