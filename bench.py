@@ -233,7 +233,7 @@ def irsde_bench(args, world, rank, dev):
         t = state["t"]
         noise = sde.noise_fn(state["x"], t, sde.sample_scale)
         noise = noise[0] if isinstance(noise, tuple) else noise
-        state["x"] = sde.reverse_sde_step(state["x"], noise, t)
+        state["x"] = sde.reverse_sde_step_from_noise(state["x"], noise, t)
         state["t"] = t - 1 if t > 1 else args.T
 
     def barrier():

@@ -221,6 +221,29 @@ int idiff_gather_channel(const float* x, const int32_t* idx, float* out, int B, 
 int idiff_irsde_reverse_step(const float* x, const float* mu, const float* noise_pred, const float* z, float* x_out,
                              int64_t n, float theta, float sigma, float sigma_bar, float dt, float sqrt_dt, int mode,
                              uint64_t seed, uint64_t offset, idiff_stream_t stream);
+/* The pieces the reference composes its steps and closed forms from, one launch each, every product / sum / quotient rounded
+ * once in the reference's order (bit-exact against the CPU reference given identical draws).  Operands a, b, z are [B][per]
+ * (NULL where an op does not read them; z == NULL on an op that draws noise -> Philox keyed by (seed, offset));
+ * mu NULL -> the scalar mu_scalar (the reference's default `self.mu = 0.`, sde_utils.py:152).
+ * Coefficients k[0..5]: by value in `k` when coef_dev == NULL (python-int t), else per-sample device rows coef_dev[B][6]
+ * (t given as a [B,1,1,1] tensor, sde_utils.py:330-336).  The host fills them from the schedule tables. */
+#define IDIFF_IRSDE_SCORE_FROM_NOISE 0 /* get_score_from_noise :187-188   (-a) / k0                       k0 = sigma_bar_t        */
+#define IDIFF_IRSDE_MU_BAR 1           /* mu_bar :169-170                  mu + (a - mu)*k0                k0 = exp(-cumsum_t dt)  */
+#define IDIFF_IRSDE_DRIFT 2            /* drift :175-176                   (k0*(mu - a))*k1                k0 = theta_t, k1 = dt   */
+#define IDIFF_IRSDE_REV_DRIFT 3        /* sde_/ode_reverse_drift :178-182  (k0*(mu - a) - k1*b)*k2         k1 = sigma_t^2 [*0.5], k2 = dt */
+#define IDIFF_IRSDE_DISPERSION 4       /* dispersion :184-185              k0*(z*k1)                       k0 = sigma_t, k1 = sqrt(dt) */
+#define IDIFF_IRSDE_STEP_MEAN 5        /* reverse_sde_step_mean / reverse_ode_step :41-42,48-49   a - REV_DRIFT(a, b)              */
+#define IDIFF_IRSDE_STEP_SDE 6         /* reverse_sde_step :45-46          (a - REV_DRIFT(a, b)) - k3*(z*k4)   k3 = sigma_t, k4 = sqrt(dt) */
+#define IDIFF_IRSDE_FORWARD_STEP 7     /* forward_step :38-39              (a + (k0*(mu - a))*k1) + k3*(z*k4)                      */
+#define IDIFF_IRSDE_OPT_STEP 8         /* reverse_optimum_step :206-214    ((k0*(a - mu)) + (k1*(b - mu))) + mu   k0 = term1, k1 = term2 */
+#define IDIFF_IRSDE_REAL_NOISE 9       /* get_real_noise :222-223          (a - (mu + (b - mu)*k0)) / k1   k1 = sigma_bar_t        */
+#define IDIFF_IRSDE_REAL_SCORE 10      /* get_real_score :225-226          (-(a - (mu + (b - mu)*k0))) / k1   k1 = sigma_bar_t^2   */
+#define IDIFF_IRSDE_INIT_FROM_NOISE 11 /* get_init_state_from_noise :228-230   (((a - mu) - k0*b)*k1) + mu   k0 = sigma_bar_t, k1 = exp(+cumsum_t dt) */
+#define IDIFF_IRSDE_RANDOM_STATES 12   /* generate_random_states :333-336  (z*k1) + (mu + (a - mu)*k0)     k0 = exp(-cumsum_t dt), k1 = sigma_bar_t */
+#define IDIFF_IRSDE_NUM_OPS 13
+int idiff_irsde_map(int op, const float* a, const float* b, const float* z, const float* mu, float mu_scalar, float* out, int B,
+                    int64_t per_sample, const float* coef_dev, const float* k, uint64_t seed, uint64_t offset,
+                    idiff_stream_t stream);
 /* x_out = ((x - a*r_hat) - b*e_hat) + c*z ;  xa_out (optional) = x_out - cond  (next step's network input) */
 int idiff_drift_reverse_step(const float* x, const float* r_hat, const float* e_hat, const float* z, const float* cond,
                              float* x_out, float* xa_out, int64_t n, float a, float b, float c, uint64_t seed,

@@ -213,6 +213,90 @@ __global__ __launch_bounds__(256) void mix3_kernel(const float* __restrict__ x0,
     }
 }
 
+
+// ---- IRSDE pieces (idiff_irsde_map): the reference's own decomposition of its steps and closed forms, one launch each ----
+struct IrsdeCoef {
+    float k[6];
+};
+
+template <int OP>
+__device__ __forceinline__ float irsde_piece(float a, float b, float z, float m, const float* k) {
+    if (OP == IDIFF_IRSDE_SCORE_FROM_NOISE) return (float)((double)(-a) / (double)k[0]);  // correctly rounded fp32 quotient
+    if (OP == IDIFF_IRSDE_MU_BAR) return __fadd_rn(m, __fmul_rn(__fsub_rn(a, m), k[0]));
+    if (OP == IDIFF_IRSDE_DRIFT) return __fmul_rn(__fmul_rn(k[0], __fsub_rn(m, a)), k[1]);
+    if (OP == IDIFF_IRSDE_DISPERSION) return __fmul_rn(k[0], __fmul_rn(z, k[1]));
+    if (OP == IDIFF_IRSDE_REV_DRIFT || OP == IDIFF_IRSDE_STEP_MEAN || OP == IDIFF_IRSDE_STEP_SDE) {
+        const float rd = __fmul_rn(__fsub_rn(__fmul_rn(k[0], __fsub_rn(m, a)), __fmul_rn(k[1], b)), k[2]);
+        if (OP == IDIFF_IRSDE_REV_DRIFT) return rd;
+        const float r = __fsub_rn(a, rd);
+        if (OP == IDIFF_IRSDE_STEP_MEAN) return r;
+        return __fsub_rn(r, __fmul_rn(k[3], __fmul_rn(z, k[4])));
+    }
+    if (OP == IDIFF_IRSDE_FORWARD_STEP)
+        return __fadd_rn(__fadd_rn(a, __fmul_rn(__fmul_rn(k[0], __fsub_rn(m, a)), k[1])), __fmul_rn(k[3], __fmul_rn(z, k[4])));
+    if (OP == IDIFF_IRSDE_OPT_STEP)
+        return __fadd_rn(__fadd_rn(__fmul_rn(k[0], __fsub_rn(a, m)), __fmul_rn(k[1], __fsub_rn(b, m))), m);
+    if (OP == IDIFF_IRSDE_REAL_NOISE || OP == IDIFF_IRSDE_REAL_SCORE) {
+        const float d = __fsub_rn(a, __fadd_rn(m, __fmul_rn(__fsub_rn(b, m), k[0])));
+        return (float)((double)(OP == IDIFF_IRSDE_REAL_SCORE ? -d : d) / (double)k[1]);
+    }
+    if (OP == IDIFF_IRSDE_INIT_FROM_NOISE) return __fadd_rn(__fmul_rn(__fsub_rn(__fsub_rn(a, m), __fmul_rn(k[0], b)), k[1]), m);
+    if (OP == IDIFF_IRSDE_RANDOM_STATES) return __fadd_rn(__fmul_rn(z, k[1]), __fadd_rn(m, __fmul_rn(__fsub_rn(a, m), k[0])));
+    return 0.f;
+}
+
+constexpr bool irsde_op_draws(int op) {
+    return op == IDIFF_IRSDE_DISPERSION || op == IDIFF_IRSDE_STEP_SDE || op == IDIFF_IRSDE_FORWARD_STEP || op == IDIFF_IRSDE_RANDOM_STATES;
+}
+
+// grid = (chunks, B); per % 4 == 0 -> float4 lanes, Philox counter = offset + (flat element index)/4 as in idiff_randn
+template <int OP>
+__global__ __launch_bounds__(256) void irsde_map_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ z,
+                                                        const float* __restrict__ mu, float mu_scalar, float* __restrict__ out, long long per,
+                                                        const float* __restrict__ coef_dev, IrsdeCoef kc, uint64_t seed, uint64_t offset, int vec4) {
+    const int s = blockIdx.y;
+    float k[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) k[i] = coef_dev ? coef_dev[s * 6 + i] : kc.k[i];
+    const long long base = (long long)s * per;
+    const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+    const floatx4 mconst = {mu_scalar, mu_scalar, mu_scalar, mu_scalar};
+    if (vec4) {  // per % 4 == 0 and every operand 16-byte aligned (checked on the host)
+        const long long nv = per / 4;
+        for (long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x; v < nv; v += (long long)gridDim.x * blockDim.x) {
+            const long long i = base + v * 4;
+            const floatx4 av = a ? *reinterpret_cast<const floatx4*>(a + i) : zero;
+            const floatx4 bv = b ? *reinterpret_cast<const floatx4*>(b + i) : zero;
+            const floatx4 mv = mu ? *reinterpret_cast<const floatx4*>(mu + i) : mconst;
+            floatx4 zv = zero;
+            if (irsde_op_draws(OP)) zv = z ? *reinterpret_cast<const floatx4*>(z + i) : philox_normal4(offset + (uint64_t)(i >> 2), seed);
+            floatx4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = irsde_piece<OP>(av[e], bv[e], zv[e], mv[e], k);
+            *reinterpret_cast<floatx4*>(out + i) = o;
+        }
+    } else {
+        for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < per; j += (long long)gridDim.x * blockDim.x) {
+            const long long i = base + j;
+            float zz = 0.f;
+            if (irsde_op_draws(OP)) zz = z ? z[i] : philox_normal4(offset + (uint64_t)(i >> 2), seed)[i & 3];
+            out[i] = irsde_piece<OP>(a ? a[i] : 0.f, b ? b[i] : 0.f, zz, mu ? mu[i] : mu_scalar, k);
+        }
+    }
+}
+
+template <int OP>
+void launch_irsde_map(const float* a, const float* b, const float* z, const float* mu, float mu_scalar, float* out, int B, long long per,
+                      const float* coef_dev, const IrsdeCoef& kc, uint64_t seed, uint64_t offset, hipStream_t st) {
+    long long gx = ((per + 3) / 4 + 255) / 256;
+    if (gx < 1) gx = 1;
+    if (gx > 1024) gx = 1024;
+    const uintptr_t bits = (uintptr_t)a | (uintptr_t)b | (uintptr_t)z | (uintptr_t)mu | (uintptr_t)out;
+    const int vec4 = (per % 4 == 0) && (bits % 16 == 0);
+    hipLaunchKernelGGL(irsde_map_kernel<OP>, dim3((unsigned)gx, (unsigned)B), dim3(256), 0, st, a, b, z, mu, mu_scalar, out, per, coef_dev, kc, seed,
+                       offset, vec4);
+}
+
 inline int stream_grid(long long nvec) {
     long long g = (nvec + 255) / 256;
     if (g < 1) g = 1;
@@ -239,6 +323,46 @@ extern "C" int idiff_irsde_reverse_step(const float* x, const float* mu, const f
         hipLaunchKernelGGL(irsde_step_kernel<IDIFF_SDE_ODE>, dim3(grid), dim3(256), 0, st, x, mu, noise_pred, z, x_out, (long long)n, theta,
                            sigma, sigma_bar, dt, sqrt_dt, seed, offset);
     IDIFF_CHECK_LAUNCH("irsde_reverse_step");
+    return IDIFF_OK;
+}
+
+
+extern "C" int idiff_irsde_map(int op, const float* a, const float* b, const float* z, const float* mu, float mu_scalar, float* out, int B,
+                               int64_t per_sample, const float* coef_dev, const float* k, uint64_t seed, uint64_t offset, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(op >= 0 && op < IDIFF_IRSDE_NUM_OPS, "irsde_map: bad op %d", op);
+    IDIFF_CHECK_ARG(out && B > 0 && B <= 65535 && per_sample > 0, "irsde_map: bad args");
+    IDIFF_CHECK_ARG(coef_dev || k, "irsde_map: needs coefficients (coef_dev or k)");
+    IDIFF_CHECK_ARG(a || op == IDIFF_IRSDE_DISPERSION, "irsde_map: op %d reads operand a", op);
+    const bool needs_b = op == IDIFF_IRSDE_REV_DRIFT || op == IDIFF_IRSDE_STEP_MEAN || op == IDIFF_IRSDE_STEP_SDE || op == IDIFF_IRSDE_OPT_STEP ||
+                         op == IDIFF_IRSDE_REAL_NOISE || op == IDIFF_IRSDE_REAL_SCORE || op == IDIFF_IRSDE_INIT_FROM_NOISE;
+    IDIFF_CHECK_ARG(b || !needs_b, "irsde_map: op %d reads operand b", op);
+    IrsdeCoef kc;
+    for (int i = 0; i < 6; ++i) kc.k[i] = k ? k[i] : 0.f;
+    if (!coef_dev && (op == IDIFF_IRSDE_SCORE_FROM_NOISE || op == IDIFF_IRSDE_REAL_NOISE || op == IDIFF_IRSDE_REAL_SCORE))
+        IDIFF_CHECK_ARG(kc.k[op == IDIFF_IRSDE_SCORE_FROM_NOISE ? 0 : 1] != 0.f, "irsde_map: division by sigma_bar == 0");
+    hipStream_t st = (hipStream_t)stream;
+    const long long per = (long long)per_sample;
+#define IDIFF_IRSDE_CASE(OP)                                                                           \
+    case OP:                                                                                           \
+        launch_irsde_map<OP>(a, b, z, mu, mu_scalar, out, B, per, coef_dev, kc, seed, offset, st); \
+        break;
+    switch (op) {
+        IDIFF_IRSDE_CASE(IDIFF_IRSDE_SCORE_FROM_NOISE)
+        IDIFF_IRSDE_CASE(IDIFF_IRSDE_MU_BAR)
+        IDIFF_IRSDE_CASE(IDIFF_IRSDE_DRIFT)
+        IDIFF_IRSDE_CASE(IDIFF_IRSDE_REV_DRIFT)
+        IDIFF_IRSDE_CASE(IDIFF_IRSDE_DISPERSION)
+        IDIFF_IRSDE_CASE(IDIFF_IRSDE_STEP_MEAN)
+        IDIFF_IRSDE_CASE(IDIFF_IRSDE_STEP_SDE)
+        IDIFF_IRSDE_CASE(IDIFF_IRSDE_FORWARD_STEP)
+        IDIFF_IRSDE_CASE(IDIFF_IRSDE_OPT_STEP)
+        IDIFF_IRSDE_CASE(IDIFF_IRSDE_REAL_NOISE)
+        IDIFF_IRSDE_CASE(IDIFF_IRSDE_REAL_SCORE)
+        IDIFF_IRSDE_CASE(IDIFF_IRSDE_INIT_FROM_NOISE)
+        IDIFF_IRSDE_CASE(IDIFF_IRSDE_RANDOM_STATES)
+    }
+#undef IDIFF_IRSDE_CASE
+    IDIFF_CHECK_LAUNCH("irsde_map");
     return IDIFF_OK;
 }
 

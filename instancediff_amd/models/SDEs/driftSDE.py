@@ -169,14 +169,21 @@ class driftSDE:
             ops.drift_reverse_step_dev(self.x, r_hat, e_hat, self.noises, self.cond, self.xa, self.coef, self.state, sde.seed, self.nper)
             ops.step_state_advance(self.state, self.tdev, self.T, self.t_stop)
 
-        def _capture(self):
-            """first step eagerly on a side stream (fills every weight / text cache outside the graph's memory pool), then
-            capture the second; returns the number of steps it executed (1)"""
+        def _warm_step(self):
+            """one step eagerly on the side stream: fills every weight / text cache outside the graph's memory pool.  It IS a
+            denoising step (x, xa and the device state {t, Philox count, step index} advance), whatever happens to the capture."""
             main = torch.cuda.current_stream()
             self.stream = torch.cuda.Stream()
             self.stream.wait_stream(main)
             with torch.cuda.stream(self.stream):
                 self._body()
+            main.wait_stream(self.stream)
+
+        def _capture(self):
+            """capture the next step as a HIP graph (enqueues nothing that executes)"""
+            main = torch.cuda.current_stream()
+            self.stream.wait_stream(main)
+            with torch.cuda.stream(self.stream):
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 # thread-local capture mode: a polling thread of the process (e.g. the RCCL watchdog of a multi-GPU job) must
@@ -184,46 +191,47 @@ class driftSDE:
                 with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
                     self._body()
             main.wait_stream(self.stream)
-            self.graph = g
-            return 1
+            return g
 
         @torch.no_grad()
         def prepare(self):
-            """capture the graph now (costs one eager step, counted in steps_done); no-op when capture is off / done"""
+            """Warm step + graph capture; returns the number of denoising steps it executed (1, counted in steps_done, also when
+            the capture then fails and the loop stays eager); 0 when capture is off or already attempted."""
             sde = self.sde
             if not (sde.hip_graph and self.x.is_cuda and self.graph is None):
                 return 0
+            self._warm_step()
+            self.steps_done += 1
+            sde._calls += 1
             try:
-                done = self._capture()
+                self.graph = self._capture()
             except Exception as e:  # stay on the eager HIP path (same kernels), say why once
                 self.graph = False
                 print(f"[instancediff_amd] HIP graph capture unavailable ({e!r}); running the step eagerly")
-                return 0
-            self.steps_done += done
-            sde._calls += done
-            return done
+            return 1
 
         @torch.no_grad()
         def run(self, nsteps):
             sde = self.sde
-            done = self.prepare() if nsteps >= 3 else 0
-            nsteps_all = nsteps
-            nsteps -= done
-            done = 0
+            nsteps -= self.prepare() if nsteps >= 3 else 0
             if self.graph:
                 main = torch.cuda.current_stream()
                 self.stream.wait_stream(main)
                 with torch.cuda.stream(self.stream):
-                    for _ in range(nsteps - done):
+                    for _ in range(nsteps):
                         self.graph.replay()
                 main.wait_stream(self.stream)
             else:
-                for _ in range(nsteps - done):
+                for _ in range(nsteps):
                     self._body()
             self.steps_done += nsteps
             sde._calls += nsteps
-            assert nsteps_all >= nsteps
             return self.x
+
+        @property
+        def mode(self):
+            """'graph' when the loop replays a captured HIP graph, 'eager' otherwise (reported by bench.py)"""
+            return "graph" if self.graph else "eager"
 
     @torch.no_grad()
     def reverse_ddpm(self, cond, names, text_encoder, reverse_type="std", optimize_type="inputRes", image_context=None, x_T=None,

@@ -153,6 +153,21 @@ class CLIPDriftModel():
     def optimize_parameters(self):  # :231-232
         return self.optimize_parameters_inputRes()
 
+    def optimize_score_map(self, score_maps, label, size=None, mult=[1, 2, 4, 8], want_grads=False):
+        """sum_i MSE(score_maps[i], Resize((size[0]//mult[i], size[1]//mult[i]))(label)) / 2   (:234-240).
+        `size` defaults to the label's own H, W (the reference hard-codes [224, 224], its dataset's size).  Resize is torchvision's
+        bilinear tensor resize WITHOUT antialiasing: the reference pins PyTorch 1.13.1 (README.md:28), i.e. torchvision 0.14, where
+        `Resize(size)` on a tensor means antialias=None = off (it became on-by-default for tensors only in 0.17).
+        Returns the loss as a 0-dim device tensor (HIP resize + MSE kernels; no graph is recorded -- the training step feeds
+        autograd the explicit per-map gradients, which `want_grads=True` also returns)."""
+        from ..train_ops import score_map_losses
+        label = label.contiguous()
+        H, W = (int(size[0]), int(size[1])) if size is not None else tuple(label.shape[-2:])
+        rec = torch.zeros(len(score_maps), device=label.device, dtype=torch.float32)
+        grads = score_map_losses(score_maps, label, rec, 0, mult=mult, size=(H, W), want_grad=want_grads)
+        loss = rec.sum() / 2.0
+        return (loss, grads) if want_grads else loss
+
     def optimize_parameters_inputRes(self):
         """(x_t-cond, cond)->drift; (x_t-cond, x_t)->noise; L2 + score-map pyramid losses; Adam (:242-312)."""
         from ..train_ops import train_step_inputRes

@@ -403,6 +403,40 @@ def irsde_reverse_step(x, mu, noise_pred, z, theta, sigma, sigma_bar, dt, sqrt_d
     return out
 
 
+# op codes of idiff_irsde_map (include/idiff.h)
+(IRSDE_SCORE_FROM_NOISE, IRSDE_MU_BAR, IRSDE_DRIFT, IRSDE_REV_DRIFT, IRSDE_DISPERSION, IRSDE_STEP_MEAN, IRSDE_STEP_SDE, IRSDE_FORWARD_STEP,
+ IRSDE_OPT_STEP, IRSDE_REAL_NOISE, IRSDE_REAL_SCORE, IRSDE_INIT_FROM_NOISE, IRSDE_RANDOM_STATES) = range(13)
+
+
+def irsde_map(op, like, a=None, b=None, z=None, mu=None, k=None, coef_dev=None, seed=0, offset=0, out=None):
+    """One piece of the reference's IRSDE arithmetic (include/idiff.h: IDIFF_IRSDE_*) over tensors shaped like `like` [B,...].
+    mu: tensor of that shape or a python number; k: up to 6 python floats, or coef_dev: device [B,6] per-sample rows."""
+    lib = _lib.load()
+    _c(like, "like")
+    for name, t in (("a", a), ("b", b), ("z", z)):
+        _c(t, name)
+        if t is not None and t.shape != like.shape:
+            raise _lib.IdiffError(f"irsde_map: operand {name} has shape {tuple(t.shape)}, expected {tuple(like.shape)}")
+    mu_t, mu_s = (mu, 0.0) if torch.is_tensor(mu) else (None, float(mu if mu is not None else 0.0))
+    if mu_t is not None:
+        if mu_t.shape != like.shape:
+            mu_t = mu_t.expand(like.shape).contiguous()
+        _c(mu_t, "mu")
+    B = like.shape[0] if (coef_dev is not None and like.dim() > 0) else 1
+    karr = None
+    if coef_dev is not None:
+        _c(coef_dev, "coef_dev")
+        assert tuple(coef_dev.shape) == (B, 6), (coef_dev.shape, B)
+    else:
+        kk = [float(v) for v in (k or [])]
+        karr = (C.c_float * 6)(*(kk + [0.0] * (6 - len(kk))))
+    if out is None:
+        out = torch.empty_like(like)
+    check(lib.idiff_irsde_map(op, _p(a), _p(b), _p(z), _p(mu_t), mu_s, _p(out), B, like.numel() // B, _p(coef_dev), karr, seed, offset,
+                              _stream()), "irsde_map")
+    return out
+
+
 def drift_reverse_step(x, r_hat, e_hat, z, a, b, c, cond=None, seed=0, offset=0, out=None, xa_out=None):
     lib = _lib.load()
     _c(x, "x"), _c(r_hat, "r_hat"), _c(e_hat, "e_hat"), _c(z, "z"), _c(cond, "cond")

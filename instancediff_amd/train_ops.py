@@ -550,14 +550,17 @@ class FusedAdam(torch.optim.Optimizer):
                     f['step'] = s['step']
 
 
-def score_map_losses(score_maps, label, loss_rec, slot0, mult=(1, 2, 4, 8)):
-    """optimize_score_map (drift_noise_model.py:234-240): sum_i MSE(sm_i, resize(label, H//m_i)) / 2 with the
-    hard-coded 224 replaced by the label's own size.  Returns the per-map gradients; loss values go to loss_rec."""
-    H, W = label.shape[-2:]
+def score_map_losses(score_maps, label, loss_rec, slot0, mult=(1, 2, 4, 8), size=None, want_grad=True):
+    """optimize_score_map (drift_noise_model.py:234-240): sum_i MSE(sm_i, resize(label, size//m_i)) / 2 with the
+    hard-coded 224 replaced by `size` (default: the label's own size).  Bilinear, align_corners=False, no antialiasing
+    (torchvision 0.14 tensor semantics, the version the reference's PyTorch 1.13.1 pins).  Returns the per-map gradients
+    (already carrying the /2); the un-halved loss values go to loss_rec[slot0 + i]."""
+    H, W = label.shape[-2:] if size is None else size
     grads = []
     for i, sm in enumerate(score_maps):
-        tgt = label if mult[i] == 1 else resize_bilinear(label, H // mult[i], W // mult[i])
-        grads.append(mse_loss_and_grad(sm, tgt, loss_rec[slot0 + i:slot0 + i + 1], weight=0.5))
+        oh, ow = H // mult[i], W // mult[i]
+        tgt = label if (oh, ow) == tuple(label.shape[-2:]) else resize_bilinear(label, oh, ow)
+        grads.append(mse_loss_and_grad(sm, tgt, loss_rec[slot0 + i:slot0 + i + 1], weight=0.5, want_grad=want_grad))
     return grads
 
 

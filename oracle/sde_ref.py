@@ -98,6 +98,20 @@ class IRSDERef:
     def reverse_ode_step(self, x, score, t):
         return x - self.ode_reverse_drift(x, score, t)
 
+    def forward_step(self, x, t, noise):  # :38-39
+        return x + self.drift(x, t) + self.dispersion(x, t, noise)
+
+    def score_fn_(self, x, t, scale=1.0):  # :190-194 (x0-predicting model)
+        x0 = self.model(x, self.mu, t * scale)
+        return -(x - self.mu_bar(x0, t)) / self.sigma_bar(t) ** 2
+
+    def optimal_reverse(self, xt, x0, T=-1):  # :308-314
+        T = self.T if T < 0 else T
+        x = xt.clone()
+        for t in reversed(range(1, T + 1)):
+            x = self.reverse_optimum_step(x, x0, t)
+        return x
+
     def score_fn(self, x, t, scale=1.0, **kw):  # :196-199
         noise = self.model(x, self.mu, t * scale, **kw)
         return self.get_score_from_noise(noise, t)

@@ -16,3 +16,9 @@ def pytest_configure(config):
 def golden_sde():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "irsde_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_sde2():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "irsde_golden2.npz"))

@@ -46,6 +46,10 @@ def test_cabi_argument_errors_are_reported_not_crashes(built_lib):
     assert b"null pointer" in built_lib.idiff_last_error()
     assert built_lib.idiff_irsde_reverse_step(None, None, None, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, None) == -1
     assert built_lib.idiff_linear_fwd(None, 0, None, 0, None, None, 0, None, None, 0, 1, 1, 1, 0, 0, None) == -1
+    k6 = (C.c_float * 6)(0, 0, 0, 0, 0, 0)
+    assert built_lib.idiff_irsde_map(99, None, None, None, None, 0.0, None, 1, 16, None, k6, 0, 0, None) == -1
+    assert b"bad op" in built_lib.idiff_last_error()
+    assert built_lib.idiff_irsde_map(0, None, None, None, None, 0.0, None, 1, 16, None, k6, 0, 0, None) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch):
@@ -62,6 +66,11 @@ def test_ops_refuse_cpu_tensors(built_lib):
         ops.affine_silu_add(x)
     with pytest.raises(RuntimeError, match="GPU"):
         ops.irsde_reverse_step(x, x, x, None, 0.1, 0.1, 0.1, 0.1, 0.3)
+    sde = IRSDE(0.4, T=10, device=torch.device("cpu"))
+    with pytest.raises(RuntimeError, match="GPU"):  # the reference-surface methods go through the same C ABI: no torch-CPU arithmetic
+        sde.reverse_sde_step(x, x, 3)
+    with pytest.raises(RuntimeError, match="GPU"):
+        sde.mu_bar(x, torch.full((1, 1, 1, 1), 3))
 
 
 # ---- options / registries ---------------------------------------------------------------------------

@@ -126,3 +126,58 @@ def test_drift_sde_spec_identities():
     xT = cond + 0.4 * eps
     out = sde0.reverse_ddpm(cond, None, None, xT, [torch.zeros_like(x0)] * T)
     assert torch.allclose(out, x0, atol=2e-5)
+
+
+# ---- second fixture (tests/golden/make_golden_sde2.py): the full method surface, scalar and per-sample t, mu tensor and mu = 0. ----
+SURFACE = ["mu_bar", "drift", "sde_reverse_drift", "ode_reverse_drift", "dispersion", "score_from_noise", "forward_step",
+           "reverse_sde_step_mean", "reverse_sde_step", "reverse_ode_step", "real_noise", "real_score", "init_from_noise",
+           "reverse_optimum_step", "weights"]
+
+
+def surface_call(sde, name, i, t, inject):
+    """One method of the IRSDE surface on the golden2 inputs `i`; inject(z) -> the kwargs that carry the draw."""
+    x, x0, score, noise, z = i["x"], i["x0"], i["score"], i["noise"], i["z"]
+    return {
+        "mu_bar": lambda: sde.mu_bar(x0, t),
+        "drift": lambda: sde.drift(x, t),
+        "sde_reverse_drift": lambda: sde.sde_reverse_drift(x, score, t),
+        "ode_reverse_drift": lambda: sde.ode_reverse_drift(x, score, t),
+        "dispersion": lambda: sde.dispersion(x, t, *inject(z)[0], **inject(z)[1]),
+        "score_from_noise": lambda: sde.get_score_from_noise(noise, t),
+        "forward_step": lambda: sde.forward_step(x, t, *inject(z)[0], **inject(z)[1]),
+        "reverse_sde_step_mean": lambda: sde.reverse_sde_step_mean(x, score, t),
+        "reverse_sde_step": lambda: sde.reverse_sde_step(x, score, t, *inject(z)[0], **inject(z)[1]),
+        "reverse_ode_step": lambda: sde.reverse_ode_step(x, score, t),
+        "real_noise": lambda: sde.get_real_noise(x, x0, t),
+        "real_score": lambda: sde.get_real_score(x, x0, t),
+        "init_from_noise": lambda: sde.get_init_state_from_noise(x, noise, t),
+        "reverse_optimum_step": lambda: sde.reverse_optimum_step(x, x0, t),
+        "weights": lambda: sde.weights(t),
+    }[name]()
+
+
+@pytest.mark.parametrize("mu_tag", ["mu", "mu0"])
+@pytest.mark.parametrize("tname", ["t1", "t42", "t100", "tt"])
+def test_method_surface_bit_exact(golden_sde2, mu_tag, tname):
+    g = golden_sde2
+    i = {k: torch.from_numpy(g[f"in/{k}"]) for k in ["x", "x0", "mu", "score", "noise", "z"]}
+    sde = sde_ref.IRSDERef(**CFGS["cos100"])
+    sde.set_mu(i["mu"] if mu_tag == "mu" else 0.)
+    t = torch.from_numpy(g["in/tt"]) if tname == "tt" else int(tname[1:])
+    for name in SURFACE:
+        key = f"{mu_tag}/{tname}/{name}"
+        if key not in g.files:
+            assert name == "reverse_optimum_step" and tname == "tt"
+            continue
+        out = surface_call(sde, name, i, t, lambda z: ((z,), {}))
+        assert np.array_equal(out.numpy(), g[key]), key
+
+
+def test_optimal_reverse_and_x0_score(golden_sde2):
+    g = golden_sde2
+    i = {k: torch.from_numpy(g[f"in/{k}"]) for k in ["x", "x0", "mu"]}
+    sde = sde_ref.IRSDERef(**CFGS["cos100"])
+    sde.set_mu(i["mu"])
+    assert np.array_equal(sde.optimal_reverse(i["x"], i["x0"], T=7).numpy(), g["opt/optimal_reverse_T7"])
+    sde.set_model(lambda xx, m, t, **kw: 0.8 * xx + 0.1 * m)
+    assert np.array_equal(sde.score_fn_(i["x"], 9, 1.0).numpy(), g["opt/score_fn_x0pred_t9"])

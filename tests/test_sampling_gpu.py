@@ -142,3 +142,32 @@ def test_graph_replay_is_bit_identical_to_eager_steps():
         outs.append(torch.from_numpy(model.get_visuals()).clone())
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1])
+
+
+def test_failed_graph_capture_keeps_the_step_count(monkeypatch):
+    """A capture that raises after the eager warm step must not cost a step: the chain equals the IDIFF_HIP_GRAPH=0 chain bit
+    for bit (the warm step is a real denoising step and is counted whether or not the capture then succeeds)."""
+    T, B, H = 6, 2, 32
+    model, sde = pipeline.build(phase="test", device=torch.device(DEV), T=T, seed=3)
+    model.set_eval()
+    batch = make_batch(B, H, seed=12)
+    g = torch.Generator().manual_seed(13)
+    x_T = (batch['input'] + 0.4 * torch.randn(batch['input'].shape, generator=g)).to(DEV)
+    noises = torch.randn((T,) + tuple(batch['input'].shape), generator=g).to(DEV)
+    outs = {}
+    for mode in ("eager", "graph", "broken"):
+        sde.hip_graph = mode != "eager"
+        if mode == "broken":
+            def boom(*a, **k):
+                raise RuntimeError("forced capture failure")
+            monkeypatch.setattr(torch.cuda, "graph", boom)
+        sde.set_seed(5)
+        model.feed_data(batch)
+        sde.set_seed(5)
+        calls0 = sde._calls
+        model.test(x_T=x_T, noises=noises)
+        assert sde._calls - calls0 == T, (mode, sde._calls - calls0)
+        outs[mode] = torch.from_numpy(model.get_visuals()).clone()
+    assert torch.isfinite(outs["eager"]).all()
+    assert torch.equal(outs["eager"], outs["graph"])
+    assert torch.equal(outs["eager"], outs["broken"])
