@@ -174,11 +174,29 @@ class ScoreMapModule(nn.Module):
     def forward(self, feat, text_encoder, idx=None):
         """feat [B,C,h,w] -> (score [B,K,h,w], sel [B,1,h,w] or None)."""
         B, C, H, W = feat.shape
-        K = self.n_cls
+        text = self.text_embeddings(text_encoder, B)  # [B,K,text_dim]
+        x, t2v = self._decoder_tokens(feat, text)
+        op = self.context_decoder.out_proj
+        # tv = text_to_visual(text) + gamma * out_proj(LN(x)): residual, per-column gain and LayerNorm fused into the last linear
+        tv = ops.linear_t(x, wT(op[1]), op[1].bias, res=t2v, gscale=self.gamma, ln=(op[0].weight, op[0].bias, op[0].eps))
+        return ops.scoremap(feat, tv.reshape(B, self.n_cls, C), idx)
+
+    def context_decode(self, feat, text):
+        """`ContextDecoder.forward(text, visual)` of the reference (_modified_BiomedCLIP.py:1236-1244) with visual = the tokens of
+        `feat` [B,C,h,w]: -> [B,K,C].  The same launches as forward() up to the last linear, which here is the plain out_proj
+        (no text_to_visual residual, no gamma); used to pin this path to outputs of the real reference class."""
+        B, C = feat.shape[:2]
+        x, _ = self._decoder_tokens(feat, text.contiguous(), cache_prefix=False)  # a caller-owned text tensor is not a stable cache key
+        op = self.context_decoder.out_proj
+        return ops.linear_t(x, wT(op[1]), op[1].bias, ln=(op[0].weight, op[0].bias, op[0].eps)).reshape(B, text.shape[1], C)
+
+    def _decoder_tokens(self, feat, text, cache_prefix=True):
+        """decoder state x [B*K, Wd] after the last TransformerDecoderLayer (before out_proj) and text_to_visual(text) [B*K, C]"""
+        B, C, H, W = feat.shape
+        K = text.shape[1]
         dec = self.context_decoder
         Wd, heads = dec.width, dec.heads
         dh = Wd // heads
-        text = self.text_embeddings(text_encoder, B)  # [B,K,text_dim]
         t2d = text.reshape(B * K, self.text_dim)
         # memory = LN(Linear(LN(feature tokens))), one fused pass (channel-major: [B, Wd, h*w])
         mp = dec.memory_proj
@@ -230,7 +248,7 @@ class ScoreMapModule(nn.Module):
                          l0.norm1.weight, l0.norm1.bias, l0.self_attn.q_proj.weight, l0.self_attn.k_proj.weight, l0.self_attn.v_proj.weight,
                          l0.self_attn.proj.weight, l0.self_attn.proj.bias, l0.norm2.weight, l0.norm2.bias, l0.cross_attn.q_proj.weight,
                          l0.cross_attn.k_proj.weight, mp[1].weight, mp[1].bias, mp[2].weight, self.text_to_visual.weight, self.text_to_visual.bias]
-        if torch.is_grad_enabled():
+        if torch.is_grad_enabled() or not cache_prefix:
             x, qf, t2v = text_prefix()
         else:
             x, qf, t2v = _PREP.get(("prefix", self, Cm), prefix_params, text_prefix)
@@ -246,9 +264,7 @@ class ScoreMapModule(nn.Module):
             x = ops.linear_t(av, wT(ca.proj), ca.proj.bias, res=x)
             hm = ops.linear_t(x, wT(layer.mlp[0]), layer.mlp[0].bias, act_out=ops.ACT_GELU, ln=(layer.norm3.weight, layer.norm3.bias, layer.norm3.eps))
             x = ops.linear_t(hm, wT(layer.mlp[3]), layer.mlp[3].bias, res=x)
-        op = dec.out_proj
-        tv = ops.linear_t(x, wT(op[1]), op[1].bias, res=t2v, gscale=self.gamma, ln=(op[0].weight, op[0].bias, op[0].eps))
-        return ops.scoremap(feat, tv.reshape(B, K, C), idx)
+        return x, t2v
 
 
 def _fold_memory_affine(lin, ln2, ca, Cm):

@@ -1,0 +1,27 @@
+"""Shared by tests/golden/make_golden_attn.py (generator, real reference classes) and the tests that replay attn_golden.npz:
+the case table and the seeded weights.  Weights are rebuilt from seeds instead of being stored (torch's CPU generator is
+platform-stable), so the fixture holds inputs and the reference's outputs only."""
+import zlib
+
+import torch
+
+# tag -> (dim, heads, N queries, M keys, weight seed)          Attention, _modified_BiomedCLIP.py:448-478
+ATTN_CASES = {"attn_self": (256, 4, 5, 5, 11), "attn_cross": (256, 4, 5, 300, 12), "attn_h8": (64, 8, 7, 33, 13)}
+LAYER_SEED = 77  # TransformerDecoderLayer(256, 4), :520-549
+# tag -> (decoder layers, visual_dim, visual tokens, weight seed)   ContextDecoder, :1194-1244 (reference default: 6 layers)
+DEC_CASES = {"dec_c64": (3, 64, 16 * 16, 167), "dec_c128": (3, 128, 8 * 8, 231), "dec_default6": (6, 256, 6 * 6, 362)}
+
+
+def seeded_state(module, seed, scale=0.08):
+    """state dict with every parameter replaced by seeded values of a useful size (LayerNorm gains around 1, biases non-zero);
+    each tensor's stream is keyed by its NAME, so the values do not depend on the order a class registers its sub-modules"""
+    sd = {}
+    for k, v in module.state_dict().items():
+        g = torch.Generator().manual_seed(seed * 1000003 + zlib.crc32(k.encode()))
+        if k.endswith("weight") and v.dim() == 1:  # LayerNorm gain
+            sd[k] = 1.0 + 0.2 * torch.randn(v.shape, generator=g)
+        elif v.dim() == 1:
+            sd[k] = 0.1 * torch.randn(v.shape, generator=g)
+        else:
+            sd[k] = scale * torch.randn(v.shape, generator=g)
+    return sd
