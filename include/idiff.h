@@ -32,6 +32,9 @@ typedef void* idiff_stream_t;
 
 const char* idiff_last_error(void);
 int idiff_version(void);
+/* kernel launches this library has enqueued since it was loaded (bench.py reports launches per denoising step; under HIP-graph
+ * capture the counter advances at capture time, not per replay) */
+int64_t idiff_launch_count(void);
 /* number of compute units etc. of the current device (plumbing for grid sizing / tests) */
 int idiff_device_info(int* num_cu, int* wave_size, char* arch_name, int arch_name_len);
 

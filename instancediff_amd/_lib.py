@@ -39,6 +39,7 @@ P, I, I64, F, U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 SIGNATURES = {
     "idiff_last_error": (C.c_char_p, []),
     "idiff_version": (I, []),
+    "idiff_launch_count": (I64, []),
     "idiff_device_info": (I, [C.POINTER(I), C.POINTER(I), C.c_char_p, I]),
     "idiff_conv2d_num_tiles": (I, [I, I]),
     "idiff_conv2d_fwd": (I, [C.POINTER(ConvDesc), c_stream]),

@@ -360,12 +360,14 @@ __global__ __launch_bounds__(256) void smm_xattn_combine_kernel(const float* __r
 }
 
 inline void smm_split(int B, int N, int* nsplit, int* kps) {
+    // The split is a function of N alone, so a sample's reduction order (and its bits) does not depend on the batch it sits
+    // in: 32..1024 keys per split, at most 64 splits up to N = 65536 (256 at the 512x512 level).  At batch 16 this is the
+    // split the old batch-dependent rule chose; small batches get fewer, longer splits (the launch is latency-bound there).
+    (void)B;
     const int nkb = (N + 31) / 32;
-    int target = 1024 / (B > 0 ? B : 1);
-    if (target < 1) target = 1;
-    if (target > 256) target = 256;  // one workgroup per CU is enough; every extra split is serial work for the combine
-    int k = (nkb + target - 1) / target;
+    int k = nkb / 64;
     if (k < 2) k = 2;
+    if (k > 32) k = 32;
     if (k > nkb) k = nkb;
     *kps = k;
     *nsplit = (nkb + k - 1) / k;

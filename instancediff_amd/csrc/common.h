@@ -8,6 +8,7 @@
 #include "../../include/idiff.h"
 
 extern thread_local char g_idiff_err[512];
+extern unsigned long long g_idiff_launches;  // kernel launches enqueued by this library (idiff_launch_count)
 
 #define IDIFF_FAIL(code, ...)                                   \
     do {                                                        \
@@ -22,6 +23,7 @@ extern thread_local char g_idiff_err[512];
 
 #define IDIFF_CHECK_LAUNCH(name)                                                               \
     do {                                                                                       \
+        ++g_idiff_launches;                                                                    \
         hipError_t e__ = hipGetLastError();                                                    \
         if (e__ != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "%s: %s", name, hipGetErrorString(e__)); \
     } while (0)

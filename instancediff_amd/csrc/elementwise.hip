@@ -5,7 +5,9 @@
 thread_local char g_idiff_err[512] = "";
 
 extern "C" const char* idiff_last_error(void) { return g_idiff_err; }
-extern "C" int idiff_version(void) { return 1; }
+unsigned long long g_idiff_launches = 0;
+extern "C" int idiff_version(void) { return 2; }
+extern "C" int64_t idiff_launch_count(void) { return (int64_t)g_idiff_launches; }
 extern "C" int idiff_device_info(int* num_cu, int* wave_size, char* arch_name, int arch_name_len) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);

@@ -564,11 +564,12 @@ def score_map_losses(score_maps, label, loss_rec, slot0, mult=(1, 2, 4, 8), size
     return grads
 
 
-def train_step_inputRes(model):
-    """One optimisation step with the reference's active objective (drift_noise_model.py:242-312):
+def forward_backward_inputRes(model):
+    """Forward of both nets, the reference's active objective and its backward (drift_noise_model.py:242-294):
        pred_drift, dsm = drift_net(x_t - LQ, LQ, t, ...) ; pred_noise, nsm = noise_net(x_t - LQ, x_t, t, ...)
        loss = MSE(pred_drift, LQ-GT) + MSE(pred_noise, std_noise) + pyramid(dsm, LQ-GT) + pyramid(nsm, std_noise)
-    Losses and their gradients come from the HIP loss kernel; autograd is entered with explicit output gradients."""
+    Losses and their gradients come from the HIP loss kernel; autograd is entered with explicit output gradients.  Leaves the
+    parameter gradients in the optimizers' flat buffers; returns (loss record [10] on the device, forward time, use_dsm, use_nsm)."""
     import time
     st = time.time()
     m = model
@@ -594,6 +595,14 @@ def train_step_inputRes(model):
     m.noise_optimizer.zero_grad()
     m.drift_optimizer.zero_grad()
     torch.autograd.backward(outs, grads)
+    return rec, iter_time, use_dsm, use_nsm
+
+
+def train_step_inputRes(model):
+    """One optimisation step (drift_noise_model.py:242-312): forward_backward_inputRes, the data-parallel gradient exchange,
+    two Adam steps, loss bookkeeping with ONE device->host copy."""
+    m = model
+    rec, iter_time, use_dsm, use_nsm = forward_backward_inputRes(m)
     scale = 1.0
     if m.grad_sync is not None:
         scale = m.grad_sync.all_reduce_flat(m.drift_optimizer.flat_grads() + m.noise_optimizer.flat_grads())

@@ -59,11 +59,22 @@ def test_token_attention_kernel_matches_reference_attention(golden_attn, tag):
     q = torch.from_numpy(golden_attn[f"{tag}/q"]).to(DEV)
     kv = torch.from_numpy(golden_attn[f"{tag}/kv"]).to(DEV)
     B = q.shape[0]
-    qp = ops.linear_t(q.reshape(B * N, dim), sd["q_proj.weight"].t().contiguous()).reshape(B, N, dim)
-    kp = ops.linear_t(kv.reshape(B * M, dim), sd["k_proj.weight"].t().contiguous()).reshape(B, M, dim)
-    vp = ops.linear_t(kv.reshape(B * M, dim), sd["v_proj.weight"].t().contiguous()).reshape(B, M, dim)
-    a = ops.attn_tokens(qp, kp, vp, heads, (dim // heads) ** -0.5)
-    out = ops.linear_t(a.reshape(B * N, dim), sd["proj.weight"].t().contiguous(), sd["proj.bias"]).reshape(B, N, dim)
+    scale = (dim // heads) ** -0.5
+    dh = dim // heads
+    qp = ops.linear_t(q.reshape(B * N, dim), sd["q_proj.weight"].t().contiguous())
+    if M <= 64:  # token-side attention (ScoreMapModule self-attention kernel)
+        kp = ops.linear_t(kv.reshape(B * M, dim), sd["k_proj.weight"].t().contiguous()).reshape(B, M, dim)
+        vp = ops.linear_t(kv.reshape(B * M, dim), sd["v_proj.weight"].t().contiguous()).reshape(B, M, dim)
+        a = ops.attn_tokens(qp.reshape(B, N, dim), kp, vp, heads, scale).reshape(B * N, dim)
+    else:  # few queries, many keys: the ScoreMapModule cross-attention kernel, K/V projections folded onto the queries
+        wk, wvT = sd["k_proj.weight"].contiguous(), sd["v_proj.weight"].t().contiguous()
+        qf = torch.empty((B * N, heads * dim), device=DEV)
+        ops.linear_t_heads(qp, wk, None, qf, heads, dh, dim, x_hs=dh, w_hs=dh * wk.stride(0), b_hs=0, o_hs=dim)
+        mem = kv.permute(0, 2, 1).contiguous()  # [B, C, M]: keys on the fast axis, as feature maps are stored
+        o = ops.smm_xattn(qf.reshape(B, N, heads, dim), mem, scale).reshape(B * N, heads * dim)
+        a = torch.empty((B * N, dim), device=DEV)
+        ops.linear_t_heads(o, wvT, None, a, heads, dim, dh, x_hs=dim, w_hs=dh, b_hs=dh, o_hs=dh)
+    out = ops.linear_t(a, sd["proj.weight"].t().contiguous(), sd["proj.bias"]).reshape(B, N, dim)
     err = rel_err(out, golden_attn[f"{tag}/out"])
     print(f"{tag}: rel err vs real reference Attention {err:.2e}")
     assert err < 1e-5

@@ -1,0 +1,244 @@
+"""BASELINE.json configurations at their own sizes, against the oracle where the oracle finishes in seconds and through
+size-independent properties at the full batch:
+
+  c2 / c4  256x256, five-modality mixed batch: a B=5 slice (one image per artifact type of Configurations/config.yml:15) of the
+           B=16 batch runs a 2-step injected-noise chain against the oracle's CPU chain; the full B=16 run must reproduce those five
+           samples BIT FOR BIT (batch invariance: catches sample-index / stride / persistent-work-item bugs at batch 16 without
+           oracle cost -- every reduction of the path is per sample, the key split of the ScoreMapModule cross-attention included).
+  c5       512x512: B=1 2-step chain against the oracle, B=8 batch invariance, and the two kernels whose sizes only occur here
+           (self-attention over N = 4096 tokens, ScoreMapModule cross-attention over N = 262 144 keys) against fp64 references.
+  c3       training: one step at 256x256 B=2 against the oracle's torch autograd; at B=32 the gradient must equal the mean of the 16
+           micro-batch gradients (linearity of the backward in the batch).
+  T=1000   a full 1000-step chain (T=1000 coefficient tables, error accumulation over the whole schedule) at 64x64 B=1.
+
+fp32 throughout; tolerance: |dPSNR| < 1e-3 dB (north_star) and max|diff| < 5e-4 against the oracle, equality for the properties.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from instancediff_amd import ops, pipeline, train_ops  # noqa: E402
+from instancediff_amd.utils.synthetic import ARTIFACT_TYPES, make_batch  # noqa: E402
+from oracle import sde_ref, unet_ref  # noqa: E402
+from tests.test_sampling_gpu import oracle_nets  # noqa: E402
+
+DEV = "cuda"
+
+
+def _slice(batch, n):
+    return {k: (v[:n] if not isinstance(v, list) else v[:n]) for k, v in batch.items()}
+
+
+def _chain(model, batch, x_T, noises):
+    model.feed_data(batch)
+    model.test(x_T=x_T.to(DEV), noises=noises.to(DEV))
+    return torch.from_numpy(model.get_visuals()).clone()
+
+
+def _oracle_chain(model, T, batch, x_T, noises):
+    refs = oracle_nets(model)
+    rsde = sde_ref.DriftSDERef(T, refs[0], refs[1], max_sigma=0.4)
+    with torch.no_grad():
+        return rsde.reverse_ddpm(batch['input'], batch['names'], unet_ref.StubTextEncoder(), x_T, noises, image_context=batch['A_emb'])
+
+
+def _check_vs_oracle(out, ref, target, what):
+    err = float((out - ref).abs().max())
+    worst = 0.0
+    for b in range(out.shape[0]):  # per image (testUM.py computes PSNR per image)
+        worst = max(worst, abs(sde_ref.psnr(out[b], target[b]) - sde_ref.psnr(ref[b], target[b])))
+    print(f"{what}: max|hip-oracle| {err:.3e}, worst per-image |dPSNR| {worst:.2e} dB")
+    assert torch.isfinite(out).all()
+    assert worst < 1e-3 and err < 5e-4, (what, worst, err)
+
+
+def test_c4_c2_five_modalities_vs_oracle_and_batch16_invariance():
+    T, H = 2, 256
+    model, sde = pipeline.build(phase="test", device=torch.device(DEV), T=T, seed=0)
+    model.set_eval()
+    b16 = make_batch(16, H, seed=2024)
+    assert b16['names'][:5] == ARTIFACT_TYPES  # one image per modality in the first five
+    g = torch.Generator().manual_seed(2025)
+    x_T = b16['input'] + 0.4 * torch.randn(b16['input'].shape, generator=g)
+    noises = torch.randn((T,) + tuple(b16['input'].shape), generator=g)
+    out16 = _chain(model, b16, x_T, noises)
+    out5 = _chain(model, _slice(b16, 5), x_T[:5], noises[:, :5].contiguous())
+    assert out16.shape == (16, 1, H, H) and torch.isfinite(out16).all()
+    assert torch.equal(out16[:5], out5), f"batch-16 run differs from the batch-5 run on the same samples: {(out16[:5] - out5).abs().max()}"
+    # a different neighbourhood as well: samples 8..15 alone
+    b8 = {k: v[8:] for k, v in b16.items()}
+    out8 = _chain(model, b8, x_T[8:], noises[:, 8:].contiguous())
+    assert torch.equal(out16[8:], out8)
+    ref5 = _oracle_chain(model, T, _slice(b16, 5), x_T[:5], noises[:, :5])
+    _check_vs_oracle(out5, ref5, b16['target'][:5], "c4 256x256 five modalities")
+
+
+def test_c5_512_chain_vs_oracle_and_batch8_invariance():
+    T, H = 2, 512
+    model, sde = pipeline.build(phase="test", device=torch.device(DEV), T=T, seed=0)
+    model.set_eval()
+    b8 = make_batch(8, H, seed=512)
+    g = torch.Generator().manual_seed(513)
+    x_T = b8['input'] + 0.4 * torch.randn(b8['input'].shape, generator=g)
+    noises = torch.randn((T,) + tuple(b8['input'].shape), generator=g)
+    out8 = _chain(model, b8, x_T, noises)
+    out1 = _chain(model, _slice(b8, 1), x_T[:1], noises[:, :1].contiguous())
+    assert torch.isfinite(out8).all()
+    assert torch.equal(out8[:1], out1), f"{(out8[:1] - out1).abs().max()}"
+    out_last = _chain(model, {k: v[7:] for k, v in b8.items()}, x_T[7:], noises[:, 7:].contiguous())
+    assert torch.equal(out8[7:], out_last)
+    ref1 = _oracle_chain(model, T, _slice(b8, 1), x_T[:1], noises[:, :1])
+    _check_vs_oracle(out1, ref1, b8['target'][:1], "c5 512x512")
+
+
+def test_c5_self_attention_4096_tokens_vs_fp64():
+    """the mid-block self-attention at the 512x512 input's lowest level: N = 64*64 = 4096 tokens, 4 heads x 64"""
+    g = torch.Generator().manual_seed(40)
+    B, C, H, heads = 2, 256, 64, 4
+    qkv = torch.randn(B, 3 * C, H, H, generator=g) * 0.7
+    q, k, v = [t.reshape(B, heads, C // heads, H * H).double() for t in qkv.chunk(3, dim=1)]
+    scale = (C // heads) ** -0.5
+    att = (torch.einsum('bhcn,bhcm->bhnm', q, k) * scale).softmax(-1)
+    ref = torch.einsum('bhnm,bhcm->bhcn', att, v).reshape(B, C, H, H)
+    out = ops.attn_self(qkv.to(DEV), heads, scale)
+    err = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
+    print(f"attn_self N=4096: rel err {err:.2e}")
+    assert err < 1e-5
+
+
+@pytest.mark.parametrize("Cm", [72, 136])
+def test_c5_scoremap_cross_attention_262144_keys_vs_fp64(Cm):
+    """ScoreMapModule cross-attention at level 0 of a 512x512 input: 20 query rows against N = 512*512 keys"""
+    g = torch.Generator().manual_seed(41)
+    B, Nq, heads, N = 2, 5, 4, 512 * 512
+    qf = torch.randn(B, Nq, heads, Cm, generator=g) * 0.3
+    mem = torch.randn(B, Cm, N, generator=g)
+    scale = 0.125
+    s = torch.einsum('bqhc,bcn->bqhn', qf.double(), mem.double()) * scale
+    ref = torch.einsum('bqhn,bcn->bqhc', s.softmax(-1), mem.double())
+    out = ops.smm_xattn(qf.to(DEV), mem.to(DEV), scale)
+    err = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
+    print(f"smm_xattn N=262144 Cm={Cm}: rel err {err:.2e}")
+    assert err < 2e-5
+    # batch invariance of the key split: sample 1 alone gives the same bits
+    out1 = ops.smm_xattn(qf[1:].contiguous().to(DEV), mem[1:].contiguous().to(DEV), scale)
+    assert torch.equal(out[1:], out1)
+
+
+# ---------------------------------------------------------------------------------------------------
+def _set_train_inputs(model, sde, batch, t, eps):
+    model.input = batch['input'].to(DEV)
+    model.target = batch['target'].to(DEV)
+    model.names = list(batch['names'])
+    model.A_emb = batch['A_emb'].to(DEV)
+    model.t, model.drift_noised_x, _, model.std_noise, _ = sde.forward_diffusion(model.target, model.input, t=t, eps=eps.to(DEV))
+
+
+def _flat_grads(model):
+    return torch.cat([g.reshape(-1) for g in model.drift_optimizer.flat_grads() + model.noise_optimizer.flat_grads()]).clone()
+
+
+def test_c3_train_step_256_vs_oracle_autograd():
+    B, H, T_ = 2, 256, 100
+    model, sde = pipeline.build(phase="train", device=torch.device(DEV), T=T_, seed=0)
+    model.set_train()
+    with torch.no_grad():  # let the score-map branch carry gradient signal (gamma is 1e-4 at init)
+        for net in (model.drift_net, model.noise_net):
+            for m in net.CLIP_ScoreMapModule:
+                m.gamma.fill_(0.3)
+    rd, rn = oracle_nets(model)
+    rd.train(), rn.train()
+    te = unet_ref.StubTextEncoder()
+    batch = make_batch(B, H, seed=31)
+    g = torch.Generator().manual_seed(32)
+    t = torch.tensor([[[[7]]], [[[63]]]])
+    eps = torch.randn(batch['input'].shape, generator=g)
+    osde = sde_ref.DriftSDERef(T_, rd, rn, max_sigma=0.4)
+    _, x_t, _, std_noise, _ = osde.forward_diffusion(batch['target'], batch['input'], t, eps)
+    tt = t.reshape(-1)
+    pd, dsm = rd(x_t - batch['input'], batch['input'], tt, batch['names'], te, image_context=batch['A_emb'])
+    pn, nsm = rn(x_t - batch['input'], x_t, tt, batch['names'], te, image_context=batch['A_emb'])
+    tgt = batch['input'] - batch['target']
+
+    def pyr(sms, lab):  # drift_noise_model.py:234-240 with torchvision-0.14 tensor Resize semantics (bilinear, no antialias)
+        tot = 0
+        for i, sm in enumerate(sms):
+            lb = lab if i == 0 else F.interpolate(lab, size=(H >> i, H >> i), mode="bilinear", align_corners=False, antialias=False)
+            tot = tot + F.mse_loss(sm, lb)
+        return tot / 2.0
+    l0 = F.mse_loss(pd, tgt) + F.mse_loss(pn, std_noise) + pyr(dsm, tgt) + pyr(nsm, std_noise)
+    l0.backward()
+    _set_train_inputs(model, sde, batch, t, eps)
+    rec, _, _, _ = train_ops.forward_backward_inputRes(model)
+    r = rec.cpu()
+    loss = float(r[0] + r[1] + r[2:6].sum() / 2 + r[6:10].sum() / 2)
+    assert abs(loss - float(l0)) < 2e-5 * abs(float(l0)), (loss, float(l0))
+    worst = 0.0
+    for net, ref, tag in ((model.drift_net, rd, "d"), (model.noise_net, rn, "n")):
+        refg = dict(ref.named_parameters())
+        for k, p in net.named_parameters():
+            rg = refg[k].grad
+            scale = float(rg.abs().max())
+            if scale < 1e-12:
+                assert float(p.grad.abs().max()) < 1e-9, (tag, k)
+                continue
+            e = float((p.grad.cpu() - rg).abs().max()) / scale
+            worst = max(worst, e)
+            assert e < 2e-3, (tag, k, e)
+    print(f"c3 256x256 B=2: loss {loss:.6f} (oracle {float(l0):.6f}), worst relative parameter-gradient error {worst:.2e}")
+
+
+def test_c3_batch32_gradient_is_mean_of_microbatch_gradients():
+    B, H, T_, MB = 32, 256, 100, 2
+    model, sde = pipeline.build(phase="train", device=torch.device(DEV), T=T_, seed=0)
+    model.set_train()
+    with torch.no_grad():
+        for net in (model.drift_net, model.noise_net):
+            for m in net.CLIP_ScoreMapModule:
+                m.gamma.fill_(0.3)
+    batch = make_batch(B, H, seed=33)
+    g = torch.Generator().manual_seed(34)
+    t = torch.randint(1, T_ + 1, (B, 1, 1, 1), generator=g)
+    eps = torch.randn(batch['input'].shape, generator=g)
+    _set_train_inputs(model, sde, batch, t, eps)
+    rec, _, _, _ = train_ops.forward_backward_inputRes(model)
+    full = _flat_grads(model)
+    rec_full = rec.clone()
+    acc = torch.zeros_like(full, dtype=torch.float64)
+    rec_acc = torch.zeros(10, dtype=torch.float64, device=DEV)
+    for i in range(0, B, MB):
+        mb = {k: v[i:i + MB] for k, v in batch.items()}
+        _set_train_inputs(model, sde, mb, t[i:i + MB], eps[i:i + MB])
+        rec, _, _, _ = train_ops.forward_backward_inputRes(model)
+        acc += _flat_grads(model).double()
+        rec_acc += rec.double()
+    acc /= B // MB
+    rec_acc /= B // MB
+    assert torch.isfinite(full).all() and float(full.abs().max()) > 0
+    err = float((full.double() - acc).abs().max() / acc.abs().max())
+    lerr = float((rec_full.double() - rec_acc).abs().max() / rec_acc.abs().max())
+    print(f"c3 B=32 vs 16 micro-batches of 2: gradient rel err {err:.2e}, loss-record rel err {lerr:.2e}")
+    assert err < 2e-5 and lerr < 1e-5
+    # the full step then runs (Adam on the flat buffers) and the loss is finite
+    _set_train_inputs(model, sde, batch, t, eps)
+    loss, _ = model.optimize_parameters()
+    assert math.isfinite(loss)
+
+
+def test_full_1000_step_chain_vs_oracle():
+    """T = 1000 (BASELINE configs 2, 5): the whole schedule -- 1000-row coefficient tables, graph replay across every t, error
+    accumulation over 1000 dependent steps -- at a size the oracle finishes in about a minute."""
+    T, B, H = 1000, 1, 64
+    model, sde = pipeline.build(phase="test", device=torch.device(DEV), T=T, seed=0)
+    model.set_eval()
+    batch = make_batch(B, H, seed=1000)
+    g = torch.Generator().manual_seed(1001)
+    x_T = batch['input'] + 0.4 * torch.randn(batch['input'].shape, generator=g)
+    noises = torch.randn((T,) + tuple(batch['input'].shape), generator=g)
+    out = _chain(model, batch, x_T, noises)
+    ref = _oracle_chain(model, T, batch, x_T, noises)
+    _check_vs_oracle(out, ref, batch['target'], "1000-step chain 64x64")
