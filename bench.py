@@ -10,11 +10,16 @@ update, fp32, random-init weights (seed 0), inputs resident in HBM, on-device Ph
 independent replicas (sampling shards by image, no data-path collective) -> weak scaling.
 
 Prints ONE JSON line: metric/value/... plus
-  roofline     : dominant kernel = the Winograd F(2x2,3x3) conv on the f32 matrix cores; ALGORITHMIC (direct-form) FLOP per
-                 launch / average launch duration (HIP events on the launch stream, second single-stream pass over the
-                 same K steps), against the 157.3 TFLOP/s f32-MFMA peak (MI355X_MICROARCH.md).  The kernel executes
-                 16/36 of the algorithmic multiply-adds, so `frac` can exceed 1; `executed_frac` is the matrix-pipe share.
-  cpu_baseline : the oracle (plain PyTorch fp32 restatement of the same step) on the host cores, bounded sample.
+  roofline     : dominant kernel = the Winograd F(2x2,3x3) conv on the f32 matrix cores.  `achieved` = the matrix-core FLOP the
+                 kernel's algorithm EXECUTES per launch (16 multiply-adds per output 2x2 tile, channel pair and tile: 16/36 of the
+                 direct form) / average launch duration (HIP events on the launch stream, a second single-stream eager pass over
+                 the same K steps); `peak` = 157.3 TFLOP/s f32 MFMA (MI355X_MICROARCH.md); `frac` = achieved / peak = the share of
+                 the matrix pipe in use.  `effective_tflops` is the direct-form rate (x `algorithmic_speedup` 2.25), `step_frac` the
+                 executed conv FLOP of a whole step / ms_per_step / peak.  `traffic` comes from a rocprofv3 --pmc pass stored under
+                 profiles/ together with a hash of the kernel sources; a stale file (sources changed since) is not reported.
+  cpu_baseline : the oracle (plain PyTorch fp32 restatement of the same step) on the host cores, at the named batch when one
+                 step fits the time budget (else a stated fraction of the batch), 1 warm + >= 1 timed step.
+  graph / launches_per_step : whether the timed loop replayed a captured HIP graph, and how many kernels one step enqueues.
 """
 import argparse
 import json
@@ -39,7 +44,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--T", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=1)
+    ap.add_argument("--cpu-sample-batch", type=int, default=0, help="images per CPU-baseline step (0 = the full batch when one step "
+                    "is estimated to fit --cpu-budget-s, else 4)")
+    ap.add_argument("--cpu-budget-s", type=float, default=75.0, help="time budget of the CPU-baseline leg (warm + timed steps)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--mode", choices=["sample", "train", "irsde"], default="sample",
                     help="sample = headline denoising-steps/s metric (driftSDE: 2 UNet forwards + update per step); train = secondary "
@@ -104,14 +111,13 @@ def host_cores():
 
 
 def cpu_baseline(args, batch_full):
-    """Oracle step (2 oracle UNet forwards + oracle reverse update) on the host cores, on a bounded sample of the
-    same workload: the first `cpu_sample_batch` images of the batch; steps/s is scaled to the full batch."""
+    """Oracle step (2 oracle UNet forwards + oracle reverse update) on the host cores: 1 warm + >= 1 timed step at the NAMED batch
+    when that fits the budget; otherwise on the first 4 images, with the measured B=1 -> B=4 scaling stated next to it."""
     import torch.nn as nn
     from oracle import sde_ref, unet_ref
     from instancediff_amd import pipeline
     ncores = host_cores()
     torch.set_num_threads(ncores)
-    bs = min(args.cpu_sample_batch, args.batch)
     opt = pipeline.load_options()
     mo = opt['models']['DriftNoise']
     nets = []
@@ -122,34 +128,78 @@ def cpu_baseline(args, batch_full):
         nets.append(unet_ref.LearnableForwardUNet_MultiScoreMap(CLIP_ScoreMapModule=smm, use_image_context=True, **s).eval())
     te = unet_ref.StubTextEncoder()
     sde = sde_ref.DriftSDERef(args.T, nets[0], nets[1], max_sigma=0.4)
-    cond = batch_full['input'][:bs]
-    names = batch_full['names'][:bs]
-    ctx = batch_full['A_emb'][:bs]
     g = torch.Generator().manual_seed(4321)
-    x = cond + 0.4 * torch.randn(cond.shape, generator=g)
 
-    def one(x, t):
-        tt = torch.full((bs,), t, dtype=torch.long)
-        with torch.no_grad():
-            rd = nets[0](x - cond, cond, tt, names, te, image_context=ctx)[0]
-            rn = nets[1](x - cond, x, tt, names, te, image_context=ctx)[0]
-        z = torch.randn(cond.shape, generator=g)
-        return sde_ref.drift_reverse_update(x, rd, rn, z, sde.a[t], sde.b[t], sde.c[t])
+    def run(bs, nsteps, budget):
+        """(seconds per step, steps timed) at batch bs: one warm step, then up to nsteps timed steps within the budget"""
+        cond, names, ctx = batch_full['input'][:bs], batch_full['names'][:bs], batch_full['A_emb'][:bs]
+        x = cond + 0.4 * torch.randn(cond.shape, generator=g)
 
-    log("cpu oracle built, warm step (B=%d)" % bs)
-    x = one(x, args.T)  # warm
-    log("cpu warm step done")
-    n, t0 = 0, time.time()
-    while True:
-        x = one(x, args.T - 1 - n)
-        n += 1
-        el = time.time() - t0
-        if el > 12.0 or n >= 3:
-            break
-    sps_sample = n / el
-    return {"value": sps_sample * bs / args.batch, "unit": "denoising steps/s (batch %d)" % args.batch, "cores": ncores, "kind": "port",
-            "sample": "%d timed step(s) of the oracle on the first %d of %d images (%.2f s/step at B=%d), scaled by %d/%d; torch %d threads"
-                      % (n, bs, args.batch, el / n, bs, bs, args.batch, ncores)}
+        def one(x, t):
+            tt = torch.full((bs,), t, dtype=torch.long)
+            with torch.no_grad():
+                rd = nets[0](x - cond, cond, tt, names, te, image_context=ctx)[0]
+                rn = nets[1](x - cond, x, tt, names, te, image_context=ctx)[0]
+            z = torch.randn(cond.shape, generator=g)
+            return sde_ref.drift_reverse_update(x, rd, rn, z, sde.a[t], sde.b[t], sde.c[t])
+
+        x = one(x, args.T)  # warm
+        n, t0 = 0, time.time()
+        while True:
+            x = one(x, args.T - 1 - n)
+            n += 1
+            el = time.time() - t0
+            if n >= nsteps or el + el / n > budget:
+                break
+        return el / n, n
+
+    t_start = time.time()
+    log("cpu oracle built (%d threads); probing B=1" % ncores)
+    s1, _ = run(1, 1, 30.0)
+    bs = args.cpu_sample_batch or args.batch
+    est = s1 * bs * 2.0  # warm + one timed step at linear scaling (batch-16 convs thread better than B=1: an upper estimate)
+    if not args.cpu_sample_batch and est > args.cpu_budget_s:
+        bs = min(4, args.batch)
+    log("cpu: %.2f s/step at B=1; timing B=%d" % (s1, bs))
+    sec, n = run(bs, 2, max(args.cpu_budget_s - (time.time() - t_start), 5.0))
+    sps = 1.0 / sec * bs / args.batch
+    sample = ("1 warm + %d timed step(s) of the oracle at batch %d of %d (%.2f s/step)" % (n, bs, args.batch, sec))
+    if bs < args.batch:
+        sample += ", scaled by %d/%d" % (bs, args.batch)
+    sample += "; B=1 probe %.2f s/step (B-scaling %.2fx per image vs B=1); torch %d threads" % (s1, (sec / bs) / s1, ncores)
+    return {"value": round(sps, 5), "unit": "denoising steps/s (batch %d)" % args.batch, "cores": ncores, "kind": "port",
+            "batch_timed": bs, "sample": sample}
+
+
+def kernel_source_hash():
+    """sha256 over the HIP sources + headers of the kernel library: the staleness key of stored PMC traffic figures"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "instancediff_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "instancediff_amd", "csrc", "*.h"))):
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the newest profiles/r*/pmc_traffic.json (written by scripts/pmc_traffic.py
+    from separate rocprofv3 --pmc passes of this command).  Reported only if the file was measured on the same kernel sources."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))
+    if not cands:
+        return {"traffic": None, "traffic_note": "no PMC pass stored"}
+    try:
+        with open(cands[-1]) as f:
+            pmc = json.load(f)
+        if pmc.get("kernel_source_hash") != kernel_source_hash():
+            return {"traffic": None, "traffic_note": "stored PMC pass (%s) is stale: kernel sources changed since (%s != %s)"
+                    % (os.path.relpath(cands[-1], ROOT), pmc.get("kernel_source_hash"), kernel_source_hash())}
+        return {"traffic": pmc["hbm_bytes_per_launch"], "traffic_unit": "bytes/launch (%s)" % pmc.get("formula", "2*FETCH_SIZE + WRITE_SIZE"),
+                "traffic_source": os.path.relpath(cands[-1], ROOT), "traffic_commit": pmc.get("commit"),
+                "traffic_from_profile": True}
+    except (OSError, KeyError, ValueError) as e:
+        return {"traffic": None, "traffic_note": repr(e)}
 
 
 def log(msg):
@@ -330,42 +380,44 @@ def main():
     log("timed region: %.3f s for %d steps" % (el, args.steps))
 
     roof = None
+    launches_per_step = None
     if rank == 0 and not args.no_roofline:
         # second pass over the same K steps, on ONE stream (the timed region overlaps the two nets on two streams, which
         # would smear per-launch event times), every conv launch bracketed by HIP events on its launch stream
         two = sde.two_streams
         sde.two_streams = False
         ops.PROFILE = []
+        lib = ops._lib.load()
+        n0 = lib.idiff_launch_count()
         for _ in range(args.steps):
             run.step()  # eager: per-launch events cannot be recorded inside a graph replay
+        launches_per_step = (lib.idiff_launch_count() - n0) / args.steps
         torch.cuda.synchronize()
         sde.two_streams = two
         # dominant kernel = conv_wino_kernel: every 3x3 conv whose shape tiles exactly (idiff_conv2d_last_algo() == 1)
         recs = [r for r in ops.PROFILE if r['algo'] == 1]
         allrecs = ops.PROFILE
         ops.PROFILE = None
+        WINO = 16.0 / 36.0  # F(2x2,3x3): 16 multiply-adds where the direct form does 36
         tot_ms = sum(r['e0'].elapsed_time(r['e1']) for r in recs)
-        tot_fl = sum(r['flops'] for r in recs)
+        tot_fl = sum(r['flops'] for r in recs)  # direct-form count 2*Cin*Cout*9*H*W*B
         all_ms = sum(r['e0'].elapsed_time(r['e1']) for r in allrecs)
         all_fl = sum(r['flops'] for r in allrecs)
-        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        exec_fl_step = (tot_fl * WINO + (all_fl - tot_fl)) / args.steps  # matrix-core FLOP one step really executes (all convs)
+        eff = tot_fl / (tot_ms * 1e-3) / 1e12
+        ach = eff * WINO
         roof = {"bound": "mfma", "kernel": "conv_wino_kernel (3x3 conv, Winograd F(2x2,3x3) on f32 MFMA)", "achieved": round(ach, 2),
                 "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                "flop_count": "algorithmic = direct-form 2*Cin*Cout*9*H*W*B per launch; the kernel executes 16/36 of them",
-                "executed_tflops": round(ach * 16 / 36, 2), "executed_frac": round(ach * 16 / 36 / F32_MFMA_PEAK_TFLOPS, 4),
+                "flop_count": "executed = 16/36 of the direct-form 2*Cin*Cout*9*H*W*B per launch (Winograd F(2x2,3x3))",
+                "algorithmic_speedup": 2.25, "effective_tflops": round(eff, 2),
+                "step_frac": round(exec_fl_step / (el / args.steps) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                "step_executed_gflop": round(exec_fl_step / 1e9, 1),
                 "launches": len(recs), "avg_launch_ms": round(tot_ms / max(len(recs), 1), 4),
-                "gflop_per_launch": round(tot_fl / max(len(recs), 1) / 1e9, 3),
+                "executed_gflop_per_launch": round(tot_fl * WINO / max(len(recs), 1) / 1e9, 3),
                 "conv_ms_per_step_single_stream": round(all_ms / args.steps, 3),
                 "wino_ms_per_step_single_stream": round(tot_ms / args.steps, 3),
-                "all_conv_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2),
-                "step_conv_gflop": round(all_fl / args.steps / 1e9, 1)}
-        try:  # HBM bytes per launch of the same kernel from a separate rocprofv3 --pmc run of this command (profiles/)
-            with open(os.path.join(ROOT, "profiles", "r01", "f_pmc_traffic.json")) as f:
-                pmc = json.load(f)
-            roof["traffic"] = pmc["hbm_bytes_per_launch"]
-            roof["traffic_unit"] = "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/r01/f_pmc_traffic.json)"
-        except (OSError, KeyError, ValueError):
-            pass
+                "step_conv_gflop_direct_form": round(all_fl / args.steps / 1e9, 1)}
+        roof.update(pmc_traffic())
     if world > 1:
         barrier()
 
@@ -381,7 +433,8 @@ def main():
         line = {"metric": "denoising steps/sec (%dx%d bs%d)" % (args.size, args.size, args.batch), "value": round(value, 4),
                 "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32", "data": "synthetic",
+                "dtype": "f32", "data": "synthetic", "graph": run.stepper.mode == "graph", "two_streams": bool(sde.two_streams),
+                "launches_per_step": launches_per_step,
                 "config": {"workload": "%dx%d 1-ch synthetic, %d-step reverse chain, batch %d per GPU, 2 UNet fwd + reverse update per step"
                                        % (args.size, args.size, args.T, args.batch),
                            "global_batch": args.batch * world, "parallelism": "replicas x%d (no collective)" % world,

@@ -127,8 +127,9 @@ class ContextDecoder(nn.Module):  # :1194-1244
 
 
 def _class_tokens(n_cls, prompt_len, names=ARTIFACT_TYPES):
-    """Deterministic stand-in token ids for the class prompts (no tokenizer/vocab offline): a stable hash of
-    the prompt words, EOT (= max id, as CLIP's argmax convention, _modified_BiomedCLIP.py:868) at the end."""
+    """Placeholder token ids for the class prompts, ONLY meaningful for the stub text encoder (which ignores them): a stable hash
+    of the prompt words, EOT (= max id, as CLIP's argmax convention, _modified_BiomedCLIP.py:868) at the end.  A real encoder
+    needs real ids: ScoreMapModule(tokenizer=...) / set_class_tokens(), or the `tokens` buffer of a loaded checkpoint."""
     tok = torch.zeros(n_cls, prompt_len, dtype=torch.long)
     for i in range(n_cls):
         words = (names[i] if i < len(names) else f"class {i}").split()
@@ -147,19 +148,49 @@ class ScoreMapModule(nn.Module):
     feature (ContextDecoder) added back to the text emb; text (x) feature -> score map [B,K,h,w]."""
 
     def __init__(self, visual_dim=64, CLIP_Type="CLIP", token_embed_dim=512, text_dim=512, n_ctx=8, n_cls=5, prompt_len=10,
-                 decoder_layers=3, decoder_width=256, decoder_heads=4):
+                 decoder_layers=3, decoder_width=256, decoder_heads=4, tokenizer=None, class_names=ARTIFACT_TYPES):
         super().__init__()
         self.visual_dim, self.n_cls, self.text_dim = visual_dim, n_cls, text_dim
         self.contexts = nn.Parameter(torch.zeros(1, n_ctx, token_embed_dim))
         _trunc_normal_(self.contexts, std=0.02)
-        self.register_buffer("tokens", _class_tokens(n_cls, prompt_len))
+        # class-prompt token ids [K, N1] are a (persistent) buffer: a checkpoint carries them.  `tokenizer` is the hook for real
+        # ids -- a callable list[str] -> LongTensor [K, N1] (e.g. clip.tokenize(names, context_length=N1),
+        # drift_noise_model.py:78-83); without one the placeholder ids are flagged so a non-stub encoder refuses them.
+        self._prompt_len, self._ph_check = prompt_len, None
+        self.register_buffer("tokens", _class_tokens(n_cls, prompt_len) if tokenizer is None else
+                             torch.as_tensor(tokenizer(list(class_names)[:n_cls])).long())
         self.text_to_visual = nn.Linear(text_dim, visual_dim)
         self.context_decoder = ContextDecoder(decoder_width, decoder_heads, decoder_layers, visual_dim, text_dim)
         self.gamma = nn.Parameter(torch.ones(visual_dim) * 1e-4)
         self._text_cache = None
 
+    def set_class_tokens(self, tokens):
+        """install real class-prompt token ids [K, N1] (from a tokenizer run elsewhere, or a config file)"""
+        tokens = torch.as_tensor(tokens).long().to(self.tokens.device)
+        assert tokens.dim() == 2 and tokens.shape[0] == self.n_cls, tokens.shape
+        self.tokens = tokens
+        self._text_cache = None
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        tk = state_dict.get(prefix + "tokens")
+        if tk is not None and tk.shape != self.tokens.shape:  # real prompts may be longer than the placeholder ones
+            self.tokens = torch.empty_like(tk, device=self.tokens.device)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    @property
+    def tokens_are_placeholders(self):
+        """True while `tokens` still holds the hash-derived placeholder ids (checked by content, so it survives save/load)"""
+        key = (self.tokens.data_ptr(), self.tokens._version)
+        if self._ph_check is None or self._ph_check[0] != key:
+            ph = _class_tokens(self.n_cls, self._prompt_len)
+            self._ph_check = (key, tuple(self.tokens.shape) == tuple(ph.shape) and bool(torch.equal(self.tokens.detach().cpu(), ph)))
+        return self._ph_check[1]
+
     # ---- text branch (frozen encoder: out of the accelerated scope, cached at inference) ---------
     def text_embeddings(self, text_encoder, B):
+        if self.tokens_are_placeholders and not getattr(text_encoder, "ignores_token_ids", False):
+            raise RuntimeError("ScoreMapModule holds placeholder class-token ids but the text encoder reads token ids: pass "
+                               "tokenizer=... / call set_class_tokens(), or load a checkpoint that carries the `tokens` buffer")
         if not torch.is_grad_enabled() or not self.contexts.requires_grad:
             key = (B, self.contexts.data_ptr(), self.contexts._version, _weight_epoch())
             c = self._text_cache

@@ -232,3 +232,45 @@ def test_gloo_world2_flat_grad_allreduce_and_sharding(tmp_path):
                         "--master-port", "29531", str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists(), r.stdout[-2000:]
+
+
+# ---- text-encoder selection is explicit: nothing falls back to random embeddings silently --------------------
+def test_text_encoder_selection_is_loud(tmp_path):
+    from instancediff_amd.models.text_encoder import StubTextEncoder, build_text_encoder
+    enc, dim = build_text_encoder(None, "stub")
+    assert isinstance(enc, StubTextEncoder) and dim == 512 and not any(p.requires_grad for p in enc.parameters())
+    with pytest.raises(FileNotFoundError, match="refusing"):
+        build_text_encoder("pretrained/ViT-B-32.pt", "CLIP")  # the reference's configured path (config.yml:137), absent here
+    with pytest.raises(ValueError):
+        build_text_encoder(None, "CLIP")
+    present = tmp_path / "ViT-B-32.pt"
+    present.write_bytes(b"not a checkpoint")
+    with pytest.raises(NotImplementedError):
+        build_text_encoder(str(present), "CLIP")
+    opt = pipeline.load_options()
+    assert opt["models"]["DriftNoise"]["CLIP_Type"] == "stub"  # the shipped synthetic configuration asks for the stub by name
+
+
+def test_placeholder_class_tokens_are_refused_by_a_token_reading_encoder():
+    from instancediff_amd.models.modules.MSM_degEmb_Unet import ScoreMapModule
+    smm = ScoreMapModule(visual_dim=64)
+    assert smm.tokens_are_placeholders
+
+    class Reads(torch.nn.Module):
+        def forward(self, text, context):
+            return torch.zeros(context.shape[0], text.shape[0], 512)
+
+    with pytest.raises(RuntimeError, match="placeholder"):
+        smm.text_embeddings(Reads(), 2)
+    ids = torch.arange(5 * 12).reshape(5, 12)
+    smm.set_class_tokens(ids)
+    assert not smm.tokens_are_placeholders and smm.text_embeddings(Reads(), 2).shape == (2, 5, 512)
+    # real ids travel with the state dict (any prompt length) and placeholders stay flagged across save/load
+    other = ScoreMapModule(visual_dim=64)
+    other.load_state_dict(smm.state_dict())
+    assert torch.equal(other.tokens, ids) and not other.tokens_are_placeholders
+    fresh = ScoreMapModule(visual_dim=64)
+    fresh.load_state_dict(ScoreMapModule(visual_dim=64).state_dict())
+    assert fresh.tokens_are_placeholders
+    tok = ScoreMapModule(visual_dim=64, tokenizer=lambda names: torch.ones(len(names), 9, dtype=torch.long))
+    assert tok.tokens.shape == (5, 9) and not tok.tokens_are_placeholders
