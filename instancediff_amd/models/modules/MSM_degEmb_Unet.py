@@ -191,16 +191,19 @@ class ScoreMapModule(nn.Module):
         if self.tokens_are_placeholders and not getattr(text_encoder, "ignores_token_ids", False):
             raise RuntimeError("ScoreMapModule holds placeholder class-token ids but the text encoder reads token ids: pass "
                                "tokenizer=... / call set_class_tokens(), or load a checkpoint that carries the `tokens` buffer")
+        # The reference calls text_encoder(tokens, contexts.expand(B, ...)) (drift_noise_model.py:252): B identical rows.  The
+        # encoder runs ONCE on the single context set and its [1,K,D] output is broadcast -- B times less frozen-encoder work per
+        # training step, and a sample's text embedding (hence its whole result) cannot depend on the batch it sits in.
         if not torch.is_grad_enabled() or not self.contexts.requires_grad:
             key = (B, self.contexts.data_ptr(), self.contexts._version, _weight_epoch())
             c = self._text_cache
             if c is not None and c[0] == key and c[2]() is text_encoder:
                 return c[1]
             with torch.no_grad():
-                text = text_encoder(self.tokens, self.contexts.expand(B, -1, -1)).float().contiguous()
+                text = text_encoder(self.tokens, self.contexts).float().expand(B, -1, -1).contiguous()
             self._text_cache = (key, text, weakref.ref(text_encoder))
             return text
-        return text_encoder(self.tokens, self.contexts.expand(B, -1, -1)).float().contiguous()
+        return text_encoder(self.tokens, self.contexts).float().expand(B, -1, -1).contiguous()
 
     def forward(self, feat, text_encoder, idx=None):
         """feat [B,C,h,w] -> (score [B,K,h,w], sel [B,1,h,w] or None)."""
