@@ -7,6 +7,8 @@
 // streamed from L2 with unit stride along co, B operand from LDS with unit stride along pixels), then the
 // second LayerNorm runs on the accumulators (per-pixel sums across the 4 waves through LDS).
 // HBM traffic = read C*4 B + write 1 KB per pixel (the unfused chain made 3 extra passes over the 1 KB/pixel map).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -329,6 +331,115 @@ __global__ __launch_bounds__(256) void linear_t_kernel(const float* __restrict__
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// The same contract on the f32 matrix cores, for the aligned shapes the token chains actually use (wT 16-byte aligned rows,
+// N % 4 == 0): the launch above is latency-bound -- each wave walks its K range with one 256-byte weight row in flight per
+// step -- so this one keeps many 16-byte weight loads in flight per lane and lets v_mfma_f32_16x16x4_f32 do the k-group sums.
+//   workgroup = 16 rows x 64 output features, 8 waves split K; per step of 4 k: lane (n = lane & 15, kk = lane >> 4) loads
+//   the float4 wT[k0+kk][n0 + 4n .. +3] (a wave reads 4 whole 256-byte row segments) and the scalar xs[n][k0+kk] from LDS;
+//   MFMA i of 4 multiplies the activations by element i of the float4 -> its column n is output feature n0 + 4n + i.
+//   Partials of the 8 waves meet in LDS; bias / gscale / residual / activation as above.  Rows are independent of each other
+//   (each output element is one fixed-order chain), so a token row's result does not depend on the batch around it.
+// ---------------------------------------------------------------------------------------------------
+constexpr int LM_ROWS = 16, LM_WAVES = 8, LM_KPAD = 4;
+__global__ __launch_bounds__(512) void linear_t_mfma_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ wT, long long ldw,
+                                                            const float* __restrict__ bias, const float* __restrict__ res, long long ldr,
+                                                            const float* __restrict__ gscale, float* __restrict__ out, long long ldo, int R, int K,
+                                                            int N, int act_in, int act_out, long long x_hs, long long w_hs, long long b_hs,
+                                                            long long o_hs, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                            float ln_eps) {
+    x += blockIdx.z * x_hs;
+    wT += blockIdx.z * w_hs;
+    if (bias) bias += blockIdx.z * b_hs;
+    out += blockIdx.z * o_hs;
+    extern __shared__ __attribute__((aligned(16))) float lm_smem[];
+    const int KS = K + LM_KPAD;                         // padded row stride: rows land 4 banks apart
+    float* xs = lm_smem;                                // [16][KS] activated (and normalised) input rows
+    float* red = lm_smem + LM_ROWS * KS;                // [8 waves][4 mfma][64 lanes][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.y * LM_ROWS, n0 = blockIdx.x * 64;
+    for (int i = tid; i < LM_ROWS * K; i += 512) {
+        const int r = i / K, k = i - r * K;
+        const int rr = r0 + r < R ? r0 + r : R - 1;
+        xs[r * KS + k] = act_apply_t(x[(long long)rr * ldx + k], act_in);
+    }
+    __syncthreads();
+    if (ln_g) {  // fused LayerNorm: one 32-lane half-wave per row, two-pass statistics (as linear_t_kernel)
+        const int row = tid >> 5, l = tid & 31;
+        float* xr = xs + row * KS;
+        float sum = 0.f;
+        for (int k = l; k < K; k += 32) sum += xr[k];
+        const float mean = half_sum(sum) / (float)K;
+        float sq = 0.f;
+        for (int k = l; k < K; k += 32) {
+            const float d = xr[k] - mean;
+            sq += d * d;
+        }
+        const float rstd = rsqrtf(half_sum(sq) / (float)K + ln_eps);
+        for (int k = l; k < K; k += 32) xr[k] = (xr[k] - mean) * rstd * ln_g[k] + ln_b[k];
+        __syncthreads();
+    }
+    // this wave's K range, in whole steps of 4
+    const int nsteps = (K + 3) / 4;
+    const int sper = (nsteps + LM_WAVES - 1) / LM_WAVES;
+    const int s0 = wave * sper, s1 = min(nsteps, s0 + sper);
+    const int n = lane & 15, kk = lane >> 4;
+    const int col = n0 + 4 * n;
+    const bool col_ok = col < N;  // N % 4 == 0: a lane's four features are in or out together
+    const float* wp = wT + (col_ok ? col : 0);
+    const float* xp = xs + n * KS + kk;
+    floatx4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    constexpr int UN = 8;  // steps in flight: 8 x 16 B per lane
+    for (int sb = s0; sb < s1; sb += UN) {
+        floatx4 w[UN];
+        float a[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int k = (sb + u) * 4 + kk;
+            const bool ok = sb + u < s1 && k < K;
+            w[u] = (ok && col_ok) ? *reinterpret_cast<const floatx4*>(wp + (long long)k * ldw) : floatx4{0.f, 0.f, 0.f, 0.f};
+            a[u] = ok ? xp[(sb + u) * 4] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], w[u].x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], w[u].y, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], w[u].z, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], w[u].w, acc[3], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) reinterpret_cast<floatx4*>(red)[(wave * 4 + i) * 64 + lane] = acc[i];
+    __syncthreads();
+    // C layout of 16x16x4: lane (n = lane & 15, g = lane >> 4) holds rows 4g .. 4g+3 of column n.  Thread t < 256 finishes
+    // mfma i = t >> 6 of lane t & 63: 4 rows x 1 feature.
+    if (tid < 256) {
+        const int i = tid >> 6, l = tid & 63;
+        floatx4 v = reinterpret_cast<const floatx4*>(red)[i * 64 + l];
+#pragma unroll
+        for (int w8 = 1; w8 < LM_WAVES; ++w8) {
+            const floatx4 p = reinterpret_cast<const floatx4*>(red)[(w8 * 4 + i) * 64 + l];
+            v.x += p.x, v.y += p.y, v.z += p.z, v.w += p.w;
+        }
+        const int feat = n0 + 4 * (l & 15) + i;
+        if (feat < N) {
+            const float gs = gscale ? gscale[feat] : 1.f, bs = bias ? bias[feat] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = r0 + 4 * (l >> 4) + e;
+                if (row < R) {
+                    float y = gs * (v[e] + bs);
+                    if (res) y += res[(long long)row * ldr + feat];
+                    out[(long long)row * ldo + feat] = act_apply_t(y, act_out);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int idiff_smm_memproj_fwd(const float* feat, int64_t feat_bstride, const float* ln1_g, const float* ln1_b, const float* wpk,
@@ -376,6 +487,26 @@ static int linear_t_launch(const float* x, int64_t ldx, const float* wT, int64_t
     IDIFF_CHECK_ARG(x && wT && out && R > 0 && K > 0 && N > 0 && heads > 0, "linear_t_fwd: bad args");
     IDIFF_CHECK_ARG(ldx >= K && ldw >= N && ldo >= N, "linear_t_fwd: bad leading dims");
     IDIFF_CHECK_ARG(K <= 8192, "linear_t_fwd: K must be <= 8192 (got %d)", K);
+    // matrix-core form for aligned weights (every token-chain shape of the ScoreMapModule); the vector-ALU form takes the rest
+    static const bool mfma_off = [] {
+        const char* e = getenv("IDIFF_LINEAR_MFMA");
+        return e && e[0] == '0';
+    }();
+    const size_t lds_m = ((size_t)LM_ROWS * (K + LM_KPAD) + (size_t)LM_WAVES * 4 * 64 * 4) * sizeof(float);
+    if (!mfma_off && N % 4 == 0 && ldw % 4 == 0 && w_hs % 4 == 0 && (reinterpret_cast<uintptr_t>(wT) & 15) == 0 && lds_m <= 160 * 1024) {
+        dim3 gridm((N + 63) / 64, (R + LM_ROWS - 1) / LM_ROWS, heads);
+        static size_t attr_m = 0;
+        if (lds_m > 64 * 1024 && lds_m > attr_m) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_t_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
+            if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "linear_t_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr_m = lds_m;
+        }
+        hipLaunchKernelGGL(linear_t_mfma_kernel, gridm, dim3(512), lds_m, (hipStream_t)stream, x, (long long)ldx, wT, (long long)ldw, bias, res,
+                           (long long)ldr, gscale, out, (long long)ldo, R, K, N, act_in, act_out, (long long)x_hs, (long long)w_hs,
+                           (long long)b_hs, (long long)o_hs, ln_g, ln_b, ln_eps);
+        IDIFF_CHECK_LAUNCH("linear_t_fwd(mfma)");
+        return IDIFF_OK;
+    }
     dim3 grid((N + 63) / 64, (R + LT_ROWS - 1) / LT_ROWS, heads);
     const size_t lds = ((size_t)LT_ROWS * K + 4 * LT_ROWS * 64) * sizeof(float);
     static size_t attr = 0;

@@ -231,8 +231,8 @@ def test_c3_batch32_gradient_is_mean_of_microbatch_gradients():
 
 def test_full_1000_step_chain_vs_oracle():
     """T = 1000 (BASELINE configs 2, 5): the whole schedule -- 1000-row coefficient tables, graph replay across every t, error
-    accumulation over 1000 dependent steps -- at a size the oracle finishes in about a minute."""
-    T, B, H = 1000, 1, 64
+    accumulation over 1000 dependent steps -- at a size the oracle finishes in about a minute (2000 oracle UNet forwards)."""
+    T, B, H = 1000, 1, 32
     model, sde = pipeline.build(phase="test", device=torch.device(DEV), T=T, seed=0)
     model.set_eval()
     batch = make_batch(B, H, seed=1000)

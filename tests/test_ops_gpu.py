@@ -322,6 +322,18 @@ def _pack(w, wino, transpose=False):
     (1, 128, 0, 256, 64, 64, "epilogue"),
     (2, 32, 0, 80, 8, 32, "plain"),         # Cout % 64 = 16: partial last channel block
     (1, 64, 0, 144, 16, 32, "epilogue"),    # partial block with residual / aux / stats
+    # image not a multiple of the 8x32 patch: partial patches at the right / bottom border (the reference's native 224 = 7 x 32 and
+    # its lower levels 112 / 56), masked stores and statistics
+    (2, 32, 0, 64, 28, 56, "plain"),
+    (1, 64, 0, 64, 14, 112, "prologue"),
+    (2, 16, 0, 48, 6, 36, "epilogue"),
+    (1, 16, 0, 32, 7, 28, "upsample"),      # out 14x56
+    (1, 24, 16, 64, 10, 40, "concat"),
+    # several items per workgroup, one and two chunks per item: the software pipeline runs across item boundaries with up to
+    # three items in flight (four table parities)
+    (11, 8, 0, 64, 64, 64, "epilogue"),
+    (10, 16, 0, 128, 64, 64, "prologue"),
+    (9, 40, 0, 64, 64, 96, "plain"),
 ])
 def test_conv_winograd_matches_direct_and_fp64(B, C0, C1, Cout, H, W, variant):
     g = _g(11)
