@@ -354,6 +354,12 @@ int idiff_image_metrics(const float* pred, const float* target, float* out_b3, f
 int idiff_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                     float weight_decay, float grad_scale, int step, idiff_stream_t stream);
 
+/* bf16 wire format of the data-parallel gradient exchange (replaces nothing in the reference, whose DDP buckets are fp32,
+ * models/drift_noise_model.py:145-146; BASELINE config c3 asks for it): round-to-nearest-even pack of the flat fp32 gradient
+ * buffer, and the widening unpack after the all-reduce.  The fp32 buffer stays the master copy Adam reads. */
+int idiff_f32_to_bf16(const float* x, uint16_t* out, int64_t n, idiff_stream_t stream);
+int idiff_bf16_to_f32(const uint16_t* x, float* out, int64_t n, idiff_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

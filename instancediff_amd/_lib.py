@@ -102,6 +102,8 @@ SIGNATURES = {
     "idiff_resize_bilinear": (I, [P, P, I64, I, I, I, I, c_stream]),
     "idiff_mse_loss": (I, [P, P, P, P, P, I64, F, c_stream]),
     "idiff_image_metrics": (I, [P, P, P, P, I, I, I, c_stream]),
+    "idiff_f32_to_bf16": (I, [P, P, I64, c_stream]),
+    "idiff_bf16_to_f32": (I, [P, P, I64, c_stream]),
     "idiff_adam_step": (I, [P, P, P, P, I64, F, F, F, F, F, F, I, c_stream]),
 }
 

@@ -372,3 +372,35 @@ extern "C" int idiff_gather_channel(const float* x, const int32_t* idx, float* o
     IDIFF_CHECK_LAUNCH("gather_channel");
     return IDIFF_OK;
 }
+
+// ---- bf16 wire format of the gradient exchange (fp32 master gradients; BASELINE config c3) ------------------------------
+namespace {
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ out, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const uint32_t u = __builtin_bit_cast(uint32_t, x[i]);
+        uint32_t r;
+        if ((u & 0x7fffffffu) > 0x7f800000u) r = (u >> 16) | 0x40u;      // NaN stays NaN (quiet)
+        else r = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;                 // round to nearest, ties to even
+        out[i] = (uint16_t)r;
+    }
+}
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const uint16_t* __restrict__ x, float* __restrict__ out, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = __builtin_bit_cast(float, (uint32_t)x[i] << 16);
+}
+}  // namespace
+
+extern "C" int idiff_f32_to_bf16(const float* x, uint16_t* out, int64_t n, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(x && out && n > 0, "f32_to_bf16: bad args");
+    const long long g = (n + 255) / 256;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, (hipStream_t)stream, x, out, (long long)n);
+    IDIFF_CHECK_LAUNCH("f32_to_bf16");
+    return IDIFF_OK;
+}
+extern "C" int idiff_bf16_to_f32(const uint16_t* x, float* out, int64_t n, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(x && out && n > 0, "bf16_to_f32: bad args");
+    const long long g = (n + 255) / 256;
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, (hipStream_t)stream, x, out, (long long)n);
+    IDIFF_CHECK_LAUNCH("bf16_to_f32");
+    return IDIFF_OK;
+}

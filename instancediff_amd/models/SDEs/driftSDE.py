@@ -247,4 +247,6 @@ class driftSDE:
             x_T = ops.axpby(cond, self._randn_like(cond), 1.0, self.max_sigma)
         x = x_T.contiguous().clone()
         stepper = driftSDE.Stepper(self, x, cond, names, text_encoder, image_context, noises=noises, t_stop=T_stop)
-        return stepper.run(self.T - T_stop)
+        out = stepper.run(self.T - T_stop)
+        self.last_mode = stepper.mode  # 'graph' | 'eager': how the loop of this call ran
+        return out

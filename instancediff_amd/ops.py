@@ -496,3 +496,24 @@ def mix3_per_sample(x0, cond, eps, c0, c1, c2):
     check(lib.idiff_mix3_per_sample(_p(x0), _p(cond), _p(eps), _p(c0), _p(c1), _p(c2), _p(out), B, x0.numel() // B, _stream()),
           "mix3_per_sample")
     return out
+
+
+def f32_to_bf16(x, out=None):
+    """flat fp32 -> bf16 (round to nearest even), the wire format of the gradient all-reduce"""
+    lib = _lib.load()
+    _c(x, "x")
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    _c(out, "out", torch.bfloat16)
+    check(lib.idiff_f32_to_bf16(_p(x), C.c_void_p(out.data_ptr()), x.numel(), _stream()), "f32_to_bf16")
+    return out
+
+
+def bf16_to_f32(x, out=None):
+    lib = _lib.load()
+    _c(x, "x", torch.bfloat16)
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    _c(out, "out")
+    check(lib.idiff_bf16_to_f32(C.c_void_p(x.data_ptr()), _p(out), x.numel(), _stream()), "bf16_to_f32")
+    return out

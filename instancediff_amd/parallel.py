@@ -42,28 +42,70 @@ def shard_indices(n, rank, world):
 
 
 class GradSync:
-    """Data-parallel exchange for optimizers that already own flat gradient buffers (train_ops.FusedAdam):
-    one all-reduce(SUM) per flat buffer per step; the 1/world average is folded into the fused Adam kernel."""
+    """Data-parallel exchange for optimizers that already own flat gradient buffers (train_ops.FusedAdam): one all-reduce(SUM)
+    per flat buffer per step over RCCL; the 1/world average is folded into the fused Adam kernel.
 
-    def __init__(self, group=None):
+      * overlap: `start(flats)` enqueues the all-reduces asynchronously (RCCL runs them on its own stream, ordered after the
+        work already on the current stream) and returns; `finish()` makes the current stream wait for them.  The train step
+        starts the drift net's exchange right after its backward, so it travels over xGMI while the noise net's backward
+        computes (the reference gets the same effect from DDP's bucket hooks, models/drift_noise_model.py:145-146).
+      * wire="bf16": the flat fp32 gradients are packed to bf16 (idiff_f32_to_bf16, round to nearest even), summed in bf16 on
+        the wire -- half the bytes per link -- and widened back into the fp32 master buffer (BASELINE config c3).  Default fp32.
+      * single_rank_collectives: run the collectives at world size 1 too (a test hook: the RCCL path -- communicator, kernels,
+        stream ordering -- is exercised on a one-GPU box).
+    """
+
+    def __init__(self, group=None, wire=None, single_rank_collectives=False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.wire = (wire or os.environ.get("IDIFF_GRAD_WIRE", "fp32")).lower()
+        if self.wire not in ("fp32", "bf16"):
+            raise ValueError(f"gradient wire format must be fp32 or bf16, got {self.wire!r}")
+        self.active = dist.is_initialized() and (self.world > 1 or single_rank_collectives)
+        self._pending = []
+        self._wirebufs = {}
 
     @torch.no_grad()
     def broadcast_parameters(self, params, src=0):
-        if self.world <= 1:
+        if not self.active:
             return
         for p in params:
             dist.broadcast(p.data, src=src, group=self.group)
 
     @torch.no_grad()
+    def start(self, flats):
+        """enqueue all-reduce(SUM) of every flat gradient buffer; returns immediately"""
+        if not self.active:
+            return
+        for f in flats:
+            if self.wire == "bf16" and f.is_cuda:
+                from . import ops
+                wb = self._wirebufs.get(f.data_ptr())
+                if wb is None or wb.numel() != f.numel():
+                    wb = self._wirebufs[f.data_ptr()] = torch.empty(f.numel(), device=f.device, dtype=torch.bfloat16)
+                ops.f32_to_bf16(f, out=wb)
+                self._pending.append((dist.all_reduce(wb, op=dist.ReduceOp.SUM, group=self.group, async_op=True), f, wb))
+            else:
+                self._pending.append((dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group, async_op=True), f, None))
+
+    @torch.no_grad()
+    def finish(self):
+        """wait for every started exchange; returns the scale (1/world) still to be applied by the optimizer"""
+        if not self.active:
+            return 1.0
+        for work, f, wb in self._pending:
+            work.wait()  # stream-ordered for RCCL (the current stream waits), blocking for gloo
+            if wb is not None:
+                from . import ops
+                ops.bf16_to_f32(wb, out=f)
+        self._pending = []
+        return 1.0 / self.world
+
+    @torch.no_grad()
     def all_reduce_flat(self, flats):
         """SUM every flat gradient buffer over the ranks; returns the scale (1/world) still to be applied."""
-        if self.world <= 1:
-            return 1.0
-        for f in flats:
-            dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group)
-        return 1.0 / self.world
+        self.start(flats)
+        return self.finish()
 
 
 class FlatGradAllReduce:

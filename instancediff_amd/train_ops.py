@@ -569,7 +569,9 @@ def forward_backward_inputRes(model):
        pred_drift, dsm = drift_net(x_t - LQ, LQ, t, ...) ; pred_noise, nsm = noise_net(x_t - LQ, x_t, t, ...)
        loss = MSE(pred_drift, LQ-GT) + MSE(pred_noise, std_noise) + pyramid(dsm, LQ-GT) + pyramid(nsm, std_noise)
     Losses and their gradients come from the HIP loss kernel; autograd is entered with explicit output gradients.  Leaves the
-    parameter gradients in the optimizers' flat buffers; returns (loss record [10] on the device, forward time, use_dsm, use_nsm)."""
+    parameter gradients in the optimizers' flat buffers -- with the data-parallel exchange of each buffer already STARTED when
+    the model has a grad_sync (finish() it before reading them); returns (loss record [10] on the device, forward time, use_dsm,
+    use_nsm)."""
     import time
     st = time.time()
     m = model
@@ -585,16 +587,25 @@ def forward_backward_inputRes(model):
     pred_n, nsm = outn if isinstance(outn, tuple) else (outn, [])
     iter_time = time.time() - st  # the reference times the forward only (:246,290)
     rec = torch.zeros(10, device=m.device, dtype=torch.float32)  # dl, nl, dsm x4, nsm x4
-    outs, grads = [pred_d, pred_n], [mse_loss_and_grad(pred_d, tgt_d, rec[0:1]), mse_loss_and_grad(pred_n, m.std_noise, rec[1:2])]
+    outs_d, grads_d = [pred_d], [mse_loss_and_grad(pred_d, tgt_d, rec[0:1])]
+    outs_n, grads_n = [pred_n], [mse_loss_and_grad(pred_n, m.std_noise, rec[1:2])]
     if use_dsm:
-        outs += list(dsm)
-        grads += score_map_losses(dsm, tgt_d, rec, 2)
+        outs_d += list(dsm)
+        grads_d += score_map_losses(dsm, tgt_d, rec, 2)
     if use_nsm:
-        outs += list(nsm)
-        grads += score_map_losses(nsm, m.std_noise, rec, 6)
+        outs_n += list(nsm)
+        grads_n += score_map_losses(nsm, m.std_noise, rec, 6)
     m.noise_optimizer.zero_grad()
     m.drift_optimizer.zero_grad()
-    torch.autograd.backward(outs, grads)
+    # The two nets share no parameters, so their backward passes are two independent graph walks: drift first, and its flat
+    # gradient buffer starts its all-reduce (RCCL's own stream) while the noise net's backward still computes.
+    sync = m.grad_sync
+    torch.autograd.backward(outs_d, grads_d)
+    if sync is not None:
+        sync.start(m.drift_optimizer.flat_grads())
+    torch.autograd.backward(outs_n, grads_n)
+    if sync is not None:
+        sync.start(m.noise_optimizer.flat_grads())
     return rec, iter_time, use_dsm, use_nsm
 
 
@@ -603,9 +614,7 @@ def train_step_inputRes(model):
     two Adam steps, loss bookkeeping with ONE device->host copy."""
     m = model
     rec, iter_time, use_dsm, use_nsm = forward_backward_inputRes(m)
-    scale = 1.0
-    if m.grad_sync is not None:
-        scale = m.grad_sync.all_reduce_flat(m.drift_optimizer.flat_grads() + m.noise_optimizer.flat_grads())
+    scale = m.grad_sync.finish() if m.grad_sync is not None else 1.0  # the exchanges were started during the backward
     m.noise_optimizer.grad_scale = m.drift_optimizer.grad_scale = scale
     m.noise_optimizer.step()
     m.drift_optimizer.step()

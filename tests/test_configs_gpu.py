@@ -9,7 +9,7 @@ size-independent properties at the full batch:
            (self-attention over N = 4096 tokens, ScoreMapModule cross-attention over N = 262 144 keys) against fp64 references.
   c3       training: one step at 256x256 B=2 against the oracle's torch autograd; at B=32 the gradient must equal the mean of the 16
            micro-batch gradients (linearity of the backward in the batch).
-  T=1000   a full 1000-step chain (T=1000 coefficient tables, error accumulation over the whole schedule) at 64x64 B=1.
+  T=1000   a full 1000-step chain (T=1000 coefficient tables, error accumulation over the whole schedule) at 32x32 B=1.
 
 fp32 throughout; tolerance: |dPSNR| < 1e-3 dB (north_star) and max|diff| < 5e-4 against the oracle, equality for the properties.
 """
