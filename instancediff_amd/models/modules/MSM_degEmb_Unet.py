@@ -209,10 +209,8 @@ class ScoreMapModule(nn.Module):
         """feat [B,C,h,w] -> (score [B,K,h,w], sel [B,1,h,w] or None)."""
         B, C, H, W = feat.shape
         text = self.text_embeddings(text_encoder, B)  # [B,K,text_dim]
-        x, t2v = self._decoder_tokens(feat, text)
-        op = self.context_decoder.out_proj
-        # tv = text_to_visual(text) + gamma * out_proj(LN(x)): residual, per-column gain and LayerNorm fused into the last linear
-        tv = ops.linear_t(x, wT(op[1]), op[1].bias, res=t2v, gscale=self.gamma, ln=(op[0].weight, op[0].bias, op[0].eps))
+        # tv = text_to_visual(text) + gamma * out_proj(LN(x))
+        tv = self._decoder_tokens(feat, text)
         return ops.scoremap(feat, tv.reshape(B, self.n_cls, C), idx)
 
     def context_decode(self, feat, text):
@@ -220,12 +218,14 @@ class ScoreMapModule(nn.Module):
         `feat` [B,C,h,w]: -> [B,K,C].  The same launches as forward() up to the last linear, which here is the plain out_proj
         (no text_to_visual residual, no gamma); used to pin this path to outputs of the real reference class."""
         B, C = feat.shape[:2]
-        x, _ = self._decoder_tokens(feat, text.contiguous(), cache_prefix=False)  # a caller-owned text tensor is not a stable cache key
-        op = self.context_decoder.out_proj
-        return ops.linear_t(x, wT(op[1]), op[1].bias, ln=(op[0].weight, op[0].bias, op[0].eps)).reshape(B, text.shape[1], C)
+        out = self._decoder_tokens(feat, text.contiguous(), cache_prefix=False, plain_out=True)  # caller-owned text: not a stable cache key
+        return out.reshape(B, text.shape[1], C)
 
-    def _decoder_tokens(self, feat, text, cache_prefix=True):
-        """decoder state x [B*K, Wd] after the last TransformerDecoderLayer (before out_proj) and text_to_visual(text) [B*K, C]"""
+    def _decoder_tokens(self, feat, text, cache_prefix=True, plain_out=False):
+        """tv [B*K, C] = text_to_visual(text) + gamma * out_proj(LN(x_L)) with x_L the decoder state after the last
+        TransformerDecoderLayer (plain_out: out_proj(LN(x_L)) alone).  Launches: the fused memory projection, then per layer one
+        cross-attention over the feature map (idiff_smm_xattn_fwd) and the token-side linears on the matrix cores (idiff_linear_t*:
+        80 workgroups per launch; a one-workgroup-per-sample fusion of the whole chain was measured and is slower)."""
         B, C, H, W = feat.shape
         K = text.shape[1]
         dec = self.context_decoder
@@ -298,7 +298,11 @@ class ScoreMapModule(nn.Module):
             x = ops.linear_t(av, wT(ca.proj), ca.proj.bias, res=x)
             hm = ops.linear_t(x, wT(layer.mlp[0]), layer.mlp[0].bias, act_out=ops.ACT_GELU, ln=(layer.norm3.weight, layer.norm3.bias, layer.norm3.eps))
             x = ops.linear_t(hm, wT(layer.mlp[3]), layer.mlp[3].bias, res=x)
-        return x, t2v
+        op = dec.out_proj
+        if plain_out:
+            return ops.linear_t(x, wT(op[1]), op[1].bias, ln=(op[0].weight, op[0].bias, op[0].eps))
+        # residual, per-column gain and LayerNorm fused into the last linear
+        return ops.linear_t(x, wT(op[1]), op[1].bias, res=t2v, gscale=self.gamma, ln=(op[0].weight, op[0].bias, op[0].eps))
 
 
 def _fold_memory_affine(lin, ln2, ca, Cm):

@@ -517,3 +517,4 @@ def bf16_to_f32(x, out=None):
     _c(out, "out")
     check(lib.idiff_bf16_to_f32(C.c_void_p(x.data_ptr()), _p(out), x.numel(), _stream()), "bf16_to_f32")
     return out
+

@@ -176,7 +176,7 @@ def test_c3_train_step_256_vs_oracle_autograd():
     rec, _, _, _ = train_ops.forward_backward_inputRes(model)
     r = rec.cpu()
     loss = float(r[0] + r[1] + r[2:6].sum() / 2 + r[6:10].sum() / 2)
-    assert abs(loss - float(l0)) < 2e-5 * abs(float(l0)), (loss, float(l0))
+    assert abs(loss - float(l0.detach())) < 2e-5 * abs(float(l0.detach())), (loss, float(l0.detach()))
     worst = 0.0
     for net, ref, tag in ((model.drift_net, rd, "d"), (model.noise_net, rn, "n")):
         refg = dict(ref.named_parameters())
@@ -189,7 +189,7 @@ def test_c3_train_step_256_vs_oracle_autograd():
             e = float((p.grad.cpu() - rg).abs().max()) / scale
             worst = max(worst, e)
             assert e < 2e-3, (tag, k, e)
-    print(f"c3 256x256 B=2: loss {loss:.6f} (oracle {float(l0):.6f}), worst relative parameter-gradient error {worst:.2e}")
+    print(f"c3 256x256 B=2: loss {loss:.6f} (oracle {float(l0.detach()):.6f}), worst relative parameter-gradient error {worst:.2e}")
 
 
 def test_c3_batch32_gradient_is_mean_of_microbatch_gradients():
@@ -242,3 +242,30 @@ def test_full_1000_step_chain_vs_oracle():
     out = _chain(model, batch, x_T, noises)
     ref = _oracle_chain(model, T, batch, x_T, noises)
     _check_vs_oracle(out, ref, batch['target'], "1000-step chain 64x64")
+
+
+def test_native_224_chain_vs_oracle_on_the_winograd_path():
+    """The reference's native resolution (data/MedSpeckle.py:44-45, drift_noise_model.py:234): 224 = 7 x 32, lower levels 112 / 56 /
+    28 are not multiples of the 8x32 patch.  The three upper levels run on the Winograd kernel with masked partial patches
+    (28x28 is narrower than a patch and stays on the direct kernel); chain parity against the oracle, B=2 batch invariance."""
+    T, H = 2, 224
+    model, sde = pipeline.build(phase="test", device=torch.device(DEV), T=T, seed=0)
+    model.set_eval()
+    b2 = make_batch(2, H, seed=224)
+    g = torch.Generator().manual_seed(225)
+    x_T = b2['input'] + 0.4 * torch.randn(b2['input'].shape, generator=g)
+    noises = torch.randn((T,) + tuple(b2['input'].shape), generator=g)
+    # which kernel serves a ResBlock conv at each level
+    lib = ops._lib.load()
+    algos = {}
+    for size, C in ((224, 64), (112, 64), (56, 128), (28, 256)):
+        x = torch.randn(1, C, size, size, device=DEV)
+        w = ops.pack_conv_weight(torch.randn(C, C, 3, 3, device=DEV) * 0.02)
+        ops.conv2d(x, w, None, 3, C, want_stats=True)
+        algos[size] = lib.idiff_conv2d_last_algo()
+    assert algos == {224: 1, 112: 1, 56: 1, 28: 0}, algos
+    out2 = _chain(model, b2, x_T, noises)
+    out1 = _chain(model, {k: v[1:] for k, v in b2.items()}, x_T[1:], noises[:, 1:].contiguous())
+    assert torch.equal(out2[1:], out1)
+    ref = _oracle_chain(model, T, b2, x_T, noises)
+    _check_vs_oracle(out2, ref, b2['target'], "224x224 (native)")
