@@ -236,10 +236,19 @@ class CLIPDriftModel():
         torch.save(state, os.path.join(save_dir, "{}.state".format(iter_step)))
 
     def resume_training(self, resume_state):
+        """Both `.state` layouts resume: this build's (state dicts) and the reference's, which pickles the scheduler and optimizer
+        OBJECTS (models/drift_noise_model.py:694-704; its own resume_training then swaps them in wholesale, :702-704 -- optimizers
+        that update orphaned copies of the weights).  From reference objects the Adam moments, step counts, hyper-parameters and
+        the schedulers' epochs are taken over into the live fused optimizers."""
         for sch, s in zip((self.drift_lr_scheduler, self.noise_lr_scheduler), resume_state['schedulers']):
+            if hasattr(s, "state_dict"):  # a pickled scheduler object
+                s = {k: v for k, v in s.state_dict().items() if k != "optimizer"}
             sch.load_state_dict(s)
         for opt, s in zip((self.drift_optimizer, self.noise_optimizer), resume_state['optimizers']):
-            opt.load_state_dict(s)
+            if hasattr(s, "state_dict") or "flat" not in s:  # a torch.optim.Adam object or its state dict
+                opt.load_torch_adam(s)
+            else:
+                opt.load_state_dict(s)
 
     @staticmethod
     def load_network(load_path, network, strict=True):

@@ -539,6 +539,38 @@ class FusedAdam(torch.optim.Optimizer):
         sd['flat'] = [None if f is None else dict(m=f['m'].cpu(), v=f['v'].cpu(), step=f['step']) for f in self._flat]
         return sd
 
+    def load_torch_adam(self, opt_or_state):
+        """Adopt the moments / step count / hyper-parameters of a `torch.optim.Adam` (the object itself, as the reference pickles it
+        into `{iter}.state`, models/drift_noise_model.py:694-704, or its state_dict()).  Parameters are matched by position: the
+        reference builds its optimizers from `net.parameters()` in the same registration order as these nets."""
+        sd = opt_or_state.state_dict() if hasattr(opt_or_state, "state_dict") else opt_or_state
+        groups, state = sd["param_groups"], sd["state"]
+        if len(groups) != len(self.param_groups):
+            raise ValueError(f"optimizer has {len(groups)} parameter groups, expected {len(self.param_groups)}")
+        for g, mine, f in zip(groups, self.param_groups, self._flat):
+            for k in ("lr", "betas", "eps", "weight_decay"):
+                if k in g:
+                    mine[k] = tuple(g[k]) if k == "betas" else g[k]
+            if f is None:
+                continue
+            ids = list(g["params"])
+            if len(ids) != len(f["params"]):
+                raise ValueError(f"optimizer group holds {len(ids)} parameters, the model {len(f['params'])}")
+            o, steps = 0, set()
+            for pid, p in zip(ids, f["params"]):
+                n = p.numel()
+                st = state.get(pid)
+                if st is not None:  # parameters the reference never stepped have no state yet
+                    if st["exp_avg"].numel() != n:
+                        raise ValueError(f"moment of parameter {pid} has {st['exp_avg'].numel()} elements, the model's has {n}")
+                    f["m"][o:o + n].copy_(st["exp_avg"].reshape(-1).to(torch.float32))
+                    f["v"][o:o + n].copy_(st["exp_avg_sq"].reshape(-1).to(torch.float32))
+                    steps.add(int(st["step"]))
+                o += n
+            if len(steps) > 1:
+                raise ValueError(f"parameters carry different step counts {sorted(steps)}: one fused step count cannot represent them")
+            f["step"] = steps.pop() if steps else 0
+
     def load_state_dict(self, sd):
         flat = sd.pop('flat', None)
         super().load_state_dict(sd)

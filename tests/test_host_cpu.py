@@ -274,3 +274,38 @@ def test_placeholder_class_tokens_are_refused_by_a_token_reading_encoder():
     assert fresh.tokens_are_placeholders
     tok = ScoreMapModule(visual_dim=64, tokenizer=lambda names: torch.ones(len(names), 9, dtype=torch.long))
     assert tok.tokens.shape == (5, 9) and not tok.tokens_are_placeholders
+
+
+def test_reference_era_state_file_resumes(tmp_path):
+    """`{iter}.state` as the reference writes it -- pickled torch.optim.Adam and CosineAnnealingLR OBJECTS
+    (models/drift_noise_model.py:694-704) -- is taken over into the fused optimizers: moments, step count, lr schedule."""
+    from instancediff_amd.train_ops import FusedAdam
+    torch.manual_seed(0)
+    net_ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
+    net_new = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
+    net_new.load_state_dict(net_ref.state_dict())
+    adam = torch.optim.Adam(net_ref.parameters(), lr=2e-5, betas=(0.9, 0.99), weight_decay=1e-4)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(adam, T_max=50, eta_min=1e-6)
+    for _ in range(3):
+        adam.zero_grad()
+        net_ref(torch.randn(4, 6)).square().mean().backward()
+        adam.step()
+        sched.step()
+    path = tmp_path / "3.state"
+    torch.save({"epoch": 1, "iter": 3, "schedulers": [sched], "optimizers": [adam]}, path)
+    state = torch.load(path, map_location="cpu", weights_only=False)
+    fused = FusedAdam(net_new.parameters(), lr=1.0, betas=(0.5, 0.5), weight_decay=0.0)
+    fsched = torch.optim.lr_scheduler.CosineAnnealingLR(fused, T_max=50, eta_min=1e-6)
+    fused.load_torch_adam(state["optimizers"][0])
+    fsched.load_state_dict({k: v for k, v in state["schedulers"][0].state_dict().items() if k != "optimizer"})
+    f = fused._flat[0]
+    assert f["step"] == 3 and fused.param_groups[0]["betas"] == (0.9, 0.99) and fused.param_groups[0]["weight_decay"] == 1e-4
+    want_m = torch.cat([adam.state[p]["exp_avg"].reshape(-1) for p in net_ref.parameters()])
+    want_v = torch.cat([adam.state[p]["exp_avg_sq"].reshape(-1) for p in net_ref.parameters()])
+    assert torch.equal(f["m"], want_m) and torch.equal(f["v"], want_v)
+    assert fsched.last_epoch == 3 and abs(fused.param_groups[0]["lr"] - adam.param_groups[0]["lr"]) < 1e-12
+    # this build's own format still round-trips
+    sd = fused.state_dict()
+    again = FusedAdam(torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3)).parameters(), lr=2e-5)
+    again.load_state_dict(sd)
+    assert again._flat[0]["step"] == 3 and torch.equal(again._flat[0]["m"], want_m)
