@@ -27,15 +27,109 @@ class StubTextEncoder(nn.Module):
         return self.table[None] + (context.mean(dim=1) @ self.ctx_proj)[:, None]
 
 
+class _Block(nn.Module):
+    """One pre-LN transformer block with the parameter names of CLIP's ResidualAttentionBlock (so CLIP checkpoints load):
+    x += out_proj(softmax(q k^T / sqrt(dh) + mask) v) over LN1(x);  x += c_proj(QuickGELU(c_fc(LN2(x))))
+    (_modified_BiomedCLIP.py:371-408; QuickGELU = x * sigmoid(1.702 x), :323-325)."""
+
+    def __init__(self, width, heads):
+        super().__init__()
+        self.heads = heads
+        self.attn = nn.MultiheadAttention(width, heads)  # parameter container: in_proj_weight / in_proj_bias / out_proj
+        self.ln_1 = nn.LayerNorm(width)
+        self.mlp = nn.Sequential()
+        self.mlp.add_module("c_fc", nn.Linear(width, width * 4))
+        self.mlp.add_module("gelu", nn.Identity())
+        self.mlp.add_module("c_proj", nn.Linear(width * 4, width))
+        self.ln_2 = nn.LayerNorm(width)
+
+    def forward(self, x, mask):  # x [S, L, W] (sequence-major here; the reference runs [L, S, W])
+        S, L, W = x.shape
+        dh = W // self.heads
+        h = self.ln_1(x)
+        qkv = h @ self.attn.in_proj_weight.t() + self.attn.in_proj_bias
+        q, k, v = [t.reshape(S, L, self.heads, dh).transpose(1, 2) for t in qkv.chunk(3, dim=-1)]  # [S, heads, L, dh]
+        att = (q * dh ** -0.5) @ k.transpose(-1, -2) + mask  # nn.MultiheadAttention scales q before the product
+        a = (att.softmax(dim=-1) @ v).transpose(1, 2).reshape(S, L, W)
+        x = x + a @ self.attn.out_proj.weight.t() + self.attn.out_proj.bias
+        m = self.mlp.c_fc(self.ln_2(x))
+        return x + self.mlp.c_proj(m * torch.sigmoid(1.702 * m))
+
+
+class _Transformer(nn.Module):
+    def __init__(self, width, layers, heads):
+        super().__init__()
+        self.resblocks = nn.Sequential(*[_Block(width, heads) for _ in range(layers)])
+
+
+class CLIPTextContextEncoder(nn.Module):
+    """The frozen context text encoder of the reference (models/_modified_BiomedCLIP.py:798-883; built at
+    models/drift_noise_model.py:79-86 with context_length 42, width 512, 8 heads, 12 layers, embed 512):
+    `forward(text [K, N1] token ids, context [B, N2, C]) -> [B, K, embed_dim]` -- the learnable context tokens are spliced in after
+    the first (start-of-text) token of every class prompt (:869-873), positions added, a causal transformer run, and the feature at
+    each prompt's end-of-text position (argmax token id, shifted by N2; :866) projected.  N1 + N2 must equal context_length.
+    Parameter names match CLIP's state dict, so `init_weights` loads the text tower of an OpenAI CLIP archive
+    (torch.jit.load(...).state_dict(), :829-846).  Frozen, forward-argument of the nets: host-side torch module,
+    evaluated once per context set at inference (ScoreMapModule caches it)."""
+    ignores_token_ids = False
+
+    def __init__(self, context_length=22, vocab_size=49408, transformer_width=512, transformer_heads=8, transformer_layers=12, embed_dim=1024,
+                 out_dim=256, pretrained=None, **kwargs):
+        super().__init__()
+        self.pretrained, self.context_length, self.embed_dim, self.vocab_size = pretrained, context_length, embed_dim, vocab_size
+        self.transformer = _Transformer(transformer_width, transformer_layers, transformer_heads)
+        self.token_embedding = nn.Embedding(vocab_size, transformer_width)
+        self.positional_embedding = nn.Parameter(torch.empty(context_length, transformer_width))
+        self.ln_final = nn.LayerNorm(transformer_width)
+        self.text_projection = nn.Parameter(torch.empty(transformer_width, embed_dim))
+        nn.init.normal_(self.positional_embedding, std=0.01)
+        nn.init.normal_(self.text_projection, std=transformer_width ** -0.5)
+        mask = torch.full((context_length, context_length), float("-inf")).triu_(1)  # causal: -inf above the diagonal (:848-854)
+        self.register_buffer("attn_mask", mask, persistent=False)
+
+    def init_weights(self, pretrained=None):
+        pretrained = pretrained or self.pretrained
+        if not isinstance(pretrained, str):
+            return
+        ck = torch.jit.load(pretrained, map_location="cpu").float().state_dict()
+        sd = {}
+        for k, v in ck.items():
+            if k.startswith("transformer.") or k.startswith("token_embedding") or k.startswith("ln_final") or k in ("positional_embedding", "text_projection"):
+                if k == "positional_embedding" and v.size(0) > self.context_length:
+                    v = v[:self.context_length]  # 77 -> context_length, as the reference truncates (:839-841)
+                sd[k] = v
+        missing, unexpected = self.load_state_dict(sd, strict=False)
+        if missing or unexpected:
+            print(missing, unexpected, "are misaligned params in text encoder")
+
+    def forward(self, text, context):
+        x_text = self.token_embedding(text)  # [K, N1, C]
+        K, N1, C = x_text.shape
+        B, N2, _ = context.shape
+        if N1 + N2 != self.context_length:
+            raise ValueError(f"prompt length {N1} + context length {N2} must equal context_length {self.context_length}")
+        eos = (text.argmax(dim=-1) + N2).reshape(1, K).expand(B, K).reshape(-1)
+        x_text = x_text.reshape(1, K, N1, C).expand(B, K, N1, C)
+        ctx = context.reshape(B, 1, N2, C).expand(B, K, N2, C)
+        x = torch.cat([x_text[:, :, 0:1], ctx, x_text[:, :, 1:]], dim=2).reshape(B * K, N1 + N2, C)
+        x = x + self.positional_embedding
+        for blk in self.transformer.resblocks:
+            x = blk(x, self.attn_mask)
+        x = self.ln_final(x)
+        x = x[torch.arange(x.shape[0], device=x.device), eos] @ self.text_projection
+        return x.reshape(B, K, self.embed_dim)
+
+
 def build_text_encoder(pretrain_path=None, CLIP_Type="CLIP"):
     """Returns (frozen encoder, token_embed_dim) for `CLIP_Type` (models/drift_noise_model.py:70-90).
 
     Nothing here substitutes weights silently:
       * CLIP_Type == "stub" (the synthetic configuration this repo ships: no pretrained file exists offline) -> the seeded
         `StubTextEncoder`, explicitly requested;
-      * any other CLIP_Type needs its pretrained file: a configured path that does not exist raises FileNotFoundError (the
-        reference would crash in torch.jit.load, _modified_BiomedCLIP.py:831), and a path that exists raises
-        NotImplementedError until the CLIP loader lands -- pass an encoder instance via CLIPDriftModel(text_encoder=...)."""
+      * CLIP_Type "CLIP" builds `CLIPTextContextEncoder` and loads the text tower of the configured OpenAI CLIP archive;
+        a configured path that does not exist raises FileNotFoundError (the reference would crash in torch.jit.load,
+        _modified_BiomedCLIP.py:831).  "BiomedCLIP" (HF PubMedBERT) is not implemented: pass an instance via
+        CLIPDriftModel(text_encoder=...)."""
     if str(CLIP_Type).lower() == "stub":
         enc = StubTextEncoder()
         for p in enc.parameters():
@@ -48,6 +142,13 @@ def build_text_encoder(pretrain_path=None, CLIP_Type="CLIP"):
     if not os.path.exists(str(pretrain_path)):
         raise FileNotFoundError(f"text_encoder_pretrain_path={pretrain_path!r} does not exist: refusing to run CLIP_Type={CLIP_Type!r} "
                                 "with random text embeddings (set CLIP_Type: stub to ask for the seeded stand-in explicitly)")
-    raise NotImplementedError(
-        "loading pretrained CLIP/BiomedCLIP text encoders is not implemented yet (SURVEY.md 8f.1); pass an encoder instance via "
-        "CLIPDriftModel(text_encoder=...)")
+    if str(CLIP_Type) == "BiomedCLIP":
+        raise NotImplementedError("the BiomedCLIP (HF PubMedBERT) context encoder (_modified_BiomedCLIP.py:885-1015) is not implemented; "
+                                  "pass an encoder instance via CLIPDriftModel(text_encoder=...)")
+    enc = CLIPTextContextEncoder(context_length=42, embed_dim=512, transformer_width=512, transformer_heads=8, transformer_layers=12,
+                                 pretrained=str(pretrain_path))  # models/drift_noise_model.py:79-86
+    enc.init_weights()
+    for p in enc.parameters():
+        p.requires_grad_(False)
+    enc.eval()
+    return enc, 512

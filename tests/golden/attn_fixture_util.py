@@ -25,3 +25,10 @@ def seeded_state(module, seed, scale=0.08):
         else:
             sd[k] = scale * torch.randn(v.shape, generator=g)
     return sd
+
+# tag -> (CLIPTextContextEncoder kwargs, context tokens N2, class prompts K, batch, weight seed)   _modified_BiomedCLIP.py:798-883
+TEXT_CASES = {
+    "text_small": (dict(context_length=14, vocab_size=300, transformer_width=64, transformer_heads=4, transformer_layers=2, embed_dim=48), 4, 5, 2, 901),
+    "text_ref_shape": (dict(context_length=42, vocab_size=49408, transformer_width=512, transformer_heads=8, transformer_layers=12, embed_dim=512),
+                       8, 5, 1, 902),  # models/drift_noise_model.py:79-86
+}
