@@ -539,7 +539,9 @@ int dispatch_mb(const ConvArgs& a, int twl, int mb, bool vecw, hipStream_t st) {
     return mb == 2 ? dispatch_tw<KS, CK, MODE, 2>(a, twl, vecw, st) : dispatch_tw<KS, CK, MODE, 1>(a, twl, vecw, st);
 }
 
-inline int pick_twl(int Wout) { return Wout >= 32 ? 5 : (Wout >= 16 ? 4 : 3); }
+// pixel tile of the direct kernel = 2^twl columns x 256/2^twl rows.  From 24 columns up it is the 8x32 patch of the Winograd kernel
+// too (so both kernels write the same GroupNorm-partial layout and a 28-wide level -- 224/8 -- can take either).
+inline int pick_twl(int Wout) { return Wout >= 24 ? 5 : (Wout >= 16 ? 4 : 3); }
 
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int taps, int transpose) {
     // transpose == 0: out[tap][ci][co] = w[co][ci][tap]

@@ -565,9 +565,9 @@ namespace idiff_detail {
 bool conv_wino_eligible(const ConvArgs& a, int ks, int mode) {
     if (ks != 3 || !a.wwino || wino_disabled()) return false;
     if (mode != IDIFF_CONV_NORMAL && mode != IDIFF_CONV_UPSAMPLE2) return false;
-    // any even image size at least one patch wide (>= 32: the GroupNorm-partial tiling is then the 8x32 one of
-    // idiff_conv2d_num_tiles for both kernels); partial patches at the right / bottom border are masked
-    if (a.Cout % 16 || a.Cin % CK || a.C0v % CK || (a.Hout & 1) || (a.Wout & 1) || a.Wout < TW) return false;
+    // any even image size from 24 columns up (there the GroupNorm-partial tiling of idiff_conv2d_num_tiles is the 8x32 patch for
+    // both kernels); partial patches at the right / bottom border are masked
+    if (a.Cout % 16 || a.Cin % CK || a.C0v % CK || (a.Hout & 1) || (a.Wout & 1) || a.Wout < 24) return false;
     if ((long long)a.Cin * a.Hin * a.Win * 4 >= (1ll << 31)) return false;  // 32-bit byte offsets inside a sample
     if (mode == IDIFF_CONV_UPSAMPLE2 && (a.pro_a || a.src1)) return false;
     if (a.pro_a && a.src1) return false;

@@ -66,7 +66,8 @@ class CLIPDriftModel():
     def __init__(self, text_encoder_pretrain_path, drift_net_lr, noise_net_lr, weight_decay_drift, beta1, beta2, nepoch, eta_min,
                  dist=False, gpu=True, optimize_type='predict_noise', optimize_target='std', if_train=True, dnet_settings=None,
                  nnet_settings=None, drift_loss='l2', noise_loss='none', if_MultiScoreMap=False, score_map_ch_mult=[1, 1, 2, 4],
-                 score_map_ngf=64, use_image_context=False, use_degra_context=False, CLIP_Type="CLIP", device=None, text_encoder=None):
+                 score_map_ngf=64, use_image_context=False, use_degra_context=False, CLIP_Type="CLIP", device=None, text_encoder=None,
+                 class_tokens=None):
         dnet_settings = dict(dnet_settings)
         nnet_settings = dict(nnet_settings)
         for s in (dnet_settings, nnet_settings):  # :58-61
@@ -100,6 +101,10 @@ class CLIPDriftModel():
 
         self.drift_prompt = prompts(dnet_settings)
         self.noise_prompt = prompts(nnet_settings)
+        if class_tokens is not None:  # real class-prompt token ids [K, N1] (the reference: clip.tokenize(prompts, context_length=N1))
+            for smms in (self.drift_prompt, self.noise_prompt):
+                for m in (smms or []):
+                    m.set_class_tokens(class_tokens)
         self.drift_net = create_net(dnet_settings, CLIP_ScoreMapModule=self.drift_prompt).to(self.device)
         self.noise_net = create_net(nnet_settings, CLIP_ScoreMapModule=self.noise_prompt).to(self.device)
         if self.drift_prompt is not None:

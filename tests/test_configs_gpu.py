@@ -246,8 +246,8 @@ def test_full_1000_step_chain_vs_oracle():
 
 def test_native_224_chain_vs_oracle_on_the_winograd_path():
     """The reference's native resolution (data/MedSpeckle.py:44-45, drift_noise_model.py:234): 224 = 7 x 32, lower levels 112 / 56 /
-    28 are not multiples of the 8x32 patch.  The three upper levels run on the Winograd kernel with masked partial patches
-    (28x28 is narrower than a patch and stays on the direct kernel); chain parity against the oracle, B=2 batch invariance."""
+    28 are not multiples of the 8x32 patch.  All four levels run on the Winograd kernel with masked partial patches (28x28 is one
+    patch column wide); chain parity against the oracle, B=2 batch invariance."""
     T, H = 2, 224
     model, sde = pipeline.build(phase="test", device=torch.device(DEV), T=T, seed=0)
     model.set_eval()
@@ -263,7 +263,7 @@ def test_native_224_chain_vs_oracle_on_the_winograd_path():
         w = ops.pack_conv_weight(torch.randn(C, C, 3, 3, device=DEV) * 0.02)
         ops.conv2d(x, w, None, 3, C, want_stats=True)
         algos[size] = lib.idiff_conv2d_last_algo()
-    assert algos == {224: 1, 112: 1, 56: 1, 28: 0}, algos
+    assert algos == {224: 1, 112: 1, 56: 1, 28: 1}, algos
     out2 = _chain(model, b2, x_T, noises)
     out1 = _chain(model, {k: v[1:] for k, v in b2.items()}, x_T[1:], noises[:, 1:].contiguous())
     assert torch.equal(out2[1:], out1)

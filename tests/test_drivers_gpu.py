@@ -44,3 +44,58 @@ def test_train_then_test_drivers(tmp_path):
             assert all(np.isfinite(x) for x in v[k])
     raws = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp_path / "results") for f in fs if f.endswith(".raw")]
     assert raws and os.path.getsize(raws[0]) == 32 * 96 * 4
+
+
+def test_pipeline_with_the_real_context_text_encoder():
+    """The real `CLIPTextContextEncoder` (random init: no CLIP archive offline) as the nets' text_encoder argument, real-shaped class
+    token ids through the tokenizer hook: a 2-step chain equals the oracle chain driven by the same encoder."""
+    import torch.nn as nn
+    from instancediff_amd import pipeline
+    from instancediff_amd.models.drift_noise_model import create_CLIPDriftModel
+    from instancediff_amd.models.SDEs import create_sde
+    from instancediff_amd.models.text_encoder import CLIPTextContextEncoder
+    from instancediff_amd.utils.synthetic import make_batch
+    from oracle import sde_ref, unet_ref
+    torch.manual_seed(5)
+    enc = CLIPTextContextEncoder(context_length=42, embed_dim=512, transformer_width=512, transformer_heads=8, transformer_layers=2).eval()
+    for p in enc.parameters():
+        p.requires_grad_(False)
+    ids = torch.randint(1, 49000, (5, 34))
+    ids[:, 0] = 49406
+    for k in range(5):
+        ids[k, 5 + 2 * k] = 49407
+        ids[k, 6 + 2 * k:] = 0
+    opt = pipeline.load_options()
+    train_opt = dict(opt['train'])
+    train_opt['dist'] = False
+    mo = opt['models']['DriftNoise']
+    torch.manual_seed(0)
+    model = create_CLIPDriftModel(train_opt, mo, phase="test", device=torch.device("cuda"), text_encoder=enc, class_tokens=ids)
+    T = 2
+    sde_opt = dict(opt['sdes'][train_opt['which_sde']])
+    sde_opt['T'] = T
+    sde = create_sde(model.get_nets(), sde_opt)
+    sde.set_gpu(model.device)
+    model.set_sde(sde)
+    model.set_eval()
+    batch = make_batch(2, 32, seed=9)
+    g = torch.Generator().manual_seed(10)
+    x_T = batch['input'] + 0.4 * torch.randn(batch['input'].shape, generator=g)
+    noises = torch.randn((T,) + tuple(batch['input'].shape), generator=g)
+    model.feed_data(batch)
+    model.test(x_T=x_T.cuda(), noises=noises.cuda())
+    out = torch.from_numpy(model.get_visuals())
+    refs = []
+    for key, net in (('dnet_settings', model.drift_net), ('nnet_settings', model.noise_net)):
+        s = {k: v for k, v in dict(mo[key]).items() if k not in ("module_name", "class_name")}
+        smm = nn.ModuleList([unet_ref.ScoreMapModule(visual_dim=mo['score_map_ngf'] * m, prompt_len=34) for m in mo['score_map_ch_mult']])
+        r = unet_ref.LearnableForwardUNet_MultiScoreMap(CLIP_ScoreMapModule=smm, use_image_context=True, **s).eval()
+        r.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()})
+        refs.append(r)
+    rsde = sde_ref.DriftSDERef(T, refs[0], refs[1], max_sigma=0.4)
+    cpu_enc = CLIPTextContextEncoder(context_length=42, embed_dim=512, transformer_width=512, transformer_heads=8, transformer_layers=2).eval()
+    cpu_enc.load_state_dict({k: v.cpu() for k, v in enc.state_dict().items()})
+    with torch.no_grad():
+        ref = rsde.reverse_ddpm(batch['input'], batch['names'], cpu_enc, x_T, noises, image_context=batch['A_emb'])
+    err = float((out - ref).abs().max())
+    assert torch.isfinite(out).all() and err < 5e-4, err

@@ -329,6 +329,8 @@ def _pack(w, wino, transpose=False):
     (2, 16, 0, 48, 6, 36, "epilogue"),
     (1, 16, 0, 32, 7, 28, "upsample"),      # out 14x56
     (1, 24, 16, 64, 10, 40, "concat"),
+    (2, 32, 0, 64, 28, 28, "epilogue"),     # narrower than a patch (the 224 / 8 level)
+    (1, 16, 0, 32, 12, 24, "plain"),
     # several items per workgroup, one and two chunks per item: the software pipeline runs across item boundaries with up to
     # three items in flight (four table parities)
     (11, 8, 0, 64, 64, 64, "epilogue"),
