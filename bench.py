@@ -48,6 +48,9 @@ def parse():
                     "is estimated to fit --cpu-budget-s, else 4)")
     ap.add_argument("--cpu-budget-s", type=float, default=75.0, help="time budget of the CPU-baseline leg (warm + timed steps)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--attn", choices=["f32", "bf16"], default="f32", help="bf16 = REDUCED-PRECISION VARIANT line (self-attention "
+                    "contractions on the bf16 matrix cores; BASELINE config c5): own metric label, PSNR delta vs the fp32 path stated")
+    ap.add_argument("--grad-wire", choices=["fp32", "bf16"], default="fp32", help="--mode train: wire format of the gradient all-reduce")
     ap.add_argument("--mode", choices=["sample", "train", "irsde"], default="sample",
                     help="sample = headline denoising-steps/s metric (driftSDE: 2 UNet forwards + update per step); train = secondary "
                          "training-iterations/s line; irsde = secondary line for the IRSDE single-network loop (1 UNet forward + reverse_sde_step)")
@@ -202,6 +205,30 @@ def pmc_traffic():
         return {"traffic": None, "traffic_note": repr(e)}
 
 
+def attention_variant_delta(args, dev, steps=8):
+    """|dPSNR| and max|diff| of the bf16-attention variant against the fp32 path: the same `steps`-step chain (same weights,
+    inputs, Philox seed) run once with each, at the benchmark's own size (batch 2)."""
+    from instancediff_amd import ops, pipeline
+    from instancediff_amd.utils.synthetic import make_batch
+    from oracle import sde_ref  # PSNR helper only (the checker's formula, trainUM.py:319-323 semantics)
+    outs = []
+    batch = make_batch(2, args.size, seed=99, mixed=True)
+    for dt in ("f32", "bf16"):
+        ops.ATTN_DTYPE = dt
+        model, sde = pipeline.build(phase="test", device=dev, T=steps, seed=0)
+        model.set_eval()
+        sde.set_seed(7)
+        model.feed_data(batch)
+        sde.set_seed(7)
+        model.test()
+        outs.append(torch.from_numpy(model.get_visuals()).clone())
+    ops.ATTN_DTYPE = "f32"
+    d = abs(sde_ref.psnr(outs[0], batch['target']) - sde_ref.psnr(outs[1], batch['target']))
+    return {"variant": "self-attention contractions on bf16 MFMA (fp32 softmax and accumulation); everything else fp32",
+            "psnr_delta_db_vs_fp32_path": float("%.3g" % d), "max_abs_diff_vs_fp32_path": float("%.3g" % float((outs[0] - outs[1]).abs().max())),
+            "measured_on": "%d-step chain, batch 2, %dx%d, same weights / inputs / noise" % (steps, args.size, args.size)}
+
+
 def log(msg):
     print("[bench %7.1fs] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
 
@@ -247,7 +274,10 @@ def train_bench(args, world, rank, dev):
         el = float(tmax.item())
     if rank == 0:
         value = world * args.steps / el
-        print(json.dumps({"metric": "training iterations/sec (%dx%d bs%d/GPU)" % (args.size, args.size, args.batch), "value": round(value, 4),
+        label = "training iterations/sec (%dx%d bs%d/GPU)" % (args.size, args.size, args.batch)
+        if args.grad_wire == "bf16":
+            label += " -- VARIANT: bf16 gradient wire format (fp32 compute and fp32 master gradients)"
+        print(json.dumps({"metric": label, "value": round(value, 4), "grad_wire": args.grad_wire,
                           "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(el / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "f32", "data": "synthetic", "last_loss": loss,
@@ -344,6 +374,12 @@ def main():
     from instancediff_amd import ops, pipeline
     from instancediff_amd.utils.synthetic import make_batch
 
+    variant = None
+    if args.attn == "bf16" and args.mode == "sample":
+        variant = attention_variant_delta(args, dev)  # measured first, on the fp32 path's own inputs
+        ops.ATTN_DTYPE = "bf16"
+    os.environ["IDIFF_GRAD_WIRE"] = args.grad_wire
+
     if args.mode == "train":
         return train_bench(args, world, rank, dev)
     if args.mode == "irsde":
@@ -430,10 +466,14 @@ def main():
             except Exception as e:  # the baseline is a reported side measurement; never hide the GPU result
                 cpu = {"error": repr(e)}
         value = world * args.steps / el
-        line = {"metric": "denoising steps/sec (%dx%d bs%d)" % (args.size, args.size, args.batch), "value": round(value, 4),
+        label = "denoising steps/sec (%dx%d bs%d)" % (args.size, args.size, args.batch)
+        if variant is not None:
+            label += " -- REDUCED-PRECISION VARIANT: bf16 MFMA self-attention"
+        line = {"metric": label, "value": round(value, 4),
                 "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32", "data": "synthetic", "graph": run.stepper.mode == "graph", "two_streams": bool(sde.two_streams),
+                "dtype": "f32" if variant is None else "f32 + bf16 attention", "data": "synthetic", "graph": run.stepper.mode == "graph",
+                "two_streams": bool(sde.two_streams), "variant": variant,
                 "launches_per_step": launches_per_step,
                 "config": {"workload": "%dx%d 1-ch synthetic, %d-step reverse chain, batch %d per GPU, 2 UNet fwd + reverse update per step"
                                        % (args.size, args.size, args.T, args.batch),

@@ -145,6 +145,140 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// attn_self with the two contractions on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16), fp32 softmax and fp32
+// accumulation: a REDUCED-PRECISION VARIANT (BASELINE config c5 names "fp16 MFMA attention"; the reference's only
+// half-precision code is its optional flash-attention branch, models/_modified_BiomedCLIP.py:396-400,509-513).  Off by
+// default -- the headline path is fp32 end to end; bench.py reports this variant as its own line with its PSNR delta.
+// Same tiling as attn_self_kernel<64>: a wave owns 32 queries, 32-key tiles pass through LDS (K as [key][d] rows, V as
+// [d][key] rows, both bf16), S^T = K Q^T takes 4 MFMAs per tile instead of 32, O^T += V^T P two per 32 channels instead of 16:
+// P is taken from the S accumulator (register r of half-wave g holds key KAPPA(r) + 4g), so the k slots of the second product
+// are enumerated in that key order on the V side as well.
+// ---------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void attn_self_bf16_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int N, int heads,
+                                                             float scale) {
+    constexpr int DH = 64, MB = 2;
+    constexpr int KROW = DH + 8;   // bf16 per K row (key-major), padded: rows land 4 banks apart
+    constexpr int VROW = 32 + 4;   // bf16 per V row (channel-major), padded
+    constexpr int KT = 32 * KROW, VT = DH * VROW, BUF = KT + VT;  // bf16 elements per buffer
+    extern __shared__ __attribute__((aligned(16))) __bf16 bsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y / heads, h = blockIdx.y % heads;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const float* qb = qkv + (long long)b * 3 * C * N + (long long)(h * DH) * N;
+    const float* kb = qb + (long long)C * N;
+    const float* vb = qb + (long long)2 * C * N;
+    const int qi = q0 + l31;
+    bf16x8 qreg[4];  // B operand of S^T = K Q^T: query l31, channels 16 s + 8 half + e
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qreg[s][e] = (__bf16)(qi < N ? qb[(long long)(16 * s + 8 * half + e) * N + qi] : 0.f);
+    floatx16 O[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[m][r] = 0.f;
+    float mrun = -INFINITY, lrun = 0.f;
+    const int nkb = (N + 31) / 32;
+    floatx4 rk[2], rv[2];  // 64 channels x 32 keys = 512 float4 per tile, 2 per thread
+    auto load_tile = [&](int kbi) {
+        const int key0 = kbi * 32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + i * 256;
+            const int d = f >> 3, j4 = (f & 7) * 4;
+            floatx4 kz = {0.f, 0.f, 0.f, 0.f}, vz = {0.f, 0.f, 0.f, 0.f};
+            if (key0 + j4 + 3 < N) {
+                kz = *reinterpret_cast<const floatx4*>(kb + (long long)d * N + key0 + j4);
+                vz = *reinterpret_cast<const floatx4*>(vb + (long long)d * N + key0 + j4);
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (key0 + j4 + e < N) kz[e] = kb[(long long)d * N + key0 + j4 + e], vz[e] = vb[(long long)d * N + key0 + j4 + e];
+            }
+            rk[i] = kz, rv[i] = vz;
+        }
+    };
+    auto write_tile = [&](int buf) {
+        __bf16* kt = bsm + buf * BUF;
+        __bf16* vt = kt + KT;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + i * 256;
+            const int d = f >> 3, j4 = (f & 7) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) kt[(j4 + e) * KROW + d] = (__bf16)rk[i][e];  // transposed: key-major rows
+            *reinterpret_cast<bf16x4*>(vt + d * VROW + j4) = bf16x4{(__bf16)rv[i][0], (__bf16)rv[i][1], (__bf16)rv[i][2], (__bf16)rv[i][3]};
+        }
+    };
+    load_tile(0);
+    write_tile(0);
+    __syncthreads();
+    for (int kbi = 0; kbi < nkb; ++kbi) {
+        const int buf = kbi & 1;
+        if (kbi + 1 < nkb) load_tile(kbi + 1);
+        const __bf16* kt = bsm + buf * BUF;
+        const __bf16* vt = kt + KT;
+        floatx16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {  // A: key l31, channels 16 s + 8 half + e
+            const bf16x8 ka = *reinterpret_cast<const bf16x8*>(kt + l31 * KROW + 16 * s + 8 * half);
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qreg[s], S, 0, 0, 0);
+        }
+        const int key0 = kbi * 32 + 4 * half;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float sv = (key0 + KAPPA(r) < N) ? S[r] * scale : -INFINITY;
+            S[r] = sv;
+            mx = fmaxf(mx, sv);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrun, mx);
+        const float alpha = __expf(mrun - mnew);
+        float ps = 0.f;
+        bf16x8 pb[2];  // B operand of O^T += V^T P: keys KAPPA(e) + 4 half (+16 for the second product)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __expf(S[r] - mnew);
+            ps += p;
+            pb[r >> 3][r & 7] = (__bf16)p;
+        }
+        lrun = lrun * alpha + ps;
+        mrun = mnew;
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[m][r] *= alpha;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {  // A: channel 32 m + l31, the same key order as pb
+                const __bf16* vr = vt + (m * 32 + l31) * VROW + 16 * t + 4 * half;
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vr), hi = *reinterpret_cast<const bf16x4*>(vr + 8);
+                const bf16x8 va = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                O[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb[t], O[m], 0, 0, 0);
+            }
+        if (kbi + 1 < nkb) write_tile(buf ^ 1);
+        __syncthreads();
+    }
+    const float l = lrun + __shfl_xor(lrun, 32, 64);
+    const float inv = 1.0f / l;
+    if (qi < N) {
+        float* ob = out + (long long)b * C * N + (long long)(h * DH) * N + qi;
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ob[(long long)(m * 32 + KAPPA(r) + 4 * half) * N] = O[m][r] * inv;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 template <int DH>
 __global__ __launch_bounds__(256) void attn_ctx_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
@@ -390,6 +524,17 @@ extern "C" int idiff_attn_self_fwd(const float* qkv, float* out, float* lse, int
         hipLaunchKernelGGL(attn_self_kernel<32>, grid, dim3(256), lds, st, qkv, out, lse, C, N, heads, scale);
     }
     IDIFF_CHECK_LAUNCH("attn_self_fwd");
+    return IDIFF_OK;
+}
+
+extern "C" int idiff_attn_self_bf16_fwd(const float* qkv, float* out, int B, int C, int N, int heads, float scale, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(qkv && out && B > 0 && C > 0 && N > 0 && heads > 0 && C % heads == 0, "attn_self_bf16: bad args");
+    IDIFF_CHECK_ARG(C / heads == 64, "attn_self_bf16: head dim must be 64 (got %d)", C / heads);
+    IDIFF_CHECK_ARG(N % 4 == 0 && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0, "attn_self_bf16: N %% 4 and 16-byte alignment required");
+    dim3 grid((N + 127) / 128, B * heads);
+    const size_t lds = (size_t)2 * (32 * (64 + 8) + 64 * (32 + 4)) * sizeof(uint16_t);
+    hipLaunchKernelGGL(attn_self_bf16_kernel, grid, dim3(256), lds, (hipStream_t)stream, qkv, out, C, N, heads, scale);
+    IDIFF_CHECK_LAUNCH("attn_self_bf16_fwd");
     return IDIFF_OK;
 }
 

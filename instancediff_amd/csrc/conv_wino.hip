@@ -110,11 +110,15 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a TRACE_PA
     const int HWin = a.Hin * a.Win;
     const int nchunks = a.Cin / CK;
 
-    // ---- per-thread gather geometry ----------------------------------------------------------------------------------
+    // ---- per-thread gather descriptors ---------------------------------------------------------------------------------
     // Thread stages R[tid + i*512]: the R index itself enumerates (ci, row, col) with the padded channel stride, so the
-    // LDS writes are linear and unmasked.  The element's byte offset inside the SAMPLE (or -1 for pad slots and for
-    // elements outside the image, which the raw buffer load answers with 0.0) is decoded afresh for every item -- a few
-    // dozen integer ops per item instead of 12 registers held through the whole kernel -- from its (ci, r, c).
+    // LDS writes are linear and unmasked.  An element's load offset is -1 for pad slots and for elements outside the image,
+    // which the raw buffer load answers with 0.0.
+    //   whole patches (RAG = false): gconst = byte offset relative to the patch origin (halo corner), constant for the whole
+    //     kernel; eflags = 4 bits per element: on the top / bottom / left / right halo edge.  Per item the edges that fall
+    //     outside the image turn their elements' offsets into -1.
+    //   partial patches (RAG = true): the offset inside the SAMPLE is decoded afresh for every item from the element's
+    //     (ci, r, c) -- a few dozen integer ops per item -- and bounds-checked against the image.
     auto slot_geometry = [&](int t, int i, int& ci, int& r, int& c) {
         const int e = t + i * NT;
         ci = e / PSP;
@@ -123,6 +127,18 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a TRACE_PA
         c = rem - r * RS;
         return ci < CK && rem < PS;
     };
+    int gconst[NL];
+    unsigned eflags = 0;
+    if (!RAG) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            int ci, r, c;
+            const bool slot = slot_geometry(tid, i, ci, r, c);
+            const int sp = MODE == IDIFF_CONV_UPSAMPLE2 ? (((r - 1) >> 1) + 1) * a.Win + ((c - 1) >> 1) + 1 : r * a.Win + c;
+            gconst[i] = slot ? (ci * HWin + sp) * 4 : -1;
+            eflags |= ((r == 0 ? 1u : 0u) | (r == TRH - 1 ? 2u : 0u) | (c == 0 ? 4u : 0u) | (c == RS - 1 ? 8u : 0u)) << (4 * i);
+        }
+    }
     // ---- per-item state ---------------------------------------------------------------------------------------------
     // Raw buffer loads: uniform base in the resource, chunk offset in an SGPR, per-lane byte offset in one VGPR -> no
     // per-load address arithmetic on the vector ALU (which the f32 MFMAs share); offset -1 fails the range check.
@@ -137,19 +153,31 @@ __global__ __launch_bounds__(NT) void conv_wino_kernel(const ConvArgs a TRACE_PA
         it_co0 = cob * 64;
         it_y0 = (it_tile / a.tiles_x) * TH;
         it_x0 = (it_tile % a.tiles_x) * TW;
-        rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0 + (long long)it_b * a.bs0), 0, 0x7fffffff, RSRC_FLAGS);
-        rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(SPEC == 3 ? a.src1 + (long long)it_b * a.bs1 : a.src0), 0, 0x7fffffff, RSRC_FLAGS);
         rsu = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wwino + (long long)cob * U_FLOATS), 0, 0x7fffffff, RSRC_FLAGS);
-        int t = tid;
-        asm volatile("" : "+v"(t));  // opaque: keeps the decode here, once per item, instead of hoisted out of the item loop and held
+        if (!RAG) {
+            // element (row 0, col 0) of the halo patch; may lie before the tensor for border patches (never dereferenced)
+            const long long org = MODE == IDIFF_CONV_UPSAMPLE2 ? (long long)(it_y0 / 2 - 1) * a.Win + (it_x0 / 2 - 1)
+                                                               : (long long)(it_y0 - 1) * a.Win + (it_x0 - 1);
+            rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0 + (long long)it_b * a.bs0 + org), 0, 0x7fffffff, RSRC_FLAGS);
+            rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(SPEC == 3 ? a.src1 + (long long)it_b * a.bs1 + org : a.src0), 0, 0x7fffffff,
+                                                    RSRC_FLAGS);
+            const unsigned out_edges = (it_y0 == 0 ? 1u : 0u) | (it_y0 + TH == a.Hout ? 2u : 0u) | (it_x0 == 0 ? 4u : 0u) | (it_x0 + TW == a.Wout ? 8u : 0u);
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            int ci, r, c;
-            const bool slot = slot_geometry(t, i, ci, r, c);
-            const int oy = it_y0 - 1 + r, ox = it_x0 - 1 + c;  // output-grid coordinates of the element
-            const bool in = slot && (unsigned)oy < (unsigned)a.Hout && (unsigned)ox < (unsigned)a.Wout;
-            const int sp = MODE == IDIFF_CONV_UPSAMPLE2 ? (oy >> 1) * a.Win + (ox >> 1) : oy * a.Win + ox;
-            goff[i] = in ? (ci * HWin + sp) * 4 : -1;
+            for (int i = 0; i < NL; ++i) goff[i] = ((eflags >> (4 * i)) & out_edges) ? -1 : gconst[i];
+        } else {
+            rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src0 + (long long)it_b * a.bs0), 0, 0x7fffffff, RSRC_FLAGS);
+            rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(SPEC == 3 ? a.src1 + (long long)it_b * a.bs1 : a.src0), 0, 0x7fffffff, RSRC_FLAGS);
+            int t = tid;
+            asm volatile("" : "+v"(t));  // opaque: keeps the decode here, once per item, instead of hoisted out of the item loop and held
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                int ci, r, c;
+                const bool slot = slot_geometry(t, i, ci, r, c);
+                const int oy = it_y0 - 1 + r, ox = it_x0 - 1 + c;  // output-grid coordinates of the element
+                const bool in = slot && (unsigned)oy < (unsigned)a.Hout && (unsigned)ox < (unsigned)a.Wout;
+                const int sp = MODE == IDIFF_CONV_UPSAMPLE2 ? (oy >> 1) * a.Win + (ox >> 1) : oy * a.Win + ox;
+                goff[i] = in ? (ci * HWin + sp) * 4 : -1;
+            }
         }
     };
     const int ustride_b = a.ncob * U_FLOATS * 4;  // bytes between chunks of one channel block (whole U < 2^31 bytes)

@@ -284,6 +284,11 @@ def chan_layernorm(x, gamma, beta, eps=1e-5, want_mean_rstd=False):
     return (out, mr) if want_mean_rstd else out
 
 
+# IDIFF_ATTN_DTYPE=bf16: the self-attention contractions on the bf16 matrix cores (reduced-precision VARIANT, never the default;
+# bench.py --attn bf16 reports it as its own line with its PSNR delta against the fp32 path)
+ATTN_DTYPE = os.environ.get("IDIFF_ATTN_DTYPE", "f32").lower()
+
+
 def attn_self(qkv, heads, scale, want_lse=False):
     """qkv [B,3C,H,W] -> [B,C,H,W]"""
     lib = _lib.load()
@@ -291,6 +296,9 @@ def attn_self(qkv, heads, scale, want_lse=False):
     B, C3, H, W = qkv.shape
     Cc, N = C3 // 3, H * W
     out = torch.empty((B, Cc, H, W), device=qkv.device, dtype=torch.float32)
+    if ATTN_DTYPE == "bf16" and not want_lse and Cc // heads == 64 and N % 4 == 0:
+        check(lib.idiff_attn_self_bf16_fwd(_p(qkv), _p(out), B, Cc, N, heads, scale, _stream()), "attn_self_bf16_fwd")
+        return out
     lse = torch.empty((B, heads, N), device=qkv.device, dtype=torch.float32) if want_lse else None
     check(lib.idiff_attn_self_fwd(_p(qkv), _p(out), _p(lse), B, Cc, N, heads, scale, _stream()), "attn_self_fwd")
     return (out, lse) if want_lse else out

@@ -190,3 +190,24 @@ def test_linear_t_fused_layernorm(R, K, N):
     out = ops.linear_t(x.to(DEV), w.t().contiguous().to(DEV), b.to(DEV), res=res.to(DEV), act_out=ops.ACT_GELU,
                        ln=(gam.to(DEV), bet.to(DEV), 1e-5))
     _close(out, ref, 5e-6, "linear_t + LayerNorm")
+
+
+def test_attn_self_bf16_variant_close_to_fp32_kernel():
+    """Reduced-precision VARIANT (off by default): bf16 matrix-core contractions, fp32 softmax / accumulation.  Against the fp64
+    formula it carries bf16 input rounding (2^-9 relative per operand), nothing worse; the fp32 kernel stays the default path."""
+    g = torch.Generator().manual_seed(77)
+    for B, H, W in ((2, 32, 32), (1, 64, 64), (1, 12, 20)):
+        C, heads = 256, 4
+        qkv = torch.randn(B, 3 * C, H, W, generator=g) * 0.6
+        q, k, v = [t.reshape(B, heads, C // heads, H * W).double() for t in qkv.chunk(3, dim=1)]
+        scale = (C // heads) ** -0.5
+        att = (torch.einsum('bhcn,bhcm->bhnm', q, k) * scale).softmax(-1)
+        ref = torch.einsum('bhnm,bhcm->bhcn', att, v).reshape(B, C, H, W)
+        f32 = ops.attn_self(qkv.to(DEV), heads, scale)
+        lib = ops._lib.load()
+        out = torch.empty_like(f32)
+        ops.check(lib.idiff_attn_self_bf16_fwd(ops._p(qkv.to(DEV)), ops._p(out), B, C, H * W, heads, scale, ops._stream()), "attn_self_bf16")
+        e32 = float((f32.cpu().double() - ref).abs().max() / ref.abs().max())
+        e16 = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
+        print(f"attn_self N={H * W}: fp32 kernel {e32:.2e}, bf16 variant {e16:.2e}")
+        assert e32 < 1e-5 and e16 < 2e-2
