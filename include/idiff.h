@@ -79,6 +79,9 @@ typedef struct {
                                when set and the shape tiles exactly (Cin % 8 == 0 per source, Cout % 16 == 0,
                                Hout % 8 == 0, Wout % 32 == 0, NORMAL / UPSAMPLE2) the F(2x2,3x3) kernel runs
                                (2.25x fewer matrix-core flops, same epilogue); otherwise wpk is used       */
+    const float* wwino4;    /* optional F(4x4,3x3)-domain copy (idiff_pack_conv_weight_wino4): preferred over wwino when
+                               Hout % 4 == 0, Wout % 4 == 0, Wout >= 24, Cin % 8 == 0, Cout % 16 == 0 and a sample has at
+                               least 16 items of 16x32 pixels x 64 channels (4x fewer matrix-core flops than direct) */
 } idiff_conv_desc;
 
 int idiff_conv2d_num_tiles(int Hout, int Wout);
@@ -87,6 +90,7 @@ int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream);
 #define IDIFF_CONV_ALGO_DIRECT 0   /* implicit GEMM, conv_igemm.hip  */
 #define IDIFF_CONV_ALGO_WINOGRAD 1 /* F(2x2,3x3),   conv_wino.hip   */
 #define IDIFF_CONV_ALGO_STREAM1X1 2 /* weight gradient only: streaming 1x1 product */
+#define IDIFF_CONV_ALGO_WINOGRAD4 3 /* F(4x4,3x3),  conv_wino4.hip  */
 int idiff_conv2d_last_algo(void);
 /* w [Cout][Cin][ks][ks] (torch layout) -> wpk [ks*ks][Cin][Cout] */
 int idiff_pack_conv_weight(const float* w, float* wpk, int Cout, int Cin, int ks, idiff_stream_t stream);
@@ -98,6 +102,14 @@ int idiff_pack_conv_weight_T(const float* w, float* wpk, int Cout, int Cin, int 
  * in the kernel's order (u0, u1, -u3, u2) -- an opaque image, only idiff_conv2d_fwd reads it.
  * transpose != 0: the flipped, in/out-swapped weights of the data-gradient conv (then the conv has Cin' = Cout, Cout' = Cin). */
 int idiff_pack_conv_weight_wino(const float* w, float* wwino, int Cout, int Cin, int transpose, idiff_stream_t stream);
+/* 3x3 weights -> Winograd F(4x4,3x3) domain (6x6 positions), laid out as conv_wino4.hip stages it:
+ * [Cin/4][ceil(Cout/64)][9 position quads][4 co-blocks][4 k][16 co][4]  (36*Cin*ceil(Cout/64)*64 floats; Cin % 8 == 0,
+ * Cout % 16 == 0: a partial last block is zero-filled) -- an opaque image, only idiff_conv2d_fwd reads it. */
+int idiff_pack_conv_weight_wino4(const float* w, float* wwino4, int Cout, int Cin, int transpose, idiff_stream_t stream);
+/* Layers with fewer than min_items items PER SAMPLE (16x32 pixels x 64 output channels each; default 16) stay on the
+ * F(2x2,3x3) kernel; the batch size never enters the choice (a sample's bits do not depend on its batch).  Sets the
+ * threshold when min_items > 0 and returns the previous value (process-wide; tests). */
+int idiff_conv_wino4_min_items(int min_items);
 
 /* ------------------------------------------------------------------------------------------------
  * GroupNorm (+FiLM) folded to a per-(sample,channel) affine, applied by the consumer kernel.

@@ -30,6 +30,7 @@ class ConvDesc(C.Structure):
         ("aux", C.c_void_p), ("aux_bstride", C.c_int64), ("aux_a", C.c_void_p), ("aux_b", C.c_void_p),
         ("stats", C.c_void_p),
         ("wwino", C.c_void_p),
+        ("wwino4", C.c_void_p),
     ]
 
 
@@ -47,6 +48,8 @@ SIGNATURES = {
     "idiff_pack_conv_weight": (I, [P, P, I, I, I, c_stream]),
     "idiff_pack_conv_weight_T": (I, [P, P, I, I, I, c_stream]),
     "idiff_pack_conv_weight_wino": (I, [P, P, I, I, I, c_stream]),
+    "idiff_pack_conv_weight_wino4": (I, [P, P, I, I, I, c_stream]),
+    "idiff_conv_wino4_min_items": (I, [I]),
     "idiff_gn_finalize": (I, [P, I, I, I, I, I, P, P, P, I64, F, P, P, P, c_stream]),
     "idiff_affine_silu_add": (I, [P, I64, P, P, P, I64, P, P, I64, I, I, I, c_stream]),
     "idiff_linear_fwd": (I, [P, I64, P, I64, P, P, I64, P, P, I64, I, I, I, I, I, c_stream]),

@@ -15,6 +15,7 @@ struct ConvArgs {
     int Cout;
     const float* wpk;
     const float* wwino;  // Winograd-domain weights (idiff_pack_conv_weight_wino) or null
+    const float* wwino4; // F(4x4,3x3)-domain weights (idiff_pack_conv_weight_wino4) or null
     const float* bias;
     const float* pro_a;
     const float* pro_b;
@@ -36,5 +37,10 @@ struct ConvArgs {
 bool conv_wino_eligible(const ConvArgs& a, int ks, int mode);
 // launches it; a.tiles_x / ntiles / ncob / total_wg must describe 8x32-pixel patches and 64-channel blocks
 int launch_conv_wino(const ConvArgs& a, int mode, hipStream_t st);
+
+// F(4x4,3x3) kernel (conv_wino4.hip): 3x3, H and W multiples of 4, Cin % 8 == 0, Cout % 16 == 0, at least one 16x32-pixel x
+// 64-channel item per CU; a.tiles_x / ntiles / ncob describe 8x32-pixel patches (the GroupNorm-partials grid) as above
+bool conv_wino4_eligible(const ConvArgs& a, int ks, int mode);
+int launch_conv_wino4(const ConvArgs& a, int mode, hipStream_t st);
 
 }  // namespace idiff_detail

@@ -594,6 +594,7 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
     a.Cout = d->Cout;
     a.wpk = d->wpk;
     a.wwino = d->wwino;
+    a.wwino4 = d->wwino4;
     a.bias = d->bias;
     a.pro_a = d->pro_a;
     a.pro_b = d->pro_b;
@@ -652,6 +653,10 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
     IDIFF_CHECK_ARG(total < (1ll << 31), "conv2d: grid too large");
     a.total_wg = (unsigned)total;
     hipStream_t st = (hipStream_t)stream;
+    if (idiff_detail::conv_wino4_eligible(a, d->ks, d->mode)) {
+        g_last_algo = IDIFF_CONV_ALGO_WINOGRAD4;
+        return idiff_detail::launch_conv_wino4(a, d->mode, st);
+    }
     if (idiff_detail::conv_wino_eligible(a, d->ks, d->mode)) {
         g_last_algo = IDIFF_CONV_ALGO_WINOGRAD;
         return idiff_detail::launch_conv_wino(a, d->mode, st);

@@ -2,11 +2,13 @@
 // LayerNorm, token LayerNorm / Linear, time embedding, score map, channel gather.  gfx950, fp32.
 #include "common.h"
 
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
 thread_local char g_idiff_err[512] = "";
 
 extern "C" const char* idiff_last_error(void) { return g_idiff_err; }
 unsigned long long g_idiff_launches = 0;
-extern "C" int idiff_version(void) { return 2; }
+extern "C" int idiff_version(void) { return 3; }
 extern "C" int64_t idiff_launch_count(void) { return (int64_t)g_idiff_launches; }
 extern "C" int idiff_device_info(int* num_cu, int* wave_size, char* arch_name, int arch_name_len) {
     int dev = 0;
@@ -33,39 +35,47 @@ inline int grid_for(long long n, int per_block, int cap = 256 * 16) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// GroupNorm finalize: one wave per (b, group); fp64 reduction of the conv partials (deterministic order)
+// GroupNorm finalize: one 256-thread workgroup per (b, group); fp64 reduction of the conv partials in a fixed order (thread-strided
+// partial sums, butterfly per wave, the four waves combined in order) -> deterministic and independent of the batch around b
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ stats, int ntiles, int C, int groups, int HW,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         const float* __restrict__ film, long long film_ld, float eps,
-                                                         float* __restrict__ out_a, float* __restrict__ out_b,
-                                                         float* __restrict__ mean_rstd) {
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ stats, int ntiles, int C, int groups, int HW,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ film, long long film_ld, float eps,
+                                                          float* __restrict__ out_a, float* __restrict__ out_b,
+                                                          float* __restrict__ mean_rstd) {
+    __shared__ double wsum[4][2];
     const int b = blockIdx.x / groups, g = blockIdx.x % groups;
     const int cpg = C / groups;
-    const int lane = threadIdx.x;
-    const float* sp = stats + (long long)b * ntiles * C * 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* sp = stats + (long long)b * ntiles * C * 2 + (long long)g * cpg * 2;
     double s = 0.0, q = 0.0;
-    const int n = ntiles * cpg;
-    for (int i = lane; i < n; i += 64) {
-        const int t = i / cpg, c = g * cpg + (i - t * cpg);
-        s += (double)sp[((long long)t * C + c) * 2 + 0];
-        q += (double)sp[((long long)t * C + c) * 2 + 1];
-    }
+    // thread = (channel of the group, tile phase): no division in the loop, one 8-byte load per partial
+    const int cl = tid % cpg, tph = tid / cpg, tstep = 256 / cpg;
+    if (tph < tstep)
+        for (int t = tph; t < ntiles; t += tstep) {
+            const floatx2 v = *reinterpret_cast<const floatx2*>(sp + ((long long)t * C + cl) * 2);
+            s += (double)v.x;
+            q += (double)v.y;
+        }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         s += __shfl_xor(s, o, 64);
         q += __shfl_xor(q, o, 64);
     }
+    if (lane == 0) wsum[wave][0] = s, wsum[wave][1] = q;
+    __syncthreads();
+    s = ((wsum[0][0] + wsum[1][0]) + wsum[2][0]) + wsum[3][0];
+    q = ((wsum[0][1] + wsum[1][1]) + wsum[2][1]) + wsum[3][1];
     const double cnt = (double)cpg * (double)HW;
     const double mean = s / cnt;
     double var = q / cnt - mean * mean;
     if (var < 0.0) var = 0.0;
     const double rstd = 1.0 / sqrt(var + (double)eps);
-    if (mean_rstd && lane == 0) {
+    if (mean_rstd && tid == 0) {
         mean_rstd[((long long)b * groups + g) * 2 + 0] = (float)mean;
         mean_rstd[((long long)b * groups + g) * 2 + 1] = (float)rstd;
     }
-    for (int i = lane; i < cpg; i += 64) {
+    for (int i = tid; i < cpg; i += 256) {
         const int c = g * cpg + i;
         const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
         float a = (float)rstd * ga;
@@ -292,7 +302,8 @@ extern "C" int idiff_gn_finalize(const float* stats, int ntiles, int B, int C, i
                                  idiff_stream_t stream) {
     IDIFF_CHECK_ARG(stats && out_a && out_b, "gn_finalize: null pointer");
     IDIFF_CHECK_ARG(B > 0 && C > 0 && groups > 0 && C % groups == 0 && ntiles > 0 && HW > 0, "gn_finalize: bad dims");
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, (hipStream_t)stream, stats, ntiles, C, groups, HW, gamma, beta,
+    IDIFF_CHECK_ARG(C / groups <= 256, "gn_finalize: at most 256 channels per group (got %d)", C / groups);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, stats, ntiles, C, groups, HW, gamma, beta,
                        film, (long long)film_ld, eps, out_a, out_b, mean_rstd);
     IDIFF_CHECK_LAUNCH("gn_finalize");
     return IDIFF_OK;

@@ -54,6 +54,8 @@ def _c(t, name="tensor", dtype=torch.float32):
 
 # IDIFF_WINOGRAD=0 keeps every 3x3 conv on the direct implicit-GEMM kernel (A/B runs, parity bisection)
 WINOGRAD = bool(int(os.environ.get("IDIFF_WINOGRAD", "1")))
+# IDIFF_WINOGRAD4=0 keeps the forward 3x3 convs off the F(4x4,3x3) kernel (they run F(2x2,3x3) or direct instead)
+WINOGRAD4 = WINOGRAD and bool(int(os.environ.get("IDIFF_WINOGRAD4", "1")))
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -71,6 +73,10 @@ def pack_conv_weight(w, transpose=False):
         wino = torch.empty((16 * kconv * ((cconv + 63) // 64) * 64,), device=w.device, dtype=torch.float32)
         check(lib.idiff_pack_conv_weight_wino(_p(w), _p(wino), co, ci, 1 if transpose else 0, _stream()), "pack_conv_weight_wino")
         out.wino = wino
+        if WINOGRAD4 and not transpose:  # forward convs only: the data-gradient convs stay on F(2x2,3x3)
+            wino4 = torch.empty((36 * kconv * ((cconv + 63) // 64) * 64,), device=w.device, dtype=torch.float32)
+            check(lib.idiff_pack_conv_weight_wino4(_p(w), _p(wino4), co, ci, 0, _stream()), "pack_conv_weight_wino4")
+            out.wino4 = wino4
     return out
 
 
@@ -95,6 +101,9 @@ def conv2d(src0, wpk, bias, ks, Cout, src1=None, mode=CONV_NORMAL, pro=None, out
     wino = getattr(wpk, "wino", None)
     if wino is not None and ks == 3:
         d.wwino = wino.data_ptr()
+        wino4 = getattr(wpk, "wino4", None)
+        if wino4 is not None:
+            d.wwino4 = wino4.data_ptr()
     if bias is not None:
         d.bias = _c(bias, "bias").data_ptr()
     if pro is not None:

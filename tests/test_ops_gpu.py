@@ -27,6 +27,11 @@ def _g(seed):
     return torch.Generator().manual_seed(seed)
 
 
+def _conv_tol():
+    """fp32 error bound (of the output range) of the kernel that served the last conv2d: direct, F(2x2,3x3), F(4x4,3x3)."""
+    return {0: 2e-6, 1: 6e-6, 3: 4e-5}[ops._lib.load().idiff_conv2d_last_algo()]
+
+
 def silu64(x):
     return x / (1 + torch.exp(-x))
 
@@ -51,7 +56,7 @@ def test_conv_plain(B, Cin, Cout, H, W, ks):
     ref = F.conv2d(x.double(), w.double(), b.double(), padding=ks // 2)
     wpk = ops.pack_conv_weight(w.to(DEV))
     out = ops.conv2d(x.to(DEV), wpk, b.to(DEV), ks, Cout)
-    _close(out, ref, 2e-6, "conv")
+    _close(out, ref, _conv_tol(), "conv")
 
 
 def test_conv_concat_prologue_epilogue_stats():
@@ -97,7 +102,7 @@ def test_conv_upsample_and_unshuffle(H, W):
     b = torch.randn(Cout, generator=g)
     ref = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), w.double(), b.double(), padding=1)
     out = ops.conv2d(x.to(DEV), ops.pack_conv_weight(w.to(DEV)), b.to(DEV), 3, Cout, mode=ops.CONV_UPSAMPLE2)
-    _close(out, ref, 2e-6, "upsample conv")
+    _close(out, ref, _conv_tol(), "upsample conv")
     w1 = torch.randn(Cout, Cin * 4, 1, 1, generator=g) / math.sqrt(Cin * 4)
     ref = F.conv2d(F.pixel_unshuffle(x.double(), 2), w1.double(), b.double())
     out = ops.conv2d(x.to(DEV), ops.pack_conv_weight(w1.to(DEV)), b.to(DEV), 1, Cout, mode=ops.CONV_UNSHUFFLE2)
@@ -302,14 +307,14 @@ def test_philox_bit_exact_and_randn():
 
 # ---------------------------------------------------------------------------------------------------
 # Winograd F(2x2,3x3) kernel (conv_wino.hip) vs the direct implicit-GEMM kernel and the fp64 reference
-def _pack(w, wino, transpose=False):
-    old = ops.WINOGRAD
-    ops.WINOGRAD = wino
+def _pack(w, wino, transpose=False, wino4=False):
+    old, old4 = ops.WINOGRAD, ops.WINOGRAD4
+    ops.WINOGRAD, ops.WINOGRAD4 = wino, wino4
     try:
         p = ops.pack_conv_weight(w, transpose=transpose)
     finally:
-        ops.WINOGRAD = old
-    assert hasattr(p, "wino") == wino
+        ops.WINOGRAD, ops.WINOGRAD4 = old, old4
+    assert hasattr(p, "wino") == wino and hasattr(p, "wino4") == (wino4 and not transpose)
     return p
 
 
@@ -425,3 +430,110 @@ def test_conv_winograd_random_shapes_match_direct():
         od, sd = ops.conv2d(x0, _pack(w, False), bias, 3, Cout, src1=x1, want_stats=True, **kw)
         _close(ow, od.cpu(), 8e-6, f"case {case}: B={B} C0={C0} C1={C1} Cout={Cout} H={H} W={W} pro={pro}")
         _close(sw, sd.cpu(), 3e-5, f"case {case}: stats")
+
+
+# ---------------------------------------------------------------------------------------------------
+# Winograd F(4x4,3x3) kernel (conv_wino4.hip): 16x32-pixel items, 6x6 transforms.  fp32 with transform constants up to 8:
+# about one decimal digit less than F(2x2,3x3) (tolerance 4e-5 of the output range, measured ~1e-5).
+@pytest.fixture
+def force_wino4():
+    lib = ops._lib.load()
+    old = lib.idiff_conv_wino4_min_items(1)
+    yield lib
+    lib.idiff_conv_wino4_min_items(old)
+
+
+@pytest.mark.parametrize("B,C0,C1,Cout,H,W,variant", [
+    (2, 64, 0, 64, 32, 32, "plain"),
+    (1, 8, 0, 128, 16, 64, "plain"),        # two chunks, two channel blocks, 1x2 patches
+    (2, 64, 0, 64, 16, 96, "prologue"),
+    (1, 24, 40, 192, 32, 32, "concat"),
+    (2, 32, 0, 64, 16, 16, "upsample"),     # out 32x32
+    (1, 128, 0, 256, 64, 64, "epilogue"),
+    (2, 32, 0, 80, 16, 32, "plain"),        # Cout % 64 = 16: partial last channel block
+    (1, 64, 0, 144, 16, 32, "epilogue"),    # partial block with residual / aux / stats
+    # image not a multiple of the 16x32 patch: partial patches at the right / bottom border, masked stores and statistics
+    (2, 32, 0, 64, 28, 56, "plain"),
+    (1, 64, 0, 64, 8, 112, "prologue"),     # half a patch high: the lower half-patch is entirely outside
+    (2, 16, 0, 48, 12, 36, "epilogue"),
+    (1, 16, 0, 32, 14, 28, "upsample"),     # out 28x56
+    (1, 24, 16, 64, 20, 40, "concat"),
+    (2, 32, 0, 64, 28, 28, "epilogue"),     # narrower than a patch (the 224 / 8 level)
+    (1, 16, 0, 32, 24, 24, "plain"),
+    (1, 8, 0, 64, 56, 56, "prologue"),      # 56 = 3.5 patches high
+    # several items per workgroup, two to ten chunks per item: the software pipeline runs across item boundaries
+    (21, 8, 0, 64, 64, 64, "epilogue"),
+    (20, 16, 0, 128, 64, 64, "prologue"),
+    (17, 40, 0, 64, 64, 96, "plain"),
+])
+def test_conv_winograd4_matches_direct_and_fp64(force_wino4, B, C0, C1, Cout, H, W, variant):
+    lib = force_wino4
+    g = _g(21)
+    Cin = C0 + C1
+    x0 = torch.randn(B, C0, H, W, generator=g)
+    x1 = torch.randn(B, C1, H, W, generator=g) if C1 else None
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    kw = {}
+    xin = x0.double() if x1 is None else torch.cat([x0, x1], 1).double()
+    if variant == "prologue":
+        pa, pb = torch.randn(B, C0, generator=g), torch.randn(B, C0, generator=g)
+        xin = silu64(pa.double()[:, :, None, None] * xin + pb.double()[:, :, None, None])
+        kw["pro"] = (pa.to(DEV), pb.to(DEV))
+    if variant == "upsample":
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+        kw["mode"] = ops.CONV_UPSAMPLE2
+    if x1 is not None:
+        kw["src1"] = x1.to(DEV)
+    raw = F.conv2d(xin, w.double(), b.double(), padding=1)
+    ref = raw
+    Ho, Wo = raw.shape[2:]
+    if variant == "epilogue":
+        res = torch.randn(B, Cout, Ho, Wo, generator=g)
+        vec = torch.randn(B, Cout, generator=g)
+        aux = torch.randn(B, Cout, Ho, Wo, generator=g)
+        aa, ab = torch.randn(B, Cout, generator=g), torch.randn(B, Cout, generator=g)
+        ref = raw + res.double() + vec.double()[:, :, None, None] + silu64(aa.double()[:, :, None, None] * aux.double() + ab.double()[:, :, None, None])
+        kw.update(res=res.to(DEV), vec=vec.to(DEV), aux=(aux.to(DEV), aa.to(DEV), ab.to(DEV)))
+    wd = w.to(DEV)
+    out_w, st_w = ops.conv2d(x0.to(DEV), _pack(wd, True, wino4=True), b.to(DEV), 3, Cout, want_stats=True, **kw)
+    assert lib.idiff_conv2d_last_algo() == 3, "the F(4x4,3x3) kernel did not run"
+    out_d, st_d = ops.conv2d(x0.to(DEV), _pack(wd, False), b.to(DEV), 3, Cout, want_stats=True, **kw)
+    assert lib.idiff_conv2d_last_algo() == 0
+    _close(out_w, ref, 4e-5, "winograd4")
+    assert st_w.shape == st_d.shape
+    _close(st_w.sum(1)[..., 0], raw.sum(dim=(2, 3)), 4e-5, "winograd4 stats sum")
+    _close(st_w.sum(1)[..., 1], (raw ** 2).sum(dim=(2, 3)), 4e-5, "winograd4 stats sumsq")
+    _close(st_w, st_d.cpu(), 1e-4, "per-patch stats layout")
+    # without statistics, and the launch is repeatable bit for bit
+    out_2 = ops.conv2d(x0.to(DEV), _pack(wd, True, wino4=True), b.to(DEV), 3, Cout, **kw)
+    assert torch.equal(out_2, out_w)
+
+
+def test_conv_winograd4_policy_and_fallback():
+    """Small levels (fewer than 16 items per sample, whatever the batch) stay on F(2x2,3x3); shapes outside the 4x4 tiling
+    fall back."""
+    lib = ops._lib.load()
+    g = _g(22)
+    w = (torch.randn(64, 32, 3, 3, generator=g) / 17.0).to(DEV)
+    wpk = _pack(w, True, wino4=True)
+    x = torch.randn(2, 32, 32, 32, generator=g).to(DEV)
+    ops.conv2d(x, wpk, None, 3, 64)
+    assert lib.idiff_conv2d_last_algo() == 1           # 2 items per sample
+    old = lib.idiff_conv_wino4_min_items(1)
+    try:
+        ops.conv2d(x, wpk, None, 3, 64)
+        assert lib.idiff_conv2d_last_algo() == 3
+        x2 = torch.randn(1, 32, 30, 36, generator=g).to(DEV)   # H % 4 != 0
+        ref = F.conv2d(x2.double().cpu(), w.double().cpu(), padding=1)
+        _close(ops.conv2d(x2, wpk, None, 3, 64), ref, 6e-6, "fallback")
+        assert lib.idiff_conv2d_last_algo() == 1
+    finally:
+        lib.idiff_conv_wino4_min_items(old)
+    big = torch.randn(16, 32, 64, 64, generator=g).to(DEV)   # 8 items per sample: the batch does not count
+    ops.conv2d(big, wpk, None, 3, 64)
+    assert lib.idiff_conv2d_last_algo() == 1
+    big = torch.randn(3, 32, 128, 128, generator=g).to(DEV)   # 32 items per sample
+    out = ops.conv2d(big, wpk, None, 3, 64)
+    assert lib.idiff_conv2d_last_algo() == 3
+    _close(out, F.conv2d(big.double().cpu(), w.double().cpu(), padding=1), 4e-5, "winograd4 128x128")
