@@ -48,6 +48,13 @@ constexpr int NU = 5;                      // float4 of weights per thread per c
 
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 
+// Numbering of the 36 Winograd positions (u, v) into 9 quads of 4: the first four columns of row u fill quad PF(u), its last
+// two a half of quad PH(u) shared with the neighbouring row -- every row is one 16-byte and one 8-byte piece at fixed places,
+// so the transform writes them without looking at the row's parity.
+__host__ __device__ constexpr int PF(int u) { return (3 * u + 1) / 2; }       // 0, 2, 3, 5, 6, 8
+__host__ __device__ constexpr int PH(int u) { return 1 + 3 * (u / 2); }       // 1, 1, 4, 4, 7, 7
+__host__ __device__ constexpr int pos(int u, int v) { return v < 4 ? 4 * PF(u) + v : 4 * PH(u) + 2 * (u & 1) + (v - 4); }
+
 struct Geo4 {
     int np;        // 16x32 patches per sample
     int total;     // items = B * np * ncob
@@ -70,13 +77,13 @@ __device__ __forceinline__ float row_sum16(float v) {
 // -DIDIFF_WINO_TRACE: per-phase cycle counts (s_memtime) summed over all items, printed by the launcher (debug builds)
 #ifdef IDIFF_WINO_TRACE
 #define TRACE_PARAM , long long* trace
-#define TRACE_INIT long long tr_t[5] = {0, 0, 0, 0, 0}, tr_acc[4] = {0, 0, 0, 0};
+#define TRACE_INIT long long tr_t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define TRACE_MARK(k)                       \
     tr_t[k] = __builtin_readcyclecounter(); \
     if (k > 0) tr_acc[k - 1] += tr_t[k] - tr_t[k - 1];
 #define TRACE_FINI                                                                                                      \
     if (tid == 0) {                                                                                                     \
-        for (int q_ = 0; q_ < 4; ++q_) atomicAdd((unsigned long long*)trace + q_, (unsigned long long)tr_acc[q_]);      \
+        for (int q_ = 0; q_ < 8; ++q_) atomicAdd((unsigned long long*)trace + q_, (unsigned long long)tr_acc[q_]);      \
     }
 #else
 #define TRACE_PARAM
@@ -212,7 +219,6 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
     struct Pro {
         floatx4 a, b;
     };
-    const bool hiw = wave >= 4;
     auto load_pro = [&](int bb, int cc) {
         Pro p;
         if (SPEC == 2) {
@@ -239,14 +245,16 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
             for (int i = 0; i < NL; ++i) dst[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs0, goff[i], so, 0));
         }
     };
-    auto load_u = [&](int cc) {
+    // the 2304 float4 of a weight chunk: four per thread, the last 256 by the light waves (tid >= 256)
+    auto load_u = [&](int cc, auto hv_tag) {
+        constexpr bool HV = decltype(hv_tag)::value;
 #pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            if (i == NU - 1 && wave >= 4) break;
+        for (int i = 0; i < NU - 1; ++i)
             ru[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsu, tid * 16, cc * ustride_b + i * NT * 16, 0));
-        }
+        if (!HV) ru[NU - 1] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsu, tid * 16, cc * ustride_b + (NU - 1) * NT * 16 - 256 * 16, 0));
     };
-    auto stage_raw = [&](const float (&src)[NL], int i, const Pro& pro, int rbuf) {
+    auto stage_raw = [&](const float (&src)[NL], int i, const Pro& pro, int rbuf, auto hv_tag) {
+        constexpr bool hiw = !decltype(hv_tag)::value;
         float x = src[i];
         if (SPEC == 2) {  // channel of element tid + i*512: (i*512 + wave*64) / 768 = {0, 0|1, 1, 2, 2|3, 3}[i]
             const float pa = i == 0 ? pro.a.x : i == 1 ? (hiw ? pro.a.y : pro.a.x) : i == 2 ? pro.a.y : i == 3 ? pro.a.z : i == 4 ? (hiw ? pro.a.w : pro.a.z) : pro.a.w;
@@ -255,15 +263,16 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
         }
         Rb[rbuf * R_FLOATS + tid + i * NT] = (SPEC == 2 && ((omask >> i) & 1u)) ? 0.f : x;  // padding is zero AFTER the activation
     };
-    auto stage_u = [&](int i, int buf) {
-        if (i == NU - 1 && wave >= 4) return;
-        reinterpret_cast<floatx4*>(Ub + buf * U_FLOATS)[tid + i * NT] = ru[i];
+    auto stage_u = [&](int i, int buf, auto hv_tag) {
+        constexpr bool HV = decltype(hv_tag)::value;
+        if (i < NU - 1) reinterpret_cast<floatx4*>(Ub + buf * U_FLOATS)[tid + i * NT] = ru[i];
+        else if (!HV) reinterpret_cast<floatx4*>(Ub + buf * U_FLOATS)[tid + i * NT - 256] = ru[i];
     };
 
     // ---- input transform B^T d B of R[rbuf] -> V[buf].  Thread = (ci = k4, tile (tyl, tx) of half-patch thalf) x row set:
     //   heavy waves 0-3: Winograd rows (1,2) (trole 0) or (3,4) (trole 1):  X = d4 + al*d2, Y = d3 + al*d1, rows X +- be*Y
     //   light waves 4-7: row 0 (from d0, d2, d4) or row 5 (from d1, d3, d5): 4*dA - 5*dB + dC
-    const bool heavy = wave < 4;
+    const bool heavy = wave < 4;  // wave class: uniform; the main loop is instantiated once per class, branch-free
     const int trole = wave & 1;
     const int thalf = (wave >> 1) & 1;
     const int tx = lane & 7, tyl = (lane >> 3) & 1;
@@ -280,7 +289,8 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
         const floatx2 hi = *reinterpret_cast<const floatx2*>(p + 4);
         d[0] = lo.x, d[1] = lo.y, d[2] = lo.z, d[3] = lo.w, d[4] = hi.x, d[5] = hi.y;
     };
-    auto tr_piece = [&](int piece, int rbuf, int buf) {
+    auto tr_piece = [&](int piece, int rbuf, int buf, auto hv_tag) {
+        constexpr bool heavy = decltype(hv_tag)::value;
         const float* p = trbase + rbuf * R_FLOATS;
         if (piece == 0) {
             if (heavy) rd_row(p + 1 * RS, ta), rd_row(p + 3 * RS, tb);  // d2, d4
@@ -312,16 +322,10 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
             if (which == 1 && !heavy) return;
             float o[6];
             bt6(which ? thi : tlo, o);
-            // row u holds positions 6u .. 6u+5: a whole quad and half of a neighbouring one, in this order for even u
             const int u = ufirst + which;
-            float* const V = vwbase + buf * V_FLOATS + (6 * u >> 2) * 512;
-            if (u & 1) {
-                *reinterpret_cast<floatx2*>(V + 2) = floatx2{o[0], o[1]};
-                *reinterpret_cast<floatx4*>(V + 512) = floatx4{o[2], o[3], o[4], o[5]};
-            } else {
-                *reinterpret_cast<floatx4*>(V) = floatx4{o[0], o[1], o[2], o[3]};
-                *reinterpret_cast<floatx2*>(V + 512) = floatx2{o[4], o[5]};
-            }
+            float* const V = vwbase + buf * V_FLOATS;
+            *reinterpret_cast<floatx4*>(V + PF(u) * 512) = floatx4{o[0], o[1], o[2], o[3]};
+            *reinterpret_cast<floatx2*>(V + PH(u) * 512 + 2 * (u & 1)) = floatx2{o[4], o[5]};
         }
     };
     auto clampc = [&](int c) { return c < nchunks ? c : nchunks - 1; };
@@ -347,7 +351,8 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
     setup_item();
     load_raw(rinA, 0);
     load_raw(rinB, 1);
-    load_u(0);
+    if (heavy) load_u(0, std::true_type{});
+    else load_u(0, std::false_type{});
     fetch_consts();
     TRACE_INIT
 
@@ -357,90 +362,112 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
 
         // ---- pipeline fill: V[0], U[0] hold chunk 0, R[1] chunk 1; raw(2), raw(3) and U(1) are in registers ---------------
         __syncthreads();  // every wave is done with the previous item's LDS
+        TRACE_MARK(1)
         const Pro pro0 = load_pro(b, 0), pro1 = load_pro(b, 1);
         if (tid < 256) econst[tid] = pre_e;
-#pragma unroll
-        for (int i = 0; i < NL; ++i) stage_raw(rinA, i, pro0, 0);
-#pragma unroll
-        for (int i = 0; i < NU; ++i) stage_u(i, 0);
-#pragma unroll
-        for (int i = 0; i < NL; ++i) stage_raw(rinB, i, pro1, 1);
-        load_raw(rinA, clampc(2));
-        load_raw(rinB, clampc(3));
-        load_u(1);
-        __syncthreads();
-#pragma unroll
-        for (int piece = 0; piece < 5; ++piece) tr_piece(piece, 0, 0);
-
         floatx4 acc[36];
+        // fill + main loop, instantiated per wave class (heavy: waves 0-3, light: waves 4-7) so that the role-dependent pieces
+        // are straight-line code; every wave passes the same barriers
+        auto run_item = [&](auto hv) {
 #pragma unroll
-        for (int p = 0; p < 36; ++p) acc[p] = floatx4{0.f, 0.f, 0.f, 0.f};
-        __syncthreads();
-        TRACE_MARK(1)
+            for (int i = 0; i < NL; ++i) stage_raw(rinA, i, pro0, 0, hv);
+#pragma unroll
+            for (int i = 0; i < NU; ++i) stage_u(i, 0, hv);
+#pragma unroll
+            for (int i = 0; i < NL; ++i) stage_raw(rinB, i, pro1, 1, hv);
+            load_raw(rinA, clampc(2));
+            load_raw(rinB, clampc(3));
+            load_u(1, hv);
+            TRACE_MARK(2)
+            __syncthreads();
+            TRACE_MARK(3)
+#pragma unroll
+            for (int piece = 0; piece < 5; ++piece) tr_piece(piece, 0, 0, hv);
 
-        // ---- main loop, ONE barrier per chunk.  Iteration c runs the 18 position pairs of chunk c and, one slice per pair:
-        //   stage raw(c+2) registers -> R[c&1], then load raw(c+4) into them;  stage U(c+1) -> U[(c+1)&1], then load U(c+2);
-        //   transform R[(c+1)&1] (staged one iteration ago) -> V[(c+1)&1].
-        const int opoff = lane * 4;
-        const bool have_next = item + G < last;
-        auto chunk = [&](int cc, auto par_tag, auto more_tag) {
-            constexpr int PAR = decltype(par_tag)::value;      // cc & 1: LDS buffers and the raw register set
-            constexpr bool MORE = decltype(more_tag)::value;   // false: last chunk, nothing left to stage
-            const float* V = Vb + PAR * V_FLOATS + tblk * 256 + opoff;
-            const float* U = Ub + PAR * U_FLOATS + cb * 256 + opoff;
-            float(&rin)[NL] = PAR ? rinB : rinA;
-            Pro pro;
-            if (MORE) pro = load_pro(b, clampc(cc + 2));  // the affine of the chunk staged below
-            floatx4 ob[2], oa[2];
-            ob[0] = *reinterpret_cast<const floatx4*>(V);
-            oa[0] = *reinterpret_cast<const floatx4*>(U);
 #pragma unroll
-            for (int q = 0; q < 9; ++q) {
-                if (q + 1 < 9) {
-                    ob[(q + 1) & 1] = *reinterpret_cast<const floatx4*>(V + (q + 1) * 512);
-                    oa[(q + 1) & 1] = *reinterpret_cast<const floatx4*>(U + (q + 1) * 1024);
-                }
-                const floatx4 bv = ob[q & 1], av = oa[q & 1];
-                acc[4 * q + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[4 * q + 0], 0, 0, 0);
-                acc[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[4 * q + 1], 0, 0, 0);
-                acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[4 * q + 2], 0, 0, 0);
-                acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[4 * q + 3], 0, 0, 0);
-                if (MORE) {
+            for (int p = 0; p < 36; ++p) acc[p] = floatx4{0.f, 0.f, 0.f, 0.f};
+            __syncthreads();
+            TRACE_MARK(4)
+
+            // ---- main loop, ONE barrier per chunk.  Iteration c runs the 18 position pairs of chunk c and, one slice per pair:
+            //   stage raw(c+2) registers -> R[c&1], then load raw(c+4) into them;  stage U(c+1) -> U[(c+1)&1], then load U(c+2);
+            //   transform R[(c+1)&1] (staged one iteration ago) -> V[(c+1)&1].
+            const int opoff = lane * 4;
+            const bool have_next = item + G < last;
+            auto chunk = [&](int cc, auto par_tag, auto more_tag) {
+                constexpr int PAR = decltype(par_tag)::value;      // cc & 1: LDS buffers and the raw register set
+                constexpr bool MORE = decltype(more_tag)::value;   // false: last chunk, nothing left to stage
+                const float* V = Vb + PAR * V_FLOATS + tblk * 256 + opoff;
+                const float* U = Ub + PAR * U_FLOATS + cb * 256 + opoff;
+                float(&rin)[NL] = PAR ? rinB : rinA;
+                Pro pro;
+                if (MORE) pro = load_pro(b, clampc(cc + 2));  // the affine of the chunk staged below
+                floatx4 ob[2], oa[2];
+                ob[0] = *reinterpret_cast<const floatx4*>(V);
+                oa[0] = *reinterpret_cast<const floatx4*>(U);
+#pragma unroll
+                for (int q = 0; q < 9; ++q) {
+                    if (q + 1 < 9) {
+                        ob[(q + 1) & 1] = *reinterpret_cast<const floatx4*>(V + (q + 1) * 512);
+                        oa[(q + 1) & 1] = *reinterpret_cast<const floatx4*>(U + (q + 1) * 1024);
+                    }
+                    const floatx4 bv = ob[q & 1], av = oa[q & 1];
+                    acc[4 * q + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[4 * q + 0], 0, 0, 0);
+                    acc[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[4 * q + 1], 0, 0, 0);
+                    acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[4 * q + 2], 0, 0, 0);
+                    acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[4 * q + 3], 0, 0, 0);
+                    if (MORE) {
 #ifndef W4_NO_TR
-                    if (q < 5) tr_piece(q, PAR ^ 1, PAR ^ 1);
+                        if (q < 5) tr_piece(q, PAR ^ 1, PAR ^ 1, hv);
 #endif
 #ifndef W4_NO_U
-                    if (q >= 1 && q < 5) stage_u(q - 1, PAR ^ 1);
-                    if (q == 5) stage_u(4, PAR ^ 1);
-                    if (q == 6) load_u(clampc(cc + 2));
+                        if (q >= 1 && q < 5) stage_u(q - 1, PAR ^ 1, hv);
+                        if (q == 5) stage_u(4, PAR ^ 1, hv);
+#ifndef W4_NO_ULOAD
+                        if (q == 6) load_u(clampc(cc + 2), hv);
+#endif
 #endif
 #ifndef W4_NO_RAW
-                    if (q == 5) stage_raw(rin, 0, pro, PAR), stage_raw(rin, 1, pro, PAR);
-                    if (q == 6) stage_raw(rin, 2, pro, PAR), stage_raw(rin, 3, pro, PAR);
-                    if (q == 7) stage_raw(rin, 4, pro, PAR), stage_raw(rin, 5, pro, PAR);
-                    if (q == 8) load_raw(rin, clampc(cc + 4));
+                        if (q == 5) stage_raw(rin, 0, pro, PAR, hv), stage_raw(rin, 1, pro, PAR, hv);
+                        if (q == 6) stage_raw(rin, 2, pro, PAR, hv), stage_raw(rin, 3, pro, PAR, hv);
+                        if (q == 7) stage_raw(rin, 4, pro, PAR, hv), stage_raw(rin, 5, pro, PAR, hv);
+#ifndef W4_NO_RAWLOAD
+                        if (q == 8) load_raw(rin, clampc(cc + 4));
 #endif
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (q == 8) __syncthreads();
-                } else if (have_next) {
-                    // Nothing is staged in the last chunk, so the item state is free: switch it to the next item between the
-                    // MFMAs and let its first patches and weights travel during the rest of the chunk and the epilogue.
-                    if (q == 0) advance_item(), setup_item();
-                    if (q == 2) load_raw(rinA, 0);
-                    if (q == 3) load_raw(rinB, 1);
-                    if (q == 4) load_u(0);
-                    if (q == 5) fetch_consts();
-                    __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifdef W4_SGB
+                        // within the slot: operand prefetch first, then the side work dealt out behind each of the four MFMAs
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x096, W4_SGB, 0);
+                        }
+#endif
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (q == 8) __syncthreads();
+                    } else if (have_next) {
+                        // Nothing is staged in the last chunk, so the item state is free: switch it to the next item between the
+                        // MFMAs and let its first patches and weights travel during the rest of the chunk and the epilogue.
+                        if (q == 0) advance_item(), setup_item();
+                        if (q == 2) load_raw(rinA, 0);
+                        if (q == 3) load_raw(rinB, 1);
+                        if (q == 4) load_u(0, hv);
+                        if (q == 5) fetch_consts();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
+            };
+            for (int cc = 0; cc + 2 < nchunks; cc += 2) {
+                chunk(cc, std::integral_constant<int, 0>{}, std::true_type{});
+                chunk(cc + 1, std::integral_constant<int, 1>{}, std::true_type{});
             }
+            chunk(nchunks - 2, std::integral_constant<int, 0>{}, std::true_type{});
+            chunk(nchunks - 1, std::integral_constant<int, 1>{}, std::false_type{});
         };
-        for (int cc = 0; cc + 2 < nchunks; cc += 2) {
-            chunk(cc, std::integral_constant<int, 0>{}, std::true_type{});
-            chunk(cc + 1, std::integral_constant<int, 1>{}, std::true_type{});
-        }
-        chunk(nchunks - 2, std::integral_constant<int, 0>{}, std::true_type{});
-        chunk(nchunks - 1, std::integral_constant<int, 1>{}, std::false_type{});
-        TRACE_MARK(2)
+        if (heavy) run_item(std::true_type{});
+        else run_item(std::false_type{});
+        TRACE_MARK(5)
 
         // ---- epilogue: in-lane output transform A^T m A, then the conv_igemm epilogue contract ---------------------------
         // C layout of 16x16x4: lane holds column j (tile) and rows 4*k4 + r (channels) of the wave's 16-channel block
@@ -465,9 +492,10 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
             for (int u = 0; u < 6; ++u) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    at6(acc[6 * u + 0][r], acc[6 * u + 1][r], acc[6 * u + 2][r], acc[6 * u + 3][r], acc[6 * u + 4][r], acc[6 * u + 5][r], zz[u][r]);
+                    at6(acc[pos(u, 0)][r], acc[pos(u, 1)][r], acc[pos(u, 2)][r], acc[pos(u, 3)][r], acc[pos(u, 4)][r], acc[pos(u, 5)][r], zz[u][r]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            TRACE_MARK(6)
             // Phase 2, per channel r: A^T along u, bias, GroupNorm partials, then four row steps.  The residual / aux row of
             // step s+1 is requested BEFORE the store of step s (vmcnt counts loads and stores in order: a load behind a store
             // would wait for it).  has_res / has_aux are uniform branches.
@@ -520,8 +548,8 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        TRACE_MARK(3)
-        TRACE_MARK(4)
+        TRACE_MARK(7)
+        TRACE_MARK(8)
     }
     TRACE_FINI
 }
@@ -561,8 +589,8 @@ int launch_rag(const ConvArgs& a, hipStream_t st) {
     long long h[8];
     (void)hipMemcpyAsync(h, tr, sizeof(h), hipMemcpyDeviceToHost, st);
     (void)hipStreamSynchronize(st);
-    fprintf(stderr, "[wino4 trace] Cin=%d Cout=%d H=%d items=%d per=%d | fill %lld  loop %lld  epilogue %lld (cycles/item, wave 0)\n", a.Cin, a.Cout, a.Hout,
-            g.total, per, h[0] / g.total, h[1] / g.total, h[2] / g.total);
+    fprintf(stderr, "[wino4 trace] Cin=%d Cout=%d H=%d items=%d per=%d | topbar %lld stage %lld bar2 %lld tr+bar3 %lld loop %lld epi1 %lld epi2 %lld (cycles/item, wave 0)\n",
+            a.Cin, a.Cout, a.Hout, g.total, per, h[0] / g.total, h[1] / g.total, h[2] / g.total, h[3] / g.total, h[4] / g.total, h[5] / g.total, h[6] / g.total);
 #else
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, a, g);
 #endif
@@ -616,7 +644,7 @@ __global__ void pack_wino4_kernel(const float* __restrict__ w, float* __restrict
             g6(t[u][0], t[u][1], t[u][2], o);
 #pragma unroll
             for (int v = 0; v < 6; ++v) {
-                const int p = 6 * u + v;
+                const int p = pos(u, v);
                 dst[(p >> 2) * 1024 + (p & 3)] = o[v];
             }
         }
