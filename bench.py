@@ -10,12 +10,13 @@ update, fp32, random-init weights (seed 0), inputs resident in HBM, on-device Ph
 independent replicas (sampling shards by image, no data-path collective) -> weak scaling.
 
 Prints ONE JSON line: metric/value/... plus
-  roofline     : dominant kernel = the Winograd F(2x2,3x3) conv on the f32 matrix cores.  `achieved` = the matrix-core FLOP the
-                 kernel's algorithm EXECUTES per launch (16 multiply-adds per output 2x2 tile, channel pair and tile: 16/36 of the
-                 direct form) / average launch duration (HIP events on the launch stream, a second single-stream eager pass over
-                 the same K steps); `peak` = 157.3 TFLOP/s f32 MFMA (MI355X_MICROARCH.md); `frac` = achieved / peak = the share of
-                 the matrix pipe in use.  `effective_tflops` is the direct-form rate (x `algorithmic_speedup` 2.25), `step_frac` the
-                 executed conv FLOP of a whole step / ms_per_step / peak.  `traffic` comes from a rocprofv3 --pmc pass stored under
+  roofline     : dominant kernel = the Winograd conv with the larger share of the step (F(4x4,3x3) conv_wino4_kernel at the
+                 default workload; `kernels` lists both).  `achieved` = the matrix-core FLOP the kernel's algorithm EXECUTES per
+                 launch (36 multiply-adds per 4x4 output tile and channel pair = 1/4 of the direct form; F(2x2,3x3): 16/36) /
+                 average launch duration (HIP events on the launch stream, a second single-stream eager pass over the same K
+                 steps); `peak` = 157.3 TFLOP/s f32 MFMA (MI355X_MICROARCH.md); `frac` = achieved / peak = the share of the matrix
+                 pipe in use.  `effective_tflops` is the direct-form rate (x `algorithmic_speedup`), `step_frac` the executed
+                 conv FLOP of a whole step / ms_per_step / peak.  `traffic` comes from a rocprofv3 --pmc pass stored under
                  profiles/ together with a hash of the kernel sources; a stale file (sources changed since) is not reported.
   cpu_baseline : the oracle (plain PyTorch fp32 restatement of the same step) on the host cores, at the named batch when one
                  step fits the time budget (else a stated fraction of the batch), 1 warm + >= 1 timed step.
@@ -185,7 +186,7 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic():
+def pmc_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the newest profiles/r*/pmc_traffic.json (written by scripts/pmc_traffic.py
     from separate rocprofv3 --pmc passes of this command).  Reported only if the file was measured on the same kernel sources."""
     import glob
@@ -195,6 +196,8 @@ def pmc_traffic():
     try:
         with open(cands[-1]) as f:
             pmc = json.load(f)
+        if pmc.get("kernel") not in kernel:
+            return {"traffic": None, "traffic_note": "stored PMC pass (%s) is of %s, not of the dominant kernel" % (os.path.relpath(cands[-1], ROOT), pmc.get("kernel"))}
         if pmc.get("kernel_source_hash") != kernel_source_hash():
             return {"traffic": None, "traffic_note": "stored PMC pass (%s) is stale: kernel sources changed since (%s != %s)"
                     % (os.path.relpath(cands[-1], ROOT), pmc.get("kernel_source_hash"), kernel_source_hash())}
@@ -430,30 +433,46 @@ def main():
         launches_per_step = (lib.idiff_launch_count() - n0) / args.steps
         torch.cuda.synchronize()
         sde.two_streams = two
-        # dominant kernel = conv_wino_kernel: every 3x3 conv whose shape tiles exactly (idiff_conv2d_last_algo() == 1)
-        recs = [r for r in ops.PROFILE if r['algo'] == 1]
+        # The 3x3 convs run on two Winograd kernels (idiff_conv2d_last_algo(): 3 = F(4x4,3x3) conv_wino4_kernel, 1 = F(2x2,3x3)
+        # conv_wino_kernel); the dominant kernel is the one with the larger share of the step.  "Executed" FLOP = what the
+        # algorithm puts on the matrix pipe: 36 multiply-adds per 4x4 output tile (1/4 of the direct form's 144) resp. 16 per 2x2
+        # tile (16/36 of 36).
         allrecs = ops.PROFILE
         ops.PROFILE = None
-        WINO = 16.0 / 36.0  # F(2x2,3x3): 16 multiply-adds where the direct form does 36
-        tot_ms = sum(r['e0'].elapsed_time(r['e1']) for r in recs)
-        tot_fl = sum(r['flops'] for r in recs)  # direct-form count 2*Cin*Cout*9*H*W*B
+        KERN = {3: ("conv_wino4_kernel (3x3 conv, Winograd F(4x4,3x3) on f32 MFMA)", 36.0 / 144.0, 4.0),
+                1: ("conv_wino_kernel (3x3 conv, Winograd F(2x2,3x3) on f32 MFMA)", 16.0 / 36.0, 2.25)}
+        groups = {}
+        for algo, (name, factor, speedup) in KERN.items():
+            recs = [r for r in allrecs if r['algo'] == algo]
+            if not recs:
+                continue
+            ms = sum(r['e0'].elapsed_time(r['e1']) for r in recs)
+            fl = sum(r['flops'] for r in recs)  # direct-form count 2*Cin*Cout*9*H*W*B
+            eff = fl / (ms * 1e-3) / 1e12
+            groups[algo] = {"kernel": name, "launches_per_step": len(recs) / args.steps, "ms_per_step_single_stream": round(ms / args.steps, 3),
+                            "avg_launch_ms": round(ms / len(recs), 4), "executed_share_of_direct": round(factor, 4),
+                            "algorithmic_speedup": speedup, "effective_tflops": round(eff, 2), "achieved": round(eff * factor, 2),
+                            "frac": round(eff * factor / F32_MFMA_PEAK_TFLOPS, 4),
+                            "executed_gflop_per_launch": round(fl * factor / len(recs) / 1e9, 3), "_fl": fl, "_ms": ms}
         all_ms = sum(r['e0'].elapsed_time(r['e1']) for r in allrecs)
         all_fl = sum(r['flops'] for r in allrecs)
-        exec_fl_step = (tot_fl * WINO + (all_fl - tot_fl)) / args.steps  # matrix-core FLOP one step really executes (all convs)
-        eff = tot_fl / (tot_ms * 1e-3) / 1e12
-        ach = eff * WINO
-        roof = {"bound": "mfma", "kernel": "conv_wino_kernel (3x3 conv, Winograd F(2x2,3x3) on f32 MFMA)", "achieved": round(ach, 2),
-                "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                "flop_count": "executed = 16/36 of the direct-form 2*Cin*Cout*9*H*W*B per launch (Winograd F(2x2,3x3))",
-                "algorithmic_speedup": 2.25, "effective_tflops": round(eff, 2),
+        wino_fl = sum(g["_fl"] for g in groups.values())
+        exec_fl_step = (sum(g["_fl"] * KERN[a][1] for a, g in groups.items()) + (all_fl - wino_fl)) / args.steps  # all convs
+        dom = max(groups, key=lambda a: groups[a]["_ms"])
+        d = groups[dom]
+        roof = {"bound": "mfma", "kernel": d["kernel"], "achieved": d["achieved"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": d["frac"], "traffic": None,
+                "flop_count": "executed = %.4f of the direct-form 2*Cin*Cout*9*H*W*B per launch" % KERN[dom][1],
+                "algorithmic_speedup": d["algorithmic_speedup"], "effective_tflops": d["effective_tflops"],
                 "step_frac": round(exec_fl_step / (el / args.steps) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
                 "step_executed_gflop": round(exec_fl_step / 1e9, 1),
-                "launches": len(recs), "avg_launch_ms": round(tot_ms / max(len(recs), 1), 4),
-                "executed_gflop_per_launch": round(tot_fl * WINO / max(len(recs), 1) / 1e9, 3),
+                "launches": int(d["launches_per_step"] * args.steps), "avg_launch_ms": d["avg_launch_ms"],
+                "executed_gflop_per_launch": d["executed_gflop_per_launch"],
                 "conv_ms_per_step_single_stream": round(all_ms / args.steps, 3),
-                "wino_ms_per_step_single_stream": round(tot_ms / args.steps, 3),
-                "step_conv_gflop_direct_form": round(all_fl / args.steps / 1e9, 1)}
-        roof.update(pmc_traffic())
+                "wino_ms_per_step_single_stream": round(sum(g["_ms"] for g in groups.values()) / args.steps, 3),
+                "step_conv_gflop_direct_form": round(all_fl / args.steps / 1e9, 1),
+                "kernels": [{k: v for k, v in groups[a].items() if not k.startswith("_")} for a in sorted(groups, key=lambda a: -groups[a]["_ms"])]}
+        roof.update(pmc_traffic(d["kernel"]))
     if world > 1:
         barrier()
 

@@ -4,7 +4,7 @@
 #   the steady-state step table, and the PMC traffic of the dominant kernel (separate FETCH_SIZE / WRITE_SIZE passes).
 set -u
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r02; mkdir -p $O
+O=${1:-gpurun_out/r02}; mkdir -p $O
 python3 bench.py > $O/a_bench_headline.json 2> $O/a_bench_headline.err; echo "headline done" 
 python3 bench.py --size 224 --batch 16 --no-cpu-baseline > $O/b_bench_224.json 2>/dev/null
 python3 bench.py --size 512 --batch 8 --steps 5 --warmup 2 --no-cpu-baseline > $O/c_bench_512_b8.json 2>/dev/null

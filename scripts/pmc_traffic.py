@@ -40,7 +40,7 @@ def per_launch(dirname, counter, needle):
 
 def main():
     fdir, wdir, out = sys.argv[1:4]
-    needle = sys.argv[4] if len(sys.argv) > 4 else "conv_wino_kernel"
+    needle = sys.argv[4] if len(sys.argv) > 4 else "conv_wino4_kernel"
     from bench import kernel_source_hash
     fetch_kb, nf, names = per_launch(fdir, "FETCH_SIZE", needle)
     write_kb, nw, _ = per_launch(wdir, "WRITE_SIZE", needle)
