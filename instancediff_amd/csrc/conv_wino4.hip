@@ -91,6 +91,28 @@ __device__ __forceinline__ float row_sum16(float v) {
 #define TRACE_MARK(k)
 #define TRACE_FINI
 #endif
+#ifdef IDIFF_WINO_SLOTS  // with IDIFF_WINO_TRACE: per wave, cycles per chunk of the main loop spent working / waiting at the barrier
+#define SLOT_INIT long long sl_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sl_t = 0;
+#define SLOT_START sl_t = __builtin_readcyclecounter();
+#define SLOT_MARK(k)                                        \
+    {                                                       \
+        const long long t_ = __builtin_readcyclecounter();  \
+        sl_acc[k] += t_ - sl_t;                             \
+        sl_t = t_;                                          \
+    }
+#define SLOT_FINI                                                                                                                   \
+    if (lane == 0) {                                                                                                                \
+        long long w_ = 0;                                                                                                           \
+        for (int q_ = 0; q_ < 9; ++q_) w_ += sl_acc[q_];                                                                            \
+        atomicAdd((unsigned long long*)trace + 8 + 2 * wave, (unsigned long long)w_);                                               \
+        atomicAdd((unsigned long long*)trace + 9 + 2 * wave, (unsigned long long)sl_acc[9]);                                        \
+    }
+#else
+#define SLOT_INIT
+#define SLOT_START
+#define SLOT_MARK(k)
+#define SLOT_FINI
+#endif
 
 // A wave-uniform pointer pinned to scalar registers.  Under register pressure the compiler may keep a uniform 64-bit address in
 // vector registers; a buffer resource built from it then costs a waterfall loop (readfirstlane + compare + exec masking) around
@@ -355,6 +377,7 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
     else load_u(0, std::false_type{});
     fetch_consts();
     TRACE_INIT
+    SLOT_INIT
 
     for (int item = first; item < last; item += G) {
         const int b = it_b, co0 = it_co0, y0 = it_y0, x0 = it_x0;  // the epilogue's view of this item
@@ -393,6 +416,9 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
             //   stage raw(c+2) registers -> R[c&1], then load raw(c+4) into them;  stage U(c+1) -> U[(c+1)&1], then load U(c+2);
             //   transform R[(c+1)&1] (staged one iteration ago) -> V[(c+1)&1].
             const int opoff = lane * 4;
+            floatx4 ob[2], oa[2];
+            ob[0] = *reinterpret_cast<const floatx4*>(Vb + tblk * 256 + opoff);  // quad 0 of chunk 0
+            oa[0] = *reinterpret_cast<const floatx4*>(Ub + cb * 256 + opoff);
             const bool have_next = item + G < last;
             auto chunk = [&](int cc, auto par_tag, auto more_tag) {
                 constexpr int PAR = decltype(par_tag)::value;      // cc & 1: LDS buffers and the raw register set
@@ -402,16 +428,31 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
                 float(&rin)[NL] = PAR ? rinB : rinA;
                 Pro pro;
                 if (MORE) pro = load_pro(b, clampc(cc + 2));  // the affine of the chunk staged below
-                floatx4 ob[2], oa[2];
-                ob[0] = *reinterpret_cast<const floatx4*>(V);
-                oa[0] = *reinterpret_cast<const floatx4*>(U);
+                // Operand quads alternate between two register sets; the parity flips from chunk to chunk (9 quads), so quad 8 of
+                // this chunk and quad 0 of the next never share a set: the next chunk's first operands are requested right after
+                // the barrier and arrive while the four MFMAs of this chunk's last quad run.
+                const float* Vn = Vb + (PAR ^ 1) * V_FLOATS + tblk * 256 + opoff;
+                const float* Un = Ub + (PAR ^ 1) * U_FLOATS + cb * 256 + opoff;
+                if (MORE) { SLOT_START }
 #pragma unroll
                 for (int q = 0; q < 9; ++q) {
                     if (q + 1 < 9) {
-                        ob[(q + 1) & 1] = *reinterpret_cast<const floatx4*>(V + (q + 1) * 512);
-                        oa[(q + 1) & 1] = *reinterpret_cast<const floatx4*>(U + (q + 1) * 1024);
+                        ob[(q + 1 + PAR) & 1] = *reinterpret_cast<const floatx4*>(V + (q + 1) * 512);
+                        oa[(q + 1 + PAR) & 1] = *reinterpret_cast<const floatx4*>(U + (q + 1) * 1024);
+                    } else if (MORE) {
+#ifndef W4_NO_RAW
+#ifndef W4_NO_RAWLOAD
+                        load_raw(rin, clampc(cc + 4));
+#endif
+#endif
+                        __builtin_amdgcn_sched_barrier(0);
+                        SLOT_MARK(8)
+                        __syncthreads();
+                        SLOT_MARK(9)
+                        ob[PAR ^ 1] = *reinterpret_cast<const floatx4*>(Vn);
+                        oa[PAR ^ 1] = *reinterpret_cast<const floatx4*>(Un);
                     }
-                    const floatx4 bv = ob[q & 1], av = oa[q & 1];
+                    const floatx4 bv = ob[(q + PAR) & 1], av = oa[(q + PAR) & 1];
                     acc[4 * q + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[4 * q + 0], 0, 0, 0);
                     acc[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[4 * q + 1], 0, 0, 0);
                     acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[4 * q + 2], 0, 0, 0);
@@ -431,21 +472,9 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
                         if (q == 5) stage_raw(rin, 0, pro, PAR, hv), stage_raw(rin, 1, pro, PAR, hv);
                         if (q == 6) stage_raw(rin, 2, pro, PAR, hv), stage_raw(rin, 3, pro, PAR, hv);
                         if (q == 7) stage_raw(rin, 4, pro, PAR, hv), stage_raw(rin, 5, pro, PAR, hv);
-#ifndef W4_NO_RAWLOAD
-                        if (q == 8) load_raw(rin, clampc(cc + 4));
-#endif
-#endif
-#ifdef W4_SGB
-                        // within the slot: operand prefetch first, then the side work dealt out behind each of the four MFMAs
-                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x096, W4_SGB, 0);
-                        }
 #endif
                         __builtin_amdgcn_sched_barrier(0);
-                        if (q == 8) __syncthreads();
+                        if (q < 8) { SLOT_MARK(q) }
                     } else if (have_next) {
                         // Nothing is staged in the last chunk, so the item state is free: switch it to the next item between the
                         // MFMAs and let its first patches and weights travel during the rest of the chunk and the epilogue.
@@ -552,6 +581,7 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
         TRACE_MARK(8)
     }
     TRACE_FINI
+    SLOT_FINI
 }
 
 template <int MODE, int SPEC, bool RAG>
@@ -583,14 +613,22 @@ int launch_rag(const ConvArgs& a, hipStream_t st) {
     const int grid = (g.total + per - 1) / per;
 #ifdef IDIFF_WINO_TRACE
     static long long* tr = nullptr;
-    if (!tr) (void)hipMalloc(&tr, 8 * sizeof(long long));
-    (void)hipMemsetAsync(tr, 0, 8 * sizeof(long long), st);
+    if (!tr) (void)hipMalloc(&tr, 32 * sizeof(long long));
+    (void)hipMemsetAsync(tr, 0, 32 * sizeof(long long), st);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, a, g, tr);
-    long long h[8];
+    long long h[32];
     (void)hipMemcpyAsync(h, tr, sizeof(h), hipMemcpyDeviceToHost, st);
     (void)hipStreamSynchronize(st);
     fprintf(stderr, "[wino4 trace] Cin=%d Cout=%d H=%d items=%d per=%d | topbar %lld stage %lld bar2 %lld tr+bar3 %lld loop %lld epi1 %lld epi2 %lld (cycles/item, wave 0)\n",
             a.Cin, a.Cout, a.Hout, g.total, per, h[0] / g.total, h[1] / g.total, h[2] / g.total, h[3] / g.total, h[4] / g.total, h[5] / g.total, h[6] / g.total);
+#ifdef IDIFF_WINO_SLOTS
+    {
+        const long long nch = (long long)g.total * (a.Cin / CK - 1);  // staged chunks
+        fprintf(stderr, "[wino4 slots] Cin=%d H=%d work/barrier-wait cycles per chunk, waves 0..7:", a.Cin, a.Hout);
+        for (int w = 0; w < 8; ++w) fprintf(stderr, " %lld/%lld", h[8 + 2 * w] / nch, h[9 + 2 * w] / nch);
+        fprintf(stderr, "\n");
+    }
+#endif
 #else
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, a, g);
 #endif
