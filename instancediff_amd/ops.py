@@ -56,6 +56,8 @@ def _c(t, name="tensor", dtype=torch.float32):
 WINOGRAD = bool(int(os.environ.get("IDIFF_WINOGRAD", "1")))
 # IDIFF_WINOGRAD4=0 keeps the forward 3x3 convs off the F(4x4,3x3) kernel (they run F(2x2,3x3) or direct instead)
 WINOGRAD4 = WINOGRAD and bool(int(os.environ.get("IDIFF_WINOGRAD4", "1")))
+# IDIFF_WINOGRAD4_DGRAD=0 keeps the data-gradient convs of the backward pass on F(2x2,3x3)
+WINOGRAD4_DGRAD = bool(int(os.environ.get("IDIFF_WINOGRAD4_DGRAD", "1")))
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -73,9 +75,9 @@ def pack_conv_weight(w, transpose=False):
         wino = torch.empty((16 * kconv * ((cconv + 63) // 64) * 64,), device=w.device, dtype=torch.float32)
         check(lib.idiff_pack_conv_weight_wino(_p(w), _p(wino), co, ci, 1 if transpose else 0, _stream()), "pack_conv_weight_wino")
         out.wino = wino
-        if WINOGRAD4 and not transpose:  # forward convs only: the data-gradient convs stay on F(2x2,3x3)
+        if WINOGRAD4 and (WINOGRAD4_DGRAD or not transpose):
             wino4 = torch.empty((36 * kconv * ((cconv + 63) // 64) * 64,), device=w.device, dtype=torch.float32)
-            check(lib.idiff_pack_conv_weight_wino4(_p(w), _p(wino4), co, ci, 0, _stream()), "pack_conv_weight_wino4")
+            check(lib.idiff_pack_conv_weight_wino4(_p(w), _p(wino4), co, ci, 1 if transpose else 0, _stream()), "pack_conv_weight_wino4")
             out.wino4 = wino4
     return out
 

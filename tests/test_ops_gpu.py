@@ -314,7 +314,7 @@ def _pack(w, wino, transpose=False, wino4=False):
         p = ops.pack_conv_weight(w, transpose=transpose)
     finally:
         ops.WINOGRAD, ops.WINOGRAD4 = old, old4
-    assert hasattr(p, "wino") == wino and hasattr(p, "wino4") == (wino4 and not transpose)
+    assert hasattr(p, "wino") == wino and hasattr(p, "wino4") == wino4
     return p
 
 
@@ -396,6 +396,14 @@ def test_conv_winograd_data_gradient_pack():
     dx_d = ops.conv2d(dy.to(DEV), _pack(wd, False, transpose=True), None, 3, Cin)
     _close(dx_d, ref, 2e-6, "direct dgrad")
     _close(dx_w, ref, 6e-6, "winograd dgrad")
+    lib = ops._lib.load()
+    old = lib.idiff_conv_wino4_min_items(1)
+    try:
+        dx_4 = ops.conv2d(dy.to(DEV), _pack(wd, True, transpose=True, wino4=True), None, 3, Cin)
+        assert lib.idiff_conv2d_last_algo() == 3
+    finally:
+        lib.idiff_conv_wino4_min_items(old)
+    _close(dx_4, ref, 4e-5, "winograd4 dgrad")
 
 
 def test_conv_winograd_random_shapes_match_direct():
