@@ -572,7 +572,11 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
                         v.x += silu_fast(aa * caux.x + ab), v.y += silu_fast(aa * caux.y + ab);
                         v.z += silu_fast(aa * caux.z + ab), v.w += silu_fast(aa * caux.w + ab);
                     }
+#ifdef W4_NO_STORE  // diagnostic: keeps the arithmetic alive, stores (almost) nothing
+                    if (inside && v.x == 12345.678f) *reinterpret_cast<floatx4*>(outb + ((long long)r * HWo + dy * a.Wout) + lane_off) = v;
+#else
                     if (inside) *reinterpret_cast<floatx4*>(outb + ((long long)r * HWo + dy * a.Wout) + lane_off) = v;
+#endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
