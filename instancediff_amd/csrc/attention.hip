@@ -480,9 +480,13 @@ __global__ __launch_bounds__(256) void smm_xattn_combine_kernel(const float* __r
     if (row >= rows) return;
     const long long ss = (long long)(XCM + 2) * 32;  // floats per split
     const float* wb = ws + (long long)b * nsplit * ss;
+    // the splits are walked in a fixed order (a sample's bits do not depend on who computed what when); eight splits' loads are
+    // in flight at a time -- the kernel is pure load latency
     float M = -INFINITY;
+#pragma unroll 8
     for (int s = 0; s < nsplit; ++s) M = fmaxf(M, wb[s * ss + XCM * 32 + row]);
     float L = 0.f, acc = 0.f;
+#pragma unroll 8
     for (int s = 0; s < nsplit; ++s) {
         const float* w = wb + s * ss;
         const float ms = w[XCM * 32 + row];

@@ -32,7 +32,7 @@ def per_launch(dirname, counter, needle):
                 if row["Counter_Name"] == counter and needle in row["Kernel_Name"]:
                     tot += float(row["Counter_Value"])
                     n += 1
-                    names.add(row["Kernel_Name"].split("(")[0][:80])
+                    names.add(row["Kernel_Name"].replace("void (anonymous namespace)::", "").split("(")[0][:80])
     if n == 0:
         raise SystemExit(f"no {counter} rows for kernels matching {needle!r} in {files}")
     return tot / n, n, sorted(names)
