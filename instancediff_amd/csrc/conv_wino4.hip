@@ -157,8 +157,7 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 15;   // tile within the 16-tile block (B operand / C column); co row within a 16-block (A operand)
-    const int k4 = lane >> 4;  // k index of the operands / row group of the C layout
+    const int k4 = lane >> 4;  // k index of the MFMA operands (lane & 15: tile of the B operand / channel of the A operand)
     const int cb = wave & 3;   // MFMA role: 16-channel block
     const int tblk = wave >> 2;  // MFMA role: upper / lower 8x32 half-patch
     const int HWin = a.Hin * a.Win;
@@ -501,6 +500,12 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
         // ---- epilogue: in-lane output transform A^T m A, then the conv_igemm epilogue contract ---------------------------
         // C layout of 16x16x4: lane holds column j (tile) and rows 4*k4 + r (channels) of the wave's 16-channel block
         if (co0 + cb * 16 < a.Cout) {  // uniform: a 16-channel block beyond a partial Cout has nothing to store
+            // lane-derived constants are recomputed here from an opaque copy of the lane id: hoisted out of the item loop they
+            // would be spilled (the main loop has no register to spare) and reloaded through the same in-order vmcnt queue as
+            // the output stores
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));
+            const int j = lane_e & 15, k4 = lane_e >> 4;
             const int HWo = a.Hout * a.Wout;
             const int ty0 = y0 + 8 * tblk;  // first row of the wave's half-patch
             const long long wave_org = (long long)(co0 + cb * 16) * HWo + (long long)ty0 * a.Wout + x0;
