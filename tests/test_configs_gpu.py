@@ -241,13 +241,13 @@ def test_full_1000_step_chain_vs_oracle():
     noises = torch.randn((T,) + tuple(batch['input'].shape), generator=g)
     out = _chain(model, batch, x_T, noises)
     ref = _oracle_chain(model, T, batch, x_T, noises)
-    _check_vs_oracle(out, ref, batch['target'], "1000-step chain 64x64")
+    _check_vs_oracle(out, ref, batch['target'], "1000-step chain 32x32")
 
 
 def test_native_224_chain_vs_oracle_on_the_winograd_path():
     """The reference's native resolution (data/MedSpeckle.py:44-45, drift_noise_model.py:234): 224 = 7 x 32, lower levels 112 / 56 /
-    28 are not multiples of the 8x32 patch.  All four levels run on the Winograd kernel with masked partial patches (28x28 is one
-    patch column wide); chain parity against the oracle, B=2 batch invariance."""
+    28 are not multiples of the 8x32 / 16x32 patches.  All four levels run on the Winograd kernels with masked partial patches (224 /
+    112 / 56 on F(4x4,3x3), 28x28 -- one patch column wide -- on F(2x2,3x3)); chain parity against the oracle, B=2 batch invariance."""
     T, H = 2, 224
     model, sde = pipeline.build(phase="test", device=torch.device(DEV), T=T, seed=0)
     model.set_eval()
