@@ -464,6 +464,10 @@ def main():
                 "frac": d["frac"], "traffic": None,
                 "flop_count": "executed = %.4f of the direct-form 2*Cin*Cout*9*H*W*B per launch" % KERN[dom][1],
                 "algorithmic_speedup": d["algorithmic_speedup"], "effective_tflops": d["effective_tflops"],
+                "frac_of_direct_form_roofline": round(d["effective_tflops"] / F32_MFMA_PEAK_TFLOPS, 4),
+                "frac_note": "frac counts only the multiply-adds the Winograd algorithm executes (1/4 of the direct form for F(4x4,3x3), "
+                             "16/36 for the F(2x2,3x3) kernel that was dominant in round 1 at frac 0.62): frac x algorithmic_speedup is the "
+                             "like-for-like throughput (r01: 0.62 x 2.25 = 1.40, now frac_of_direct_form_roofline)",
                 "step_frac": round(exec_fl_step / (el / args.steps) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
                 "step_executed_gflop": round(exec_fl_step / 1e9, 1),
                 "launches": int(d["launches_per_step"] * args.steps), "avg_launch_ms": d["avg_launch_ms"],
