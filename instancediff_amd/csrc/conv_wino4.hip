@@ -525,8 +525,12 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
 #pragma unroll
             for (int u = 0; u < 6; ++u) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r) {
                     at6(acc[pos(u, 0)][r], acc[pos(u, 1)][r], acc[pos(u, 2)][r], acc[pos(u, 3)][r], acc[pos(u, 4)][r], acc[pos(u, 5)][r], zz[u][r]);
+                    // pinned here: left alone, the optimiser sinks these sums to their uses in phase 2 and keeps the accumulators --
+                    // spilled -- until then, reloading them through the same in-order vmcnt queue as the output stores
+                    asm volatile("" : "+v"(zz[u][r][0]), "+v"(zz[u][r][1]), "+v"(zz[u][r][2]), "+v"(zz[u][r][3]));
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             TRACE_MARK(6)
