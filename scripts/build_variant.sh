@@ -6,7 +6,10 @@ NAME=$1; SRC=$2; shift 2
 CS=/root/repo/instancediff_amd/csrc
 OBJ=$(basename "$SRC" .hip).o
 mkdir -p /root/repo/instancediff_amd/variants /tmp/variants/$NAME
+# the copy is compiled from the sources' directory (relative includes) and removed whatever the compiler says: a stray *.hip there
+# would be swept into the library by the Makefile's wildcard
 cp "$SRC" $CS/_variant_$NAME.hip
+trap 'rm -f $CS/_variant_$NAME.hip' EXIT
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wno-unused-function "$@" -c $CS/_variant_$NAME.hip -o /tmp/variants/$NAME/$OBJ
 rm -f $CS/_variant_$NAME.hip
 OBJS=$(ls $CS/*.o | grep -v "/$OBJ")
