@@ -545,3 +545,64 @@ def test_conv_winograd4_policy_and_fallback():
     out = ops.conv2d(big, wpk, None, 3, 64)
     assert lib.idiff_conv2d_last_algo() == 3
     _close(out, F.conv2d(big.double().cpu(), w.double().cpu(), padding=1), 4e-5, "winograd4 128x128")
+
+
+def test_conv_winograd4_random_shapes_match_direct(force_wino4):
+    """Seeded sweep over the F(4x4,3x3) kernel's eligibility lattice (channel blocks incl. partial ones, whole and partial 16x32
+    patches, one to many items per workgroup, gather variants, epilogue terms): it must agree with the direct kernel everywhere."""
+    lib = force_wino4
+    rng = np.random.RandomState(17)
+    for case in range(28):
+        B = int(rng.randint(1, 6))
+        C0 = 8 * int(rng.randint(1, 13))
+        two = bool(rng.randint(0, 2)) and case % 3 == 1
+        C1 = 4 * int(rng.randint(1, 9)) if two else 0
+        if (C0 + C1) % 8:
+            C1 += 4
+        Cout = 16 * int(rng.randint(1, 13))
+        H = 4 * int(rng.randint(1, 13))
+        W = 4 * int(rng.randint(6, 25))
+        up = (not two) and case % 7 == 3
+        pro = (not two) and (not up) and case % 3 == 2
+        g = _g(300 + case)
+        x0 = torch.randn(B, C0, H, W, generator=g).to(DEV)
+        x1 = torch.randn(B, C1, H, W, generator=g).to(DEV) if two else None
+        w = (torch.randn(Cout, C0 + C1, 3, 3, generator=g) / math.sqrt(9 * (C0 + C1))).to(DEV)
+        bias = torch.randn(Cout, generator=g).to(DEV)
+        Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+        kw = {}
+        if up:
+            kw["mode"] = ops.CONV_UPSAMPLE2
+        if pro:
+            kw["pro"] = (torch.randn(B, C0, generator=g).to(DEV), torch.randn(B, C0, generator=g).to(DEV))
+        if case % 2:
+            kw["res"] = torch.randn(B, Cout, Ho, Wo, generator=g).to(DEV)
+            kw["vec"] = torch.randn(B, Cout, generator=g).to(DEV)
+        if case % 4 == 0:
+            kw["aux"] = (torch.randn(B, Cout, Ho, Wo, generator=g).to(DEV), torch.randn(B, Cout, generator=g).to(DEV), torch.randn(B, Cout, generator=g).to(DEV))
+        tag = f"case {case}: B={B} C0={C0} C1={C1} Cout={Cout} H={H} W={W} up={up} pro={pro}"
+        ow, sw = ops.conv2d(x0, _pack(w, True, wino4=True), bias, 3, Cout, src1=x1, want_stats=True, **kw)
+        assert lib.idiff_conv2d_last_algo() == 3, tag
+        od, sd = ops.conv2d(x0, _pack(w, False), bias, 3, Cout, src1=x1, want_stats=True, **kw)
+        assert lib.idiff_conv2d_last_algo() == 0, tag
+        _close(ow, od.cpu(), 4e-5, tag)
+        _close(sw, sd.cpu(), 1e-4, tag + " stats")
+
+
+def test_conv_winograd4_bits_do_not_depend_on_the_batch(force_wino4):
+    """A sample's result is the same bit pattern whether it is convolved alone or inside a batch (persistent items of several
+    samples per workgroup, item order, kernel choice): the property the B=16 / B=5 chain tests rest on, at op level."""
+    lib = force_wino4
+    g = _g(23)
+    B, C0, Cout, H, W = 5, 40, 80, 28, 56
+    x = torch.randn(B, C0, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cout, C0, 3, 3, generator=g) / math.sqrt(9 * C0)).to(DEV)
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    pro = (torch.randn(B, C0, generator=g).to(DEV), torch.randn(B, C0, generator=g).to(DEV))
+    wp = _pack(w, True, wino4=True)
+    full, st = ops.conv2d(x, wp, bias, 3, Cout, pro=pro, want_stats=True)
+    assert lib.idiff_conv2d_last_algo() == 3
+    for b in (0, 3, 4):
+        one, s1 = ops.conv2d(x[b:b + 1].contiguous(), wp, bias, 3, Cout, pro=(pro[0][b:b + 1].contiguous(), pro[1][b:b + 1].contiguous()), want_stats=True)
+        assert lib.idiff_conv2d_last_algo() == 3
+        assert torch.equal(one[0], full[b]) and torch.equal(s1[0], st[b]), b
