@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Headline benchmark: denoising steps/sec of the InstanceDiff sampling loop on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank/GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU.  Under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) the process IS
+a rank; started plainly (`python bench.py --gpus N`, the reference's one-command launch: README.md:35, trainUM.py:50-66) the parent
+-- before anything touches the GPU -- starts N fresh rank processes of itself with that environment, waits for them, and exits
+non-zero if any rank failed (spawn_ranks below; never os.exec*).  n_gpus in the line is the world size the process group reports.
 
 Workload (BASELINE.json configs[1]): 256x256 1-channel synthetic batch of 16, T=1000 reverse chain; one STEP =
 one reverse-loop iteration of CLIPDriftModel.test()/driftSDE.reverse_ddpm = 2 UNet forwards (drift_net +
@@ -25,6 +30,8 @@ Prints ONE JSON line: metric/value/... plus
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -47,7 +54,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=0, help="images per CPU-baseline step (0 = the full batch when one step "
                     "is estimated to fit --cpu-budget-s, else 4)")
-    ap.add_argument("--cpu-budget-s", type=float, default=75.0, help="time budget of the CPU-baseline leg (warm + timed steps)")
+    ap.add_argument("--cpu-budget-s", type=float, default=140.0, help="time budget of the CPU-baseline leg (warm + timed steps)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--attn", choices=["f32", "bf16"], default="f32", help="bf16 = REDUCED-PRECISION VARIANT line (self-attention "
                     "contractions on the bf16 matrix cores; BASELINE config c5): own metric label, PSNR delta vs the fp32 path stated")
@@ -56,6 +63,44 @@ def parse():
                     help="sample = headline denoising-steps/s metric (driftSDE: 2 UNet forwards + update per step); train = secondary "
                          "training-iterations/s line; irsde = secondary line for the IRSDE single-network loop (1 UNet forward + reverse_sde_step)")
     return ap.parse_args()
+
+
+def spawn_ranks(n, cmd, env=None, poll_s=0.2):
+    """Start `n` rank processes of `cmd` (a list), rank r with RANK = LOCAL_RANK = r, WORLD_SIZE = n and a rendezvous on
+    127.0.0.1 at a free port; stdout / stderr are inherited (rank 0 prints the JSON line).  Returns the exit code: 0 when every
+    rank exited 0; otherwise the first failing rank's code, after the ranks still running (which would wait for it at the next
+    barrier forever) have been terminated -- by the exact PIDs started here.  The caller must not have initialised the GPU."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ if env is None else env)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen(cmd, env=dict(base, RANK=str(r), LOCAL_RANK=str(r))))
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            time.sleep(poll_s)
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print("[bench] rank %d exited with code %d; stopping the other ranks" % (procs.index(p), code), file=sys.stderr, flush=True)
+                    for q in live:
+                        q.terminate()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+    return rc
 
 
 class StepRunner:
@@ -148,31 +193,34 @@ def cpu_baseline(args, batch_full):
             return sde_ref.drift_reverse_update(x, rd, rn, z, sde.a[t], sde.b[t], sde.c[t])
 
         x = one(x, args.T)  # warm
-        n, t0 = 0, time.time()
+        n, t0, per = 0, time.time(), []
         while True:
+            ts = time.time()
             x = one(x, args.T - 1 - n)
+            per.append(time.time() - ts)
             n += 1
             el = time.time() - t0
             if n >= nsteps or el + el / n > budget:
                 break
-        return el / n, n
+        return el / n, n, per
 
     t_start = time.time()
     log("cpu oracle built (%d threads); probing B=1" % ncores)
-    s1, _ = run(1, 1, 30.0)
+    s1, _, _ = run(1, 1, 30.0)
     bs = args.cpu_sample_batch or args.batch
-    est = s1 * bs * 2.0  # warm + one timed step at linear scaling (batch-16 convs thread better than B=1: an upper estimate)
+    est = s1 * bs * 3.0  # warm + two timed steps at linear scaling (batch-16 convs thread better than B=1: an upper estimate)
     if not args.cpu_sample_batch and est > args.cpu_budget_s:
         bs = min(4, args.batch)
     log("cpu: %.2f s/step at B=1; timing B=%d" % (s1, bs))
-    sec, n = run(bs, 2, max(args.cpu_budget_s - (time.time() - t_start), 5.0))
+    sec, n, per = run(bs, 3, max(args.cpu_budget_s - (time.time() - t_start), 5.0))
     sps = 1.0 / sec * bs / args.batch
-    sample = ("1 warm + %d timed step(s) of the oracle at batch %d of %d (%.2f s/step)" % (n, bs, args.batch, sec))
+    sample = ("1 warm + %d timed step(s) of the oracle at batch %d of %d (mean %.2f s/step, min %.2f, max %.2f)"
+              % (n, bs, args.batch, sec, min(per), max(per)))
     if bs < args.batch:
         sample += ", scaled by %d/%d" % (bs, args.batch)
     sample += "; B=1 probe %.2f s/step (B-scaling %.2fx per image vs B=1); torch %d threads" % (s1, (sec / bs) / s1, ncores)
     return {"value": round(sps, 5), "unit": "denoising steps/s (batch %d)" % args.batch, "cores": ncores, "kind": "port",
-            "batch_timed": bs, "sample": sample}
+            "batch_timed": bs, "steps_timed": n, "s_per_step": [round(v, 3) for v in per], "sample": sample}
 
 
 def kernel_source_hash():
@@ -353,7 +401,12 @@ def irsde_bench(args, world, rank, dev):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (no torch.cuda / HIP call has happened yet)
+        sys.exit(spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log("WORLD_SIZE=%d from the launcher overrides --gpus %d" % (world, args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -373,6 +426,7 @@ def main():
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        assert dist.get_world_size() == world
 
     from instancediff_amd import ops, pipeline
     from instancediff_amd.utils.synthetic import make_batch

@@ -82,6 +82,11 @@ typedef struct {
     const float* wwino4;    /* optional F(4x4,3x3)-domain copy (idiff_pack_conv_weight_wino4): preferred over wwino when
                                Hout % 4 == 0, Wout % 4 == 0, Wout >= 24, Cin % 8 == 0, Cout % 16 == 0 and a sample has at
                                least 16 items of 16x32 pixels x 64 channels (4x fewer matrix-core flops than direct) */
+    int32_t algo_request;   /* 0 = the library picks (by the layer's per-sample shape only, never by the batch); 1 + IDIFF_CONV_ALGO_x =
+                               run exactly that kernel or fail with IDIFF_E_ARG if the shape does not tile for it (a per-call
+                               request: profiling, parity tests of a kernel at small sizes; a request for the F(4x4,3x3) kernel
+                               waives its 16-items-per-sample threshold, nothing else); -(1 + IDIFF_CONV_ALGO_x) = prefer that
+                               kernel where the shape tiles for it, the library's own choice elsewhere */
 } idiff_conv_desc;
 
 int idiff_conv2d_num_tiles(int Hout, int Wout);
@@ -106,10 +111,9 @@ int idiff_pack_conv_weight_wino(const float* w, float* wwino, int Cout, int Cin,
  * [Cin/4][ceil(Cout/64)][9 position quads][4 co-blocks][4 k][16 co][4]  (36*Cin*ceil(Cout/64)*64 floats; Cin % 8 == 0,
  * Cout % 16 == 0: a partial last block is zero-filled) -- an opaque image, only idiff_conv2d_fwd reads it. */
 int idiff_pack_conv_weight_wino4(const float* w, float* wwino4, int Cout, int Cin, int transpose, idiff_stream_t stream);
-/* Layers with fewer than min_items items PER SAMPLE (16x32 pixels x 64 output channels each; default 16) stay on the
- * F(2x2,3x3) kernel; the batch size never enters the choice (a sample's bits do not depend on its batch).  Sets the
- * threshold when min_items > 0 and returns the previous value (process-wide; tests). */
-int idiff_conv_wino4_min_items(int min_items);
+/* Layers with fewer than 16 items PER SAMPLE (16x32 pixels x 64 output channels each) stay on the F(2x2,3x3) kernel; the batch
+ * size never enters the choice (a sample's bits do not depend on its batch).  There is no process-wide switch: a caller that
+ * wants another kernel for ONE call says so in idiff_conv_desc.algo_request. */
 
 /* ------------------------------------------------------------------------------------------------
  * GroupNorm (+FiLM) folded to a per-(sample,channel) affine, applied by the consumer kernel.
@@ -269,11 +273,12 @@ int idiff_drift_reverse_step(const float* x, const float* r_hat, const float* e_
 /* Graph-replayable drift step: all per-step scalars live in device memory, so ONE captured HIP graph of a denoising step
  * (two UNet forwards + this update + idiff_step_state_advance) replays for every t with no host input in between.
  *   state int32[3] = {t, Philox call count, step index of this run};  coef float[3][Tp1] = tables of (a_t, b_t, c_t);
- *   a, b, c = coef[.][t];  Philox offset = state[1]*nper;  z_base (optional, parity runs) [steps][n] indexed by state[2].
+ *   a, b, c = coef[.][t];  Philox offset = offset_base + state[1]*nper (offset_base: the counters this stream's earlier draws, of
+ *   whatever size, have consumed -- successive draws never share counters);  z_base (optional, parity runs) [steps][n] indexed by state[2].
  * In place:  x <- ((x - a*r_hat) - b*e_hat) + c*z ;  xa <- x - cond.   Same fp32 operation order as idiff_drift_reverse_step. */
 int idiff_drift_reverse_step_dev(float* x, const float* r_hat, const float* e_hat, const float* z_base, const float* cond,
                                  float* xa, int64_t n, const float* coef, int Tp1, const int32_t* state, uint64_t seed,
-                                 uint64_t nper, idiff_stream_t stream);
+                                 uint64_t nper, uint64_t offset_base, idiff_stream_t stream);
 /* t <- t-1 (back to T once t <= t_stop), both counters += 1, tdev[0..B) = (float)t   (the UNets' timestep input) */
 int idiff_step_state_advance(int32_t* state, float* tdev, int B, int T, int t_stop, idiff_stream_t stream);
 /* standard normals (Philox4x32-10, Box-Muller), element i uses counter (offset + i/4) lane i%4 */

@@ -31,6 +31,7 @@ class ConvDesc(C.Structure):
         ("stats", C.c_void_p),
         ("wwino", C.c_void_p),
         ("wwino4", C.c_void_p),
+        ("algo_request", C.c_int32),
     ]
 
 
@@ -49,7 +50,6 @@ SIGNATURES = {
     "idiff_pack_conv_weight_T": (I, [P, P, I, I, I, c_stream]),
     "idiff_pack_conv_weight_wino": (I, [P, P, I, I, I, c_stream]),
     "idiff_pack_conv_weight_wino4": (I, [P, P, I, I, I, c_stream]),
-    "idiff_conv_wino4_min_items": (I, [I]),
     "idiff_gn_finalize": (I, [P, I, I, I, I, I, P, P, P, I64, F, P, P, P, c_stream]),
     "idiff_affine_silu_add": (I, [P, I64, P, P, P, I64, P, P, I64, I, I, I, c_stream]),
     "idiff_linear_fwd": (I, [P, I64, P, I64, P, P, I64, P, P, I64, I, I, I, I, I, c_stream]),
@@ -73,7 +73,7 @@ SIGNATURES = {
     "idiff_irsde_reverse_step": (I, [P, P, P, P, P, I64, F, F, F, F, F, I, U64, U64, c_stream]),
     "idiff_irsde_map": (I, [I, P, P, P, P, F, P, I, I64, P, C.POINTER(C.c_float), U64, U64, c_stream]),
     "idiff_drift_reverse_step": (I, [P, P, P, P, P, P, P, I64, F, F, F, U64, U64, c_stream]),
-    "idiff_drift_reverse_step_dev": (I, [P, P, P, P, P, P, I64, P, I, P, U64, U64, c_stream]),
+    "idiff_drift_reverse_step_dev": (I, [P, P, P, P, P, P, I64, P, I, P, U64, U64, U64, c_stream]),
     "idiff_step_state_advance": (I, [P, P, I, I, I, c_stream]),
     "idiff_randn": (I, [P, I64, U64, U64, c_stream]),
     "idiff_philox_raw": (I, [P, I64, U64, U64, c_stream]),

@@ -1,6 +1,7 @@
 // Shared helpers for the idiff HIP kernels (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -8,7 +9,7 @@
 #include "../../include/idiff.h"
 
 extern thread_local char g_idiff_err[512];
-extern unsigned long long g_idiff_launches;  // kernel launches enqueued by this library (idiff_launch_count)
+extern std::atomic<unsigned long long> g_idiff_launches;  // kernel launches enqueued by this library, any host thread (idiff_launch_count)
 
 #define IDIFF_FAIL(code, ...)                                   \
     do {                                                        \
@@ -23,7 +24,7 @@ extern unsigned long long g_idiff_launches;  // kernel launches enqueued by this
 
 #define IDIFF_CHECK_LAUNCH(name)                                                               \
     do {                                                                                       \
-        ++g_idiff_launches;                                                                    \
+        g_idiff_launches.fetch_add(1, std::memory_order_relaxed);                              \
         hipError_t e__ = hipGetLastError();                                                    \
         if (e__ != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "%s: %s", name, hipGetErrorString(e__)); \
     } while (0)

@@ -40,7 +40,8 @@ int launch_conv_wino(const ConvArgs& a, int mode, hipStream_t st);
 
 // F(4x4,3x3) kernel (conv_wino4.hip): 3x3, H and W multiples of 4, Cin % 8 == 0, Cout % 16 == 0, at least one 16x32-pixel x
 // 64-channel item per CU; a.tiles_x / ntiles / ncob describe 8x32-pixel patches (the GroupNorm-partials grid) as above
-bool conv_wino4_eligible(const ConvArgs& a, int ks, int mode);
+// requested: the caller asked for this kernel by name (idiff_conv_desc.algo_request): the items-per-sample threshold is waived
+bool conv_wino4_eligible(const ConvArgs& a, int ks, int mode, bool requested = false);
 int launch_conv_wino4(const ConvArgs& a, int mode, hipStream_t st);
 
 }  // namespace idiff_detail

@@ -653,14 +653,20 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
     IDIFF_CHECK_ARG(total < (1ll << 31), "conv2d: grid too large");
     a.total_wg = (unsigned)total;
     hipStream_t st = (hipStream_t)stream;
-    if (idiff_detail::conv_wino4_eligible(a, d->ks, d->mode)) {
+    const bool hard = d->algo_request > 0;
+    const int req = (hard ? d->algo_request : -d->algo_request) - 1;  // -1: the library picks
+    IDIFF_CHECK_ARG(req == -1 || req == IDIFF_CONV_ALGO_DIRECT || req == IDIFF_CONV_ALGO_WINOGRAD || req == IDIFF_CONV_ALGO_WINOGRAD4,
+                    "conv2d: bad algo_request %d", d->algo_request);
+    if ((req == -1 || req == IDIFF_CONV_ALGO_WINOGRAD4) && idiff_detail::conv_wino4_eligible(a, d->ks, d->mode, req == IDIFF_CONV_ALGO_WINOGRAD4)) {
         g_last_algo = IDIFF_CONV_ALGO_WINOGRAD4;
         return idiff_detail::launch_conv_wino4(a, d->mode, st);
     }
-    if (idiff_detail::conv_wino_eligible(a, d->ks, d->mode)) {
+    IDIFF_CHECK_ARG(!hard || req != IDIFF_CONV_ALGO_WINOGRAD4, "conv2d: algo_request F(4x4,3x3) but the shape does not tile for it");
+    if ((req == -1 || req == IDIFF_CONV_ALGO_WINOGRAD || !hard) && req != IDIFF_CONV_ALGO_DIRECT && idiff_detail::conv_wino_eligible(a, d->ks, d->mode)) {
         g_last_algo = IDIFF_CONV_ALGO_WINOGRAD;
         return idiff_detail::launch_conv_wino(a, d->mode, st);
     }
+    IDIFF_CHECK_ARG(!hard || req != IDIFF_CONV_ALGO_WINOGRAD, "conv2d: algo_request F(2x2,3x3) but the shape does not tile for it");
     g_last_algo = IDIFF_CONV_ALGO_DIRECT;
     if (d->ks == 3) {
         if (d->mode == IDIFF_CONV_NORMAL) return dispatch_mb<3, 8, IDIFF_CONV_NORMAL>(a, twl, mb, vecw, st);

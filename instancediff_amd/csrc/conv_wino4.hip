@@ -711,15 +711,15 @@ int wino4_mode() {  // IDIFF_WINOGRAD4: 0 = never, 1 (default) = where eligible
 }
 // Small levels stay on the 8x32-patch F(2x2,3x3) kernel, whose items are half the size (fuller grid): the threshold is on the
 // items PER SAMPLE (16x32 pixels x 64 channels each), never on the batch -- which kernel serves a layer, and so every bit of
-// its result, must not depend on the batch a sample sits in.  idiff_conv_wino4_min_items overrides (tests).
-int g_min_items = 16;
+// its result, must not depend on the batch a sample sits in.  (A per-call idiff_conv_desc.algo_request waives it.)
+constexpr int MIN_ITEMS = 16;
 
 }  // namespace
 
 namespace idiff_detail {
 
-bool conv_wino4_eligible(const ConvArgs& a, int ks, int mode) {
-    if (ks != 3 || !a.wwino4 || wino4_mode() == 0) return false;
+bool conv_wino4_eligible(const ConvArgs& a, int ks, int mode, bool requested) {
+    if (ks != 3 || !a.wwino4 || (wino4_mode() == 0 && !requested)) return false;
     if (mode != IDIFF_CONV_NORMAL && mode != IDIFF_CONV_UPSAMPLE2) return false;
     if (a.Cout % 16 || a.Cin % 8 || a.C0v % CK || (a.Hout & 3) || (a.Wout & 3) || a.Wout < 24) return false;
     if ((long long)a.Cin * a.Hin * a.Win * 4 >= (1ll << 31)) return false;  // 32-bit byte offsets inside a sample
@@ -731,7 +731,7 @@ bool conv_wino4_eligible(const ConvArgs& a, int ks, int mode) {
     if ((a.obs & 3) || (a.res && (a.rbs & 3)) || (a.aux && (a.abs_ & 3))) return false;
     if ((reinterpret_cast<uintptr_t>(a.out) & 15) || (reinterpret_cast<uintptr_t>(a.res) & 15) || (reinterpret_cast<uintptr_t>(a.aux) & 15)) return false;
     const long long items = (long long)a.tiles_x * ((a.Hout + TH - 1) / TH) * a.ncob;  // per sample
-    if (items < g_min_items) return false;
+    if (items < MIN_ITEMS && !requested) return false;
     return true;
 }
 
@@ -747,12 +747,6 @@ int launch_conv_wino4(const ConvArgs& a, int mode, hipStream_t st) {
 }
 
 }  // namespace idiff_detail
-
-extern "C" int idiff_conv_wino4_min_items(int min_items) {
-    const int old = g_min_items;
-    if (min_items > 0) g_min_items = min_items;
-    return old;
-}
 
 extern "C" int idiff_pack_conv_weight_wino4(const float* w, float* wwino4, int Cout, int Cin, int transpose, idiff_stream_t stream) {
     IDIFF_CHECK_ARG(w && wwino4 && Cout > 0 && Cin > 0, "pack_conv_weight_wino4: bad args");

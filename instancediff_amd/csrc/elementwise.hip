@@ -7,9 +7,9 @@ typedef float floatx2 __attribute__((ext_vector_type(2)));
 thread_local char g_idiff_err[512] = "";
 
 extern "C" const char* idiff_last_error(void) { return g_idiff_err; }
-unsigned long long g_idiff_launches = 0;
+std::atomic<unsigned long long> g_idiff_launches{0};
 extern "C" int idiff_version(void) { return 3; }
-extern "C" int64_t idiff_launch_count(void) { return (int64_t)g_idiff_launches; }
+extern "C" int64_t idiff_launch_count(void) { return (int64_t)g_idiff_launches.load(std::memory_order_relaxed); }
 extern "C" int idiff_device_info(int* num_cu, int* wave_size, char* arch_name, int arch_name_len) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);

@@ -131,10 +131,10 @@ __global__ __launch_bounds__(256) void drift_step_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void drift_step_dev_kernel(float* x, const float* __restrict__ rh, const float* __restrict__ eh,
                                                              const float* __restrict__ zbase, const float* __restrict__ cond, float* xa, long long n,
                                                              const float* __restrict__ coef, int Tp1, const int* __restrict__ state, uint64_t seed,
-                                                             uint64_t nper) {
+                                                             uint64_t nper, uint64_t offset_base) {
     const int t = state[0];
     const float a = coef[t], b = coef[Tp1 + t], c = coef[2 * Tp1 + t];
-    const uint64_t offset = (uint64_t)(unsigned)state[1] * nper;
+    const uint64_t offset = offset_base + (uint64_t)(unsigned)state[1] * nper;
     const float* z = zbase ? zbase + (long long)state[2] * n : nullptr;
     const long long nv = (n + 3) / 4;
     for (long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x; v < nv; v += (long long)gridDim.x * blockDim.x) {
@@ -379,10 +379,10 @@ extern "C" int idiff_drift_reverse_step(const float* x, const float* r_hat, cons
 
 extern "C" int idiff_drift_reverse_step_dev(float* x, const float* r_hat, const float* e_hat, const float* z_base, const float* cond, float* xa,
                                             int64_t n, const float* coef, int Tp1, const int32_t* state, uint64_t seed, uint64_t nper,
-                                            idiff_stream_t stream) {
+                                            uint64_t offset_base, idiff_stream_t stream) {
     IDIFF_CHECK_ARG(x && r_hat && e_hat && cond && xa && coef && state && n > 0 && Tp1 > 1, "drift_reverse_step_dev: bad args");
     hipLaunchKernelGGL(drift_step_dev_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, r_hat, e_hat, z_base, cond, xa,
-                       (long long)n, coef, Tp1, state, seed, nper);
+                       (long long)n, coef, Tp1, state, seed, nper, offset_base);
     IDIFF_CHECK_LAUNCH("drift_reverse_step_dev");
     return IDIFF_OK;
 }

@@ -71,7 +71,8 @@ class driftSDE:
         self.drift_schedule = self._h_drift.to(device) if device is not None else self._h_drift
         self.noise_schedule = self._h_noise.to(device) if device is not None else self._h_noise
         self.seed = 0
-        self._calls = 0
+        self._calls = 0  # draws made
+        self._off = 0    # Philox counters consumed: draws of any mix of sizes use disjoint counter ranges
         self.two_streams = bool(int(os.environ.get("IDIFF_TWO_STREAMS", "1")))
         self.hip_graph = bool(int(os.environ.get("IDIFF_HIP_GRAPH", "1")))
         self._streams = None
@@ -84,10 +85,12 @@ class driftSDE:
     def set_seed(self, seed):
         self.seed = int(seed)
         self._calls = 0
+        self._off = 0
 
     def _randn_like(self, x):
-        off = self._calls * ((x.numel() + 3) // 4)
+        off = self._off
         self._calls += 1
+        self._off += (x.numel() + 3) // 4
         return ops.randn(x.shape, x.device, self.seed, off)
 
     # ---- training-state sampler -------------------------------------------------------------------
@@ -157,16 +160,17 @@ class driftSDE:
             t0 = sde.T if t_start is None else int(t_start)
             self.tdev = torch.full((x.shape[0],), float(t0), dtype=torch.float32, device=dev)
             self.coef = torch.stack([sde._a, sde._b, sde._c]).to(device=dev, dtype=torch.float32).contiguous()
-            self.state = torch.tensor([t0, sde._calls, 0], dtype=torch.int32, device=dev)
+            self.state = torch.tensor([t0, 0, 0], dtype=torch.int32, device=dev)  # {t, draws of this run, step index}
             self.noises = None if noises is None else noises.contiguous()
             self.nper = (x.numel() + 3) // 4
+            self.off_base = sde._off  # this run's draws start where the stream's earlier ones ended
             self.graph = None
             self.steps_done = 0
 
         def _body(self):
             sde = self.sde
             r_hat, e_hat = sde.predict(self.xa, self.x, self.cond, self.tdev, self.names, self.text_encoder, self.ctx)
-            ops.drift_reverse_step_dev(self.x, r_hat, e_hat, self.noises, self.cond, self.xa, self.coef, self.state, sde.seed, self.nper)
+            ops.drift_reverse_step_dev(self.x, r_hat, e_hat, self.noises, self.cond, self.xa, self.coef, self.state, sde.seed, self.nper, self.off_base)
             ops.step_state_advance(self.state, self.tdev, self.T, self.t_stop)
 
         def _warm_step(self):
@@ -203,6 +207,7 @@ class driftSDE:
             self._warm_step()
             self.steps_done += 1
             sde._calls += 1
+            sde._off += self.nper
             try:
                 self.graph = self._capture()
             except Exception as e:  # stay on the eager HIP path (same kernels), say why once
@@ -226,6 +231,7 @@ class driftSDE:
                     self._body()
             self.steps_done += nsteps
             sde._calls += nsteps
+            sde._off += nsteps * self.nper
             return self.x
 
         @property
@@ -241,6 +247,10 @@ class driftSDE:
         if optimize_type not in ("inputRes", "predict_noise", ""):
             raise NotImplementedError(f"optimize_type={optimize_type!r}: only the active 'inputRes' path of the reference "
                                       "(drift_noise_model.py:231-232) is in scope")
+        if "std" not in str(reverse_type):
+            # optimize_target (drift_noise_model.py:68,581-604): 'std*' nets predict LQ-GT and the standard noise, which is what
+            # the update consumes; 'scaled*' nets predict d_t*(LQ-GT) and s_t*eps and would need rescaling -- not silently ignored
+            raise NotImplementedError(f"reverse_type={reverse_type!r}: only the 'std' prediction targets of config.yml:144 are in scope")
         cond = cond.contiguous()
         B = cond.shape[0]
         if x_T is None:

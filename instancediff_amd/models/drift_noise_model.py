@@ -240,6 +240,27 @@ class CLIPDriftModel():
                  "optimizers": [self.drift_optimizer.state_dict(), self.noise_optimizer.state_dict()]}
         torch.save(state, os.path.join(save_dir, "{}.state".format(iter_step)))
 
+    @staticmethod
+    def load_training_state(path, trusted=False):
+        """Read a `{iter}.state` file (the call trainUM.py makes before resume_training).  This build's layout (state dicts) loads
+        under torch's `weights_only=True`.  The reference pickles the optimizer and scheduler OBJECTS (:694-704), which that mode
+        rejects (it cannot even rebuild Adam's defaultdict); they are read by an unpickler whose find_class admits exactly what such
+        a file holds -- torch.optim.Adam, CosineAnnealingLR, Parameter / tensor / storage rebuilders, defaultdict / OrderedDict --
+        and nothing that could run code.  A pickle holding anything else needs `trusted=True` (option path.resume_state_trusted),
+        i.e. the unrestricted unpickler the reference's torch 1.13 `torch.load` was."""
+        import pickle
+        try:
+            return torch.load(path, map_location="cpu", weights_only=True)
+        except pickle.UnpicklingError:
+            pass
+        try:
+            return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_restricted_pickle())
+        except pickle.UnpicklingError as e:
+            if not trusted:
+                raise RuntimeError(f"{path}: holds more than state dicts and pickled Adam / CosineAnnealingLR objects ({e}); set "
+                                   f"path.resume_state_trusted: true to unpickle it without restrictions") from e
+        return torch.load(path, map_location="cpu", weights_only=False)
+
     def resume_training(self, resume_state):
         """Both `.state` layouts resume: this build's (state dicts) and the reference's, which pickles the scheduler and optimizer
         OBJECTS (models/drift_noise_model.py:694-704; its own resume_training then swaps them in wholesale, :702-704 -- optimizers
@@ -274,6 +295,32 @@ class CLIPDriftModel():
             path = os.path.join(save_dir, f"lastest_{label}_ema.pth")
             if net is not None and os.path.exists(path):
                 self.load_network(path, net)
+
+
+def _restricted_pickle():
+    """a `pickle`-shaped module for torch.load(pickle_module=...) whose Unpickler resolves only the globals of a reference-era
+    `.state` file (see CLIPDriftModel.load_training_state)"""
+    import pickle
+    import types
+    allowed = {("collections", "OrderedDict"), ("collections", "defaultdict"), ("builtins", "dict"), ("builtins", "set"),
+               ("builtins", "list"), ("builtins", "tuple"), ("builtins", "int"), ("builtins", "float"), ("builtins", "bool"),
+               ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_parameter"), ("torch._utils", "_rebuild_parameter_with_state"),
+               ("torch._tensor", "_rebuild_from_type_v2"), ("torch.nn.parameter", "Parameter"), ("torch", "Size"), ("torch", "device"),
+               ("torch.storage", "UntypedStorage"), ("torch.serialization", "_get_layout"),
+               ("torch.optim.adam", "Adam"), ("torch.optim.lr_scheduler", "CosineAnnealingLR")}
+
+    class Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            key = ("builtins" if module == "__builtin__" else module, name)  # protocol-2 pickles (torch.save's default) say __builtin__
+            if key in allowed or (module == "torch" and name.endswith("Storage")):
+                return super().find_class(module, name)
+            raise pickle.UnpicklingError(f"global {module}.{name} is not on the .state allow-list")
+
+    mod = types.ModuleType("idiff_restricted_pickle")
+    mod.__dict__.update({k: getattr(pickle, k) for k in ("load", "loads", "dump", "dumps", "Pickler", "PickleError", "UnpicklingError",
+                                                         "HIGHEST_PROTOCOL", "DEFAULT_PROTOCOL")})
+    mod.Unpickler = Unpickler
+    return mod
 
 
 def create_CLIPDriftModel(train_opt, model_opt, phase='train', **extra):  # :758-810

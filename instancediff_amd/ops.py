@@ -1,8 +1,10 @@
 """Thin torch-tensor wrappers over the C ABI (include/idiff.h).  torch supplies device memory and the
 stream; every arithmetic operation below runs in the hand-written HIP kernels.  No fallbacks."""
+import contextlib
 import ctypes as C
 import math
 import os
+import threading
 
 import torch
 
@@ -15,6 +17,8 @@ SDE_STEP, SDE_MEAN, SDE_ODE = 0, 1, 2
 
 # bench.py sets this to a list to time every conv launch with events on the launch stream (roofline leg)
 PROFILE = None
+# tests set this to a collections.Counter: (algo, ks, Cin, Cout, Hout, Wout) -> calls, to assert which kernel served a layer
+ALGO_TRACE = None
 
 
 def _stream():
@@ -60,6 +64,23 @@ WINOGRAD4 = WINOGRAD and bool(int(os.environ.get("IDIFF_WINOGRAD4", "1")))
 WINOGRAD4_DGRAD = bool(int(os.environ.get("IDIFF_WINOGRAD4_DGRAD", "1")))
 
 
+CONV_ALGO_DIRECT, CONV_ALGO_WINOGRAD, CONV_ALGO_STREAM1X1, CONV_ALGO_WINOGRAD4 = 0, 1, 2, 3
+_ALGO_REQUEST = threading.local()
+
+
+@contextlib.contextmanager
+def request_conv3x3_algo(algo):
+    """Diagnostic / test scope (this thread only): every 3x3 conv2d() issued inside asks the library for `algo` through the per-call
+    idiff_conv_desc.algo_request where the layer's shape tiles for it, e.g. the F(4x4,3x3) kernel on the small levels of a 64x64
+    input (which the library's own choice leaves on F(2x2,3x3)).  The product path never enters this scope."""
+    old = getattr(_ALGO_REQUEST, "algo", None)
+    _ALGO_REQUEST.algo = algo
+    try:
+        yield
+    finally:
+        _ALGO_REQUEST.algo = old
+
+
 # ---------------------------------------------------------------------------------------------------
 def pack_conv_weight(w, transpose=False):
     """[Cout,Cin,k,k] -> packed [k*k][Cin][Cout] (or the flipped/transposed pack for the data gradient)."""
@@ -87,12 +108,17 @@ def conv_num_tiles(Hout, Wout):
 
 
 def conv2d(src0, wpk, bias, ks, Cout, src1=None, mode=CONV_NORMAL, pro=None, out=None, res=None, vec=None, aux=None,
-           want_stats=False):
+           want_stats=False, algo=None):
     """Implicit-GEMM conv.  pro=(a,b): per-(b,c) affine+SiLU applied to src0 while it is gathered;
-    aux=(tensor,a,b): adds silu(a*tensor+b) in the epilogue.  Returns out or (out, stats)."""
+    aux=(tensor,a,b): adds silu(a*tensor+b) in the epilogue.  Returns out or (out, stats).
+    algo: None = the library picks; CONV_ALGO_x = that kernel or an error (idiff_conv_desc.algo_request)."""
     lib = _lib.load()
     B, C0, Hin, Win = src0.shape
     d = ConvDesc()
+    if algo is not None:
+        d.algo_request = 1 + algo
+    elif ks == 3 and getattr(_ALGO_REQUEST, "algo", None) is not None:
+        d.algo_request = -(1 + _ALGO_REQUEST.algo)  # scope request: taken where the shape tiles, the library's choice elsewhere
     d.src0, d.src0_bstride, d.C0 = src0.data_ptr(), _bs(src0, "src0"), C0
     if src1 is not None:
         assert src1.shape[0] == B and src1.shape[2:] == src0.shape[2:]
@@ -147,6 +173,9 @@ def conv2d(src0, wpk, bias, ks, Cout, src1=None, mode=CONV_NORMAL, pro=None, out
                             flops=2.0 * Cin * Cout * ks * ks * Hout * Wout * B))
     else:
         check(lib.idiff_conv2d_fwd(C.byref(d), _stream()), "conv2d_fwd")
+    if ALGO_TRACE is not None:
+        Cin = (C0 * 4 if mode == CONV_UNSHUFFLE2 else C0) + (src1.shape[1] if src1 is not None else 0)
+        ALGO_TRACE[(lib.idiff_conv2d_last_algo(), ks, Cin, Cout, Hout, Wout)] += 1
     return (out, stats) if want_stats else out
 
 
@@ -468,13 +497,13 @@ def drift_reverse_step(x, r_hat, e_hat, z, a, b, c, cond=None, seed=0, offset=0,
     return (out, xa_out) if cond is not None else out
 
 
-def drift_reverse_step_dev(x, r_hat, e_hat, z_base, cond, xa, coef, state, seed, nper):
+def drift_reverse_step_dev(x, r_hat, e_hat, z_base, cond, xa, coef, state, seed, nper, offset_base=0):
     """in-place, graph-replayable drift step: per-step scalars from `coef` [3, T+1] and `state` int32 [3] on the device"""
     lib = _lib.load()
     _c(x, "x"), _c(r_hat, "r_hat"), _c(e_hat, "e_hat"), _c(z_base, "z"), _c(cond, "cond"), _c(xa, "xa"), _c(coef, "coef")
     assert state.dtype == torch.int32 and state.is_cuda and state.numel() == 3 and coef.dim() == 2 and coef.shape[0] == 3
     check(lib.idiff_drift_reverse_step_dev(_p(x), _p(r_hat), _p(e_hat), _p(z_base), _p(cond), _p(xa), x.numel(), _p(coef), coef.shape[1],
-                                           C.c_void_p(state.data_ptr()), seed, nper, _stream()), "drift_reverse_step_dev")
+                                           C.c_void_p(state.data_ptr()), seed, nper, offset_base, _stream()), "drift_reverse_step_dev")
 
 
 def step_state_advance(state, tdev, T, t_stop=0):

@@ -77,6 +77,10 @@ class GradSync:
         """enqueue all-reduce(SUM) of every flat gradient buffer; returns immediately"""
         if not self.active:
             return
+        if any(f is g for _, g, _ in self._pending for f in flats):
+            # a previous step left between start() and finish() (an exception the caller caught): its stale handles must not be
+            # waited on -- and, on the bf16 wire, widened over the fresh gradients -- by this step's finish()
+            self.drain()
         for f in flats:
             if self.wire == "bf16" and f.is_cuda:
                 from . import ops
@@ -93,13 +97,21 @@ class GradSync:
         """wait for every started exchange; returns the scale (1/world) still to be applied by the optimizer"""
         if not self.active:
             return 1.0
-        for work, f, wb in self._pending:
+        pending, self._pending = self._pending, []  # cleared whatever happens below
+        for work, f, wb in pending:
             work.wait()  # stream-ordered for RCCL (the current stream waits), blocking for gloo
             if wb is not None:
                 from . import ops
                 ops.bf16_to_f32(wb, out=f)
-        self._pending = []
         return 1.0 / self.world
+
+    @torch.no_grad()
+    def drain(self):
+        """wait for exchanges that were started and never finished, and discard their results (collectives are matched across
+        ranks by order, so they are completed, not cancelled)"""
+        pending, self._pending = self._pending, []
+        for work, _, _ in pending:
+            work.wait()
 
     @torch.no_grad()
     def all_reduce_flat(self, flats):

@@ -95,7 +95,8 @@ def main(argv=None):
     model = create_model(train_opt, opt["models"][train_opt["which_model"]])
     current_step, start_epoch = 0, 0
     if opt["path"]["resume_state"]:
-        resume_state = torch.load(opt["path"]["resume_state"], map_location="cpu")
+        # reference-era .state files pickle optimizer / scheduler objects (drift_noise_model.py:694-704): see load_training_state
+        resume_state = model.load_training_state(opt["path"]["resume_state"], trusted=bool(opt["path"].get("resume_state_trusted")))
         option.check_resume(opt, resume_state["iter"])
         start_epoch, current_step = resume_state["epoch"] + 1, resume_state["iter"]
         model.resume_training(resume_state)

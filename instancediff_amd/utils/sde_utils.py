@@ -68,7 +68,7 @@ class IRSDE(SDE):
         self.sample_scale = self.T / self.sample_T  # :89
         self._initialize(self.max_sigma, self.sample_T, schedule, eps)
         self.seed = 0
-        self._noise_calls = 0
+        self._noise_off = 0
 
     # ---- host-side schedule construction, operation order of sde_utils.py:94-147 -------------------
     def _initialize(self, max_sigma, T, schedule, eps=0.01):
@@ -117,7 +117,15 @@ class IRSDE(SDE):
     def set_seed(self, seed):
         """key of the on-device Philox stream that stands in for torch.randn_like"""
         self.seed = int(seed)
-        self._noise_calls = 0
+        self._noise_off = 0
+
+    def _next_offset(self, numel):
+        """Philox counter offset of the next draw of `numel` normals (4 per counter).  Cumulative: successive draws use disjoint
+        counter ranges whatever their sizes (a per-call index times the CURRENT size re-read counters an earlier, larger draw had
+        consumed); same-shape sequences are reproducible as before."""
+        off = self._noise_off
+        self._noise_off += (numel + 3) // 4
+        return off
 
     # ---- coefficient plumbing ------------------------------------------------------------------------
     def _rows(self, t):
@@ -152,9 +160,7 @@ class IRSDE(SDE):
         """(z, seed, offset): injected draws, or the next slice of the Philox stream"""
         if z is not None:
             return dict(z=z.contiguous())
-        off = self._noise_calls * ((like.numel() + 3) // 4)
-        self._noise_calls += 1
-        return dict(z=None, seed=self.seed, offset=off)
+        return dict(z=None, seed=self.seed, offset=self._next_offset(like.numel()))
 
     def _w(self, r):  # exp(-thetas_cumsum[t] * dt), fp32 on the host exactly as :170
         return torch.exp(-self._h["thetas_cumsum"][r] * self.dt)
@@ -269,8 +275,7 @@ class IRSDE(SDE):
         mu = self.mu if torch.is_tensor(self.mu) else torch.full_like(x, float(self.mu))
         off = 0
         if mode == ops.SDE_STEP and z is None:
-            off = self._noise_calls * ((x.numel() + 3) // 4)
-            self._noise_calls += 1
+            off = self._next_offset(x.numel())
         return ops.irsde_reverse_step(x, mu.contiguous(), noise_pred.contiguous(), z, float(h["thetas"][t]), float(h["sigmas"][t]),
                                       float(h["sigma_bars"][t]), self._dt, self._sqrt_dt, mode=mode, seed=self.seed, offset=off, out=out)
 
@@ -342,9 +347,7 @@ class IRSDE(SDE):
         return timesteps.to(self.device), noisy_states
 
     def _randn_like(self, x):
-        off = self._noise_calls * ((x.numel() + 3) // 4)
-        self._noise_calls += 1
-        return ops.randn(x.shape, x.device, self.seed, off)
+        return ops.randn(x.shape, x.device, self.seed, self._next_offset(x.numel()))
 
     def noise_state(self, tensor, eps=None):
         """tensor + randn * max_sigma (:340-341)."""

@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 from instancediff_amd import ops, pipeline, train_ops  # noqa: E402
 from instancediff_amd.utils.synthetic import ARTIFACT_TYPES, make_batch  # noqa: E402
 from oracle import sde_ref, unet_ref  # noqa: E402
-from tests.test_sampling_gpu import oracle_nets  # noqa: E402
+from tests.test_sampling_gpu import make_scoremap_branch_visible, oracle_nets  # noqa: E402
 
 DEV = "cuda"
 
@@ -60,6 +60,7 @@ def test_c4_c2_five_modalities_vs_oracle_and_batch16_invariance():
     T, H = 2, 256
     model, sde = pipeline.build(phase="test", device=torch.device(DEV), T=T, seed=0)
     model.set_eval()
+    make_scoremap_branch_visible(model)  # gamma 0.3, decoder biases de-zeroed: memproj / Gram / folds / key split carry weight
     b16 = make_batch(16, H, seed=2024)
     assert b16['names'][:5] == ARTIFACT_TYPES  # one image per modality in the first five
     g = torch.Generator().manual_seed(2025)
@@ -81,6 +82,7 @@ def test_c5_512_chain_vs_oracle_and_batch8_invariance():
     T, H = 2, 512
     model, sde = pipeline.build(phase="test", device=torch.device(DEV), T=T, seed=0)
     model.set_eval()
+    make_scoremap_branch_visible(model)  # gamma 0.3, decoder biases de-zeroed: memproj / Gram / folds / key split carry weight
     b8 = make_batch(8, H, seed=512)
     g = torch.Generator().manual_seed(513)
     x_T = b8['input'] + 0.4 * torch.randn(b8['input'].shape, generator=g)
@@ -251,6 +253,7 @@ def test_native_224_chain_vs_oracle_on_the_winograd_path():
     T, H = 2, 224
     model, sde = pipeline.build(phase="test", device=torch.device(DEV), T=T, seed=0)
     model.set_eval()
+    make_scoremap_branch_visible(model)  # gamma 0.3, decoder biases de-zeroed: memproj / Gram / folds / key split carry weight
     b2 = make_batch(2, H, seed=224)
     g = torch.Generator().manual_seed(225)
     x_T = b2['input'] + 0.4 * torch.randn(b2['input'].shape, generator=g)

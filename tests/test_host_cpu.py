@@ -311,3 +311,74 @@ def test_reference_era_state_file_resumes(tmp_path):
     again = FusedAdam(torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3)).parameters(), lr=2e-5)
     again.load_state_dict(sd)
     assert again._flat[0]["step"] == 3 and torch.equal(again._flat[0]["m"], want_m)
+
+
+def test_reference_era_state_file_resumes_through_the_model_entry_point(tmp_path):
+    """The path trainUM.py takes: CLIPDriftModel.load_training_state(path) (torch.load under weights_only with an allow-list of the
+    classes a reference-era `.state` pickles) -> model.resume_training(state).  A plain torch.load(path) of such a file raises
+    UnpicklingError under torch >= 2.6 defaults, which is what trainUM.py used to call."""
+    import pickle
+    model, _ = pipeline.build(phase="train", device=torch.device("cpu"), T=4)
+    adams, scheds = [], []
+    for net, lr in ((model.drift_net, 3e-5), (model.noise_net, 2e-5)):
+        params = [torch.nn.Parameter(p.detach().clone()) for p in net.parameters()]
+        adam = torch.optim.Adam(params, lr=lr, betas=(0.9, 0.99), weight_decay=1e-4)
+        sched = torch.optim.lr_scheduler.CosineAnnealingLR(adam, T_max=50, eta_min=1e-6)
+        g = torch.Generator().manual_seed(int(lr * 1e7))
+        for _ in range(2):
+            for p in params[:6]:  # parameters without state (never stepped) are legal too
+                p.grad = torch.randn(p.shape, generator=g) * 1e-3
+            adam.step()
+            sched.step()
+        adams.append(adam), scheds.append(sched)
+    path = tmp_path / "2.state"
+    torch.save({"epoch": 0, "iter": 2, "schedulers": scheds, "optimizers": adams}, path)  # models/drift_noise_model.py:694-699
+    with pytest.raises(pickle.UnpicklingError):
+        torch.load(path, map_location="cpu")
+    state = model.load_training_state(str(path))
+    assert state["iter"] == 2
+    model.resume_training(state)
+    for fused, adam, sch in ((model.drift_optimizer, adams[0], model.drift_lr_scheduler), (model.noise_optimizer, adams[1], model.noise_lr_scheduler)):
+        f = fused._flat[0]
+        first = adam.param_groups[0]["params"][0]
+        n = first.numel()
+        assert f["step"] == 2 and torch.equal(f["m"][:n].cpu(), adam.state[first]["exp_avg"].reshape(-1))
+        assert fused.param_groups[0]["betas"] == (0.9, 0.99) and sch.last_epoch == 2
+        assert abs(fused.param_groups[0]["lr"] - adam.param_groups[0]["lr"]) < 1e-12
+    # this build's own layout goes through the same entry point
+    model.save_training_state(0, 5, str(tmp_path))
+    again = model.load_training_state(str(tmp_path / "5.state"))
+    model.resume_training(again)
+    # a pickle holding anything else is refused unless declared trusted
+    evil = tmp_path / "9.state"
+    torch.save({"iter": 9, "optimizers": [os.getcwd]}, evil)  # a global outside the allow-list
+    with pytest.raises(RuntimeError):
+        model.load_training_state(str(evil))
+    assert model.load_training_state(str(evil), trusted=True)["iter"] == 9
+
+
+def test_bench_spawns_one_rank_per_gpu_with_the_rendezvous_environment(tmp_path):
+    """`python bench.py --gpus N` started plainly becomes the launcher: N fresh rank processes with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set (the reference's one-command launch, trainUM.py:50-66); a failing rank stops the others and the exit code is its."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    child = ("import os, json, sys; open(os.path.join(sys.argv[1], 'r' + os.environ['RANK']), 'w').write(json.dumps({k: os.environ.get(k) "
+             "for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'HSA_ENABLE_IPC_MODE_LEGACY')}))")
+    assert bench.spawn_ranks(3, [sys.executable, "-c", child, str(tmp_path)]) == 0
+    envs = [json.loads((tmp_path / f"r{r}").read_text()) for r in range(3)]
+    assert [e["RANK"] for e in envs] == ["0", "1", "2"] and [e["LOCAL_RANK"] for e in envs] == ["0", "1", "2"]
+    assert all(e["WORLD_SIZE"] == "3" and e["MASTER_ADDR"] == "127.0.0.1" and e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for e in envs)
+    assert len({e["MASTER_PORT"] for e in envs}) == 1 and int(envs[0]["MASTER_PORT"]) > 0
+    # rank 1 fails at once, rank 0 would wait forever: the launcher stops it and reports rank 1's code
+    hang = "import os, sys, time; sys.exit(7) if os.environ['RANK'] == '1' else time.sleep(600)"
+    import time
+    t0 = time.time()
+    assert bench.spawn_ranks(2, [sys.executable, "-c", hang]) == 7
+    assert time.time() - t0 < 60
+    # the real command line: without a GPU every rank refuses (exit 2, "needs a GPU") and so does the launcher -- but it did launch
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    if not torch.cuda.is_available():
+        assert r.returncode == 2 and r.stderr.count("needs a GPU") >= 1 and "rank" in r.stderr

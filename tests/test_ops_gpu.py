@@ -397,12 +397,8 @@ def test_conv_winograd_data_gradient_pack():
     _close(dx_d, ref, 2e-6, "direct dgrad")
     _close(dx_w, ref, 6e-6, "winograd dgrad")
     lib = ops._lib.load()
-    old = lib.idiff_conv_wino4_min_items(1)
-    try:
-        dx_4 = ops.conv2d(dy.to(DEV), _pack(wd, True, transpose=True, wino4=True), None, 3, Cin)
-        assert lib.idiff_conv2d_last_algo() == 3
-    finally:
-        lib.idiff_conv_wino4_min_items(old)
+    dx_4 = ops.conv2d(dy.to(DEV), _pack(wd, True, transpose=True, wino4=True), None, 3, Cin, algo=ops.CONV_ALGO_WINOGRAD4)
+    assert lib.idiff_conv2d_last_algo() == 3
     _close(dx_4, ref, 4e-5, "winograd4 dgrad")
 
 
@@ -445,10 +441,10 @@ def test_conv_winograd_random_shapes_match_direct():
 # about one decimal digit less than F(2x2,3x3) (tolerance 4e-5 of the output range, measured ~1e-5).
 @pytest.fixture
 def force_wino4():
-    lib = ops._lib.load()
-    old = lib.idiff_conv_wino4_min_items(1)
-    yield lib
-    lib.idiff_conv_wino4_min_items(old)
+    """every 3x3 conv of the test asks for the F(4x4,3x3) kernel through the per-call idiff_conv_desc.algo_request (the library's own
+    choice keeps layers with fewer than 16 items per sample on F(2x2,3x3))"""
+    with ops.request_conv3x3_algo(ops.CONV_ALGO_WINOGRAD4):
+        yield ops._lib.load()
 
 
 @pytest.mark.parametrize("B,C0,C1,Cout,H,W,variant", [
@@ -506,7 +502,7 @@ def test_conv_winograd4_matches_direct_and_fp64(force_wino4, B, C0, C1, Cout, H,
     wd = w.to(DEV)
     out_w, st_w = ops.conv2d(x0.to(DEV), _pack(wd, True, wino4=True), b.to(DEV), 3, Cout, want_stats=True, **kw)
     assert lib.idiff_conv2d_last_algo() == 3, "the F(4x4,3x3) kernel did not run"
-    out_d, st_d = ops.conv2d(x0.to(DEV), _pack(wd, False), b.to(DEV), 3, Cout, want_stats=True, **kw)
+    out_d, st_d = ops.conv2d(x0.to(DEV), _pack(wd, False), b.to(DEV), 3, Cout, want_stats=True, algo=ops.CONV_ALGO_DIRECT, **kw)
     assert lib.idiff_conv2d_last_algo() == 0
     _close(out_w, ref, 4e-5, "winograd4")
     assert st_w.shape == st_d.shape
@@ -528,16 +524,18 @@ def test_conv_winograd4_policy_and_fallback():
     x = torch.randn(2, 32, 32, 32, generator=g).to(DEV)
     ops.conv2d(x, wpk, None, 3, 64)
     assert lib.idiff_conv2d_last_algo() == 1           # 2 items per sample
-    old = lib.idiff_conv_wino4_min_items(1)
-    try:
-        ops.conv2d(x, wpk, None, 3, 64)
-        assert lib.idiff_conv2d_last_algo() == 3
-        x2 = torch.randn(1, 32, 30, 36, generator=g).to(DEV)   # H % 4 != 0
-        ref = F.conv2d(x2.double().cpu(), w.double().cpu(), padding=1)
+    ops.conv2d(x, wpk, None, 3, 64, algo=ops.CONV_ALGO_WINOGRAD4)   # asked for by name: the threshold is waived
+    assert lib.idiff_conv2d_last_algo() == 3
+    x2 = torch.randn(1, 32, 30, 36, generator=g).to(DEV)   # H % 4 != 0
+    ref = F.conv2d(x2.double().cpu(), w.double().cpu(), padding=1)
+    with pytest.raises(ops._lib.IdiffError):               # a hard request for a shape the kernel does not tile fails loudly
+        ops.conv2d(x2, wpk, None, 3, 64, algo=ops.CONV_ALGO_WINOGRAD4)
+    with ops.request_conv3x3_algo(ops.CONV_ALGO_WINOGRAD4):  # the scope form is a preference: the library's choice elsewhere
         _close(ops.conv2d(x2, wpk, None, 3, 64), ref, 6e-6, "fallback")
-        assert lib.idiff_conv2d_last_algo() == 1
-    finally:
-        lib.idiff_conv_wino4_min_items(old)
+    assert lib.idiff_conv2d_last_algo() == 1
+    o_d = ops.conv2d(x, wpk, None, 3, 64, algo=ops.CONV_ALGO_DIRECT)
+    assert lib.idiff_conv2d_last_algo() == 0
+    _close(o_d, F.conv2d(x.double().cpu(), w.double().cpu(), padding=1), 2e-6, "direct by request")
     big = torch.randn(16, 32, 64, 64, generator=g).to(DEV)   # 8 items per sample: the batch does not count
     ops.conv2d(big, wpk, None, 3, 64)
     assert lib.idiff_conv2d_last_algo() == 1

@@ -1,6 +1,9 @@
 """Pins oracle/sde_ref.py against golden vectors generated from the real reference
 (utils/sde_utils.py, via tests/golden/make_golden_sde.py).  Bit-exact (same torch-CPU op order)."""
+import os
+
 import numpy as np
+
 import pytest
 import torch
 
@@ -181,3 +184,25 @@ def test_optimal_reverse_and_x0_score(golden_sde2):
     assert np.array_equal(sde.optimal_reverse(i["x"], i["x0"], T=7).numpy(), g["opt/optimal_reverse_T7"])
     sde.set_model(lambda xx, m, t, **kw: 0.8 * xx + 0.1 * m)
     assert np.array_equal(sde.score_fn_(i["x"], 9, 1.0).numpy(), g["opt/score_fn_x0pred_t9"])
+
+
+@pytest.mark.parametrize("T", [50, 100, 1000])
+def test_cosine_drift_level_increments_match_the_reference_function(T):
+    """`get_drift_deferential_cosine(t, T)` (models/drift_noise_model.py:10-16) -- the reference-held piece of the drift schedule:
+    level(t+1) - level(t) of the half-cosine level.  Golden increments come from the reference's own function definition
+    (tests/golden/make_golden_drift_cosine.py); the oracle's and the product's `cosine` level tables must reproduce them."""
+    import numpy as np
+    from instancediff_amd.models.SDEs.driftSDE import _level_table
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "drift_cosine_golden.npz"))
+    inc = gold[f"T{T}/increment"]
+    assert np.array_equal(inc, gold[f"T{T}/increment_int_t"]) and inc.shape == (T,)
+    assert abs(inc.sum() - 1.0) < 1e-12   # the increments telescope to level(T) - level(0) = 1
+    for name, table in (("oracle", sde_ref.drift_level_table(T, "cosine")), ("product", _level_table(T, "cosine"))):
+        lv = table.double().numpy()
+        assert lv.shape == (T + 1,) and lv[0] == 0.0 and lv[-1] == 1.0
+        err = np.abs((lv[1:] - lv[:-1]) - inc).max()
+        assert err < 1.5e-7, (name, err)  # the tables are stored in fp32: two roundings of values <= 1
+    # and in fp64 the closed form itself is the reference's, to the last bits
+    t = np.arange(T + 1, dtype=np.float64)
+    lv64 = (1 - np.cos(t * np.pi / T)) / 2
+    assert np.abs((lv64[1:] - lv64[:-1]) - inc).max() < 1e-15

@@ -1,13 +1,15 @@
 """End-to-end sampling parity (BASELINE config c1: 64x64, batch 4, 50-step reverse chain): HIP pipeline on the
 GPU vs the oracle chain on the CPU with identical weights, inputs and injected noise.  Bar: |dPSNR| < 1e-3 dB
 (north_star), fp32."""
+import collections
+
 import pytest
 import torch
 import torch.nn as nn
 
 pytestmark = pytest.mark.gpu
 
-from instancediff_amd import pipeline  # noqa: E402
+from instancediff_amd import ops, pipeline  # noqa: E402
 from instancediff_amd.utils.sde_utils import IRSDE  # noqa: E402
 from instancediff_amd.utils.synthetic import make_batch  # noqa: E402
 from oracle import sde_ref, unet_ref  # noqa: E402
@@ -26,6 +28,81 @@ def oracle_nets(model):
         r.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()})
         refs.append(r)
     return refs
+
+
+def make_scoremap_branch_visible(model, gamma=0.3, seed=77):
+    """The ScoreMapModule's decoder contribution enters the score maps as gamma * out_proj(...) with gamma = 1e-4 at init, and the
+    decoder's biases are zero-initialised: at init the memory projection, Gram-matrix variance, query / value folds, the key split
+    and its combine add 1e-4 of their error to a chain's output.  Raise gamma and de-zero those vectors (both nets; the oracle copies
+    the state dict afterwards) so those kernels carry weight in the compared images."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for net in (model.drift_net, model.noise_net):
+            for m in net.CLIP_ScoreMapModule:
+                m.gamma.fill_(gamma)
+                for p in m.context_decoder.parameters():
+                    if p.dim() == 1 and float(p.abs().sum()) == 0:
+                        p.copy_((torch.randn(p.shape, generator=g) * 0.02).to(p.device))
+    from instancediff_amd import train_ops
+    train_ops.WEIGHT_EPOCH[0] += 1  # prepared-weight caches key on it
+
+
+def _long_chain(T, B, H, seed, what, request=None, expect_wino4=()):
+    """T-step injected-noise chain (2 UNet forwards + update per step) against the oracle's CPU chain; expect_wino4 lists
+    (Cin, Cout, Hout) conv shapes that must have been served by the F(4x4,3x3) kernel (idiff_conv2d_last_algo() == 3)."""
+    model, sde = pipeline.build(phase="test", device=torch.device(DEV), T=T, seed=0)
+    model.set_eval()
+    make_scoremap_branch_visible(model)
+    batch = make_batch(B, H, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    x_T = batch['input'] + 0.4 * torch.randn(batch['input'].shape, generator=g)
+    noises = torch.randn((T,) + tuple(batch['input'].shape), generator=g)
+    model.feed_data(batch)
+    ops.ALGO_TRACE = collections.Counter()
+    try:
+        if request is None:
+            model.test(x_T=x_T.to(DEV), noises=noises.to(DEV))
+        else:
+            with ops.request_conv3x3_algo(request):
+                model.test(x_T=x_T.to(DEV), noises=noises.to(DEV))
+        trace = ops.ALGO_TRACE
+    finally:
+        ops.ALGO_TRACE = None
+    for cin, cout, hout in expect_wino4:
+        served = {k[0] for k in trace if k[1] == 3 and k[2] == cin and k[3] == cout and k[4] == hout}
+        assert served == {3}, f"{what}: conv {cin}->{cout} at {hout} ran on algos {served}, expected F(4x4,3x3) only"
+    n4 = sum(v for k, v in trace.items() if k[0] == 3)
+    n2 = sum(v for k, v in trace.items() if k[0] == 1)
+    out = torch.from_numpy(model.get_visuals())
+    assert out.shape == (B, 1, H, H) and torch.isfinite(out).all()
+    refs = oracle_nets(model)
+    rsde = sde_ref.DriftSDERef(T, refs[0], refs[1], max_sigma=0.4)
+    with torch.no_grad():
+        ref = rsde.reverse_ddpm(batch['input'], batch['names'], unet_ref.StubTextEncoder(), x_T, noises, image_context=batch['A_emb'])
+    err = float((out - ref).abs().max())
+    worst = max(abs(sde_ref.psnr(out[b], batch['target'][b]) - sde_ref.psnr(ref[b], batch['target'][b])) for b in range(B))
+    print(f"{what}: {T} steps, F(4x4,3x3) / F(2x2,3x3) conv calls per traced step {n4} / {n2}; max|hip-oracle| {err:.3e}, "
+          f"worst per-image |dPSNR| {worst:.2e} dB")
+    assert worst < 1e-3 and err < 5e-4, (what, worst, err)
+
+
+def test_c1_chain_forced_through_the_f4x4_kernel():
+    """BASELINE c1 (64x64, batch 4, 50 steps) once more with every 3x3 conv asking for the F(4x4,3x3) kernel: the 64x64 and 32x32
+    levels (8 and fewer items per sample: F(2x2,3x3) by the library's own choice) then run on it, so the kernel that carries most of
+    a 256x256 step takes part in a 50-step dependent chain.  Same bound as the c1 chain."""
+    _long_chain(50, 4, 64, 1234, "c1 forced F(4x4,3x3)", request=ops.CONV_ALGO_WINOGRAD4,
+                expect_wino4=[(64, 64, 64), (144, 64, 64), (64, 64, 32), (208, 128, 32)])
+
+
+def test_128_chain_50_steps_through_the_f4x4_kernel_by_default_choice():
+    """128x128 batch 1: levels 0 and 1 (32 and 16 items per sample) select the F(4x4,3x3) kernel on their own, 50 dependent steps."""
+    _long_chain(50, 1, 128, 128, "128x128 50-step chain", expect_wino4=[(64, 64, 128), (144, 64, 128), (208, 128, 64), (128, 64, 128)])
+
+
+def test_c2_shape_25_step_chain_through_the_f4x4_kernel():
+    """The headline shape (256x256): 25 dependent steps, three levels on the F(4x4,3x3) kernel, ScoreMapModule memory at N = 65 536
+    with the key split and the compact memory carrying weight (gamma = 0.3)."""
+    _long_chain(25, 1, 256, 256, "256x256 25-step chain", expect_wino4=[(64, 64, 256), (64, 64, 128), (128, 128, 64), (144, 64, 256)])
 
 
 def test_c1_drift_chain_psnr_parity():
@@ -171,3 +248,44 @@ def test_failed_graph_capture_keeps_the_step_count(monkeypatch):
     assert torch.isfinite(outs["eager"]).all()
     assert torch.equal(outs["eager"], outs["graph"])
     assert torch.equal(outs["eager"], outs["broken"])
+
+
+def test_philox_draws_of_mixed_sizes_never_share_counters():
+    """Successive draws of one stream use disjoint Philox counter ranges whatever their sizes (training crops, then a validation
+    image of another size): the second draw continues where the first ended, for IRSDE and for driftSDE incl. its graph-replayed
+    steps."""
+    sde = IRSDE(0.4, T=10, schedule='cosine', eps=0.01, device=torch.device(DEV))
+    sde.set_seed(5)
+    a = sde._randn_like(torch.empty(2, 1, 32, 32, device=DEV))
+    b = sde._randn_like(torch.empty(1, 1, 16, 20, device=DEV))
+    c = sde.noise_state(torch.zeros(1, 1, 8, 8, device=DEV))
+    ref = ops.randn((2048 + 320 + 64,), DEV, 5, 0)
+    assert torch.equal(a.reshape(-1), ref[:2048]) and torch.equal(b.reshape(-1), ref[2048:2368])
+    assert torch.equal(c.reshape(-1), ref[2368:] * sde.max_sigma)
+    # driftSDE: forward_diffusion draw (big), then a 4-step reverse chain on a smaller image: its x_T draw and its per-step draws
+    T, H = 4, 32
+    model, dsde = pipeline.build(phase="test", device=torch.device(DEV), T=T, seed=0)
+    model.set_eval()
+    dsde.set_seed(9)
+    big = make_batch(2, 64, seed=3)
+    dsde.forward_diffusion(big['target'].to(DEV), big['input'].to(DEV))         # counters [0, 2048)
+    small = make_batch(1, H, seed=4)
+    model.feed_data(small)                                                       # forward_diffusion again: [2048, 2304)
+    off0 = dsde._off
+    assert off0 == 2048 + 256
+    model.test()                                                                 # x_T draw + T step draws of 256 counters each
+    assert dsde._off == off0 + 256 * (1 + T)
+    out = torch.from_numpy(model.get_visuals()).clone()
+    # the same chain with the draws injected from the counter ranges they must have used
+    stream = ops.randn((4 * (off0 + 256 * (1 + T)),), DEV, 9, 0)
+    x_T = ops.axpby(small['input'].to(DEV), stream[4 * off0:4 * (off0 + 256)].reshape(1, 1, H, H).contiguous(), 1.0, dsde.max_sigma)  # reverse_ddpm's own formula
+    noises = stream[4 * (off0 + 256):].reshape(T, 1, 1, H, H).contiguous()
+    model.test(x_T=x_T, noises=noises)
+    assert torch.equal(torch.from_numpy(model.get_visuals()), out)
+
+
+def test_reverse_type_other_than_std_is_refused():
+    model, sde = pipeline.build(phase="test", device=torch.device(DEV), T=4, seed=0)
+    b = make_batch(1, 32, seed=1)
+    with pytest.raises(NotImplementedError):
+        sde.reverse_ddpm(b['input'].to(DEV), b['names'], model.text_encoder, reverse_type="scaled", image_context=b['A_emb'].to(DEV))

@@ -361,3 +361,29 @@ def test_conv_wgrad_winograd_random_shapes_vs_fp64():
         dw = T.conv2d_wgrad(x0.to(DEV), None if x1 is None else x1.to(DEV), ops.CONV_NORMAL, 3, dy.to(DEV), C0 + C1)
         assert lib.idiff_conv2d_wgrad_last_algo() == 1, (case, B, C0, C1, Cout, H, W)
         assert _rel(dw, w.grad) < 1e-5, (case, B, C0, C1, Cout, H, W)
+
+
+def test_optimize_score_map_by_name_with_the_reference_size_argument():
+    """CLIPDriftModel.optimize_score_map(score_maps, label, size=[224, 224]) exactly as the reference calls it
+    (models/drift_noise_model.py:234-240, 290-291): sum_i MSE(sm_i, Resize(224 // m_i)(label)) / 2, m = [1, 2, 4, 8]; torchvision-0.14
+    tensor Resize = bilinear without antialiasing.  Value and per-map gradients against torch."""
+    import torch.nn.functional as F
+    from instancediff_amd import pipeline
+    model, _ = pipeline.build(phase="train", device=torch.device(DEV), T=10, seed=0)
+    g = torch.Generator().manual_seed(61)
+    B, S = 3, 224
+    label = torch.randn(B, 1, S, S, generator=g)
+    sms = [torch.randn(B, 1, S // m, S // m, generator=g) for m in (1, 2, 4, 8)]
+    want = 0.0
+    leaves = [s.clone().requires_grad_(True) for s in sms]
+    for m, sm in zip((1, 2, 4, 8), leaves):
+        lb = label if m == 1 else F.interpolate(label, size=(S // m, S // m), mode="bilinear", align_corners=False, antialias=False)
+        want = want + F.mse_loss(sm, lb)
+    want = want / 2.0
+    want.backward()
+    loss, grads = model.optimize_score_map([s.to(DEV) for s in sms], label.to(DEV), size=[224, 224], want_grads=True)
+    assert abs(float(loss) - float(want)) < 2e-6 * abs(float(want)), (float(loss), float(want))
+    for gh, leaf in zip(grads, leaves):
+        assert float((gh.cpu() - leaf.grad).abs().max()) < 2e-6 * float(leaf.grad.abs().max()) + 1e-12  # the /2 of :240 included
+    # default size = the label's own
+    assert float(model.optimize_score_map([s.to(DEV) for s in sms], label.to(DEV))) == float(loss)
