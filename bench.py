@@ -494,6 +494,7 @@ def main():
         allrecs = ops.PROFILE
         ops.PROFILE = None
         KERN = {3: ("conv_wino4_kernel (3x3 conv, Winograd F(4x4,3x3) on f32 MFMA)", 36.0 / 144.0, 4.0),
+                4: ("conv_wino4h_kernel (3x3 conv, Winograd F(4x4,3x3) on f32 MFMA, half-patch items, 2 workgroups per CU)", 36.0 / 144.0, 4.0),
                 1: ("conv_wino_kernel (3x3 conv, Winograd F(2x2,3x3) on f32 MFMA)", 16.0 / 36.0, 2.25)}
         groups = {}
         for algo, (name, factor, speedup) in KERN.items():

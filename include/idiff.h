@@ -96,6 +96,7 @@ int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream);
 #define IDIFF_CONV_ALGO_WINOGRAD 1 /* F(2x2,3x3),   conv_wino.hip   */
 #define IDIFF_CONV_ALGO_STREAM1X1 2 /* weight gradient only: streaming 1x1 product */
 #define IDIFF_CONV_ALGO_WINOGRAD4 3 /* F(4x4,3x3),  conv_wino4.hip  */
+#define IDIFF_CONV_ALGO_WINOGRAD4H 4 /* F(4x4,3x3), half-patch items, two workgroups per CU: conv_wino4h.hip */
 int idiff_conv2d_last_algo(void);
 /* w [Cout][Cin][ks][ks] (torch layout) -> wpk [ks*ks][Cin][Cout] */
 int idiff_pack_conv_weight(const float* w, float* wpk, int Cout, int Cin, int ks, idiff_stream_t stream);

@@ -38,10 +38,14 @@ bool conv_wino_eligible(const ConvArgs& a, int ks, int mode);
 // launches it; a.tiles_x / ntiles / ncob / total_wg must describe 8x32-pixel patches and 64-channel blocks
 int launch_conv_wino(const ConvArgs& a, int mode, hipStream_t st);
 
-// F(4x4,3x3) kernel (conv_wino4.hip): 3x3, H and W multiples of 4, Cin % 8 == 0, Cout % 16 == 0, at least one 16x32-pixel x
-// 64-channel item per CU; a.tiles_x / ntiles / ncob describe 8x32-pixel patches (the GroupNorm-partials grid) as above
-// requested: the caller asked for this kernel by name (idiff_conv_desc.algo_request): the items-per-sample threshold is waived
-bool conv_wino4_eligible(const ConvArgs& a, int ks, int mode, bool requested = false);
+// F(4x4,3x3) kernels: H and W multiples of 4, W >= 24, Cin % 8 == 0, Cout % 16 == 0, a weight image (idiff_pack_conv_weight_wino4).
+// conv_wino4_items: 0 when they do not cover the problem, else the 16x32-pixel x 64-channel items PER SAMPLE (the quantity the choice
+// between the kernels is made on -- never the batch).  `requested`: asked for by name (idiff_conv_desc.algo_request), which also
+// overrides IDIFF_WINOGRAD4=0.  a.tiles_x / ntiles / ncob describe 8x32-pixel patches (the GroupNorm-partials grid) as above.
+long long conv_wino4_items(const ConvArgs& a, int ks, int mode, bool requested = false);
+// conv_wino4.hip: one 512-thread workgroup per CU, items of 16x32 pixels x 64 channels, weights staged through LDS
 int launch_conv_wino4(const ConvArgs& a, int mode, hipStream_t st);
+// conv_wino4h.hip: two 256-thread workgroups per CU, items of 8x32 pixels x 64 channels, weights read straight into the A operand
+int launch_conv_wino4h(const ConvArgs& a, int mode, hipStream_t st);
 
 }  // namespace idiff_detail

@@ -655,13 +655,37 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
     hipStream_t st = (hipStream_t)stream;
     const bool hard = d->algo_request > 0;
     const int req = (hard ? d->algo_request : -d->algo_request) - 1;  // -1: the library picks
-    IDIFF_CHECK_ARG(req == -1 || req == IDIFF_CONV_ALGO_DIRECT || req == IDIFF_CONV_ALGO_WINOGRAD || req == IDIFF_CONV_ALGO_WINOGRAD4,
+    IDIFF_CHECK_ARG(req == -1 || req == IDIFF_CONV_ALGO_DIRECT || req == IDIFF_CONV_ALGO_WINOGRAD || req == IDIFF_CONV_ALGO_WINOGRAD4 ||
+                        req == IDIFF_CONV_ALGO_WINOGRAD4H,
                     "conv2d: bad algo_request %d", d->algo_request);
-    if ((req == -1 || req == IDIFF_CONV_ALGO_WINOGRAD4) && idiff_detail::conv_wino4_eligible(a, d->ks, d->mode, req == IDIFF_CONV_ALGO_WINOGRAD4)) {
-        g_last_algo = IDIFF_CONV_ALGO_WINOGRAD4;
-        return idiff_detail::launch_conv_wino4(a, d->mode, st);
+    // Which F(4x4,3x3) kernel (both read the same weight image): decided on the layer's PER-SAMPLE shape only.
+    //   >= 16 items of 16x32 pixels x 64 channels per sample: the 16x32 kernel -- except two-source (virtual concat) layers, whose long
+    //      K favours the half-patch kernel (weights straight into the A operand: -4..8 % measured on the up-path layers at c2);
+    //   fewer, but >= 16 half-patch (8x32) items: the half-patch kernel (the 32x32 level at c2: -7..17 % against F(2x2,3x3));
+    //   fewer still: F(2x2,3x3) / direct below.
+    static const int w4h_mode = [] {  // IDIFF_W4H (A/B runs): 0 = never by itself, 1 (default) = the rule above, 2 = wherever it tiles
+        const char* e = getenv("IDIFF_W4H");
+        return e ? atoi(e) : 1;
+    }();
+    const bool req4 = req == IDIFF_CONV_ALGO_WINOGRAD4, req4h = req == IDIFF_CONV_ALGO_WINOGRAD4H;
+    const long long items16 = (req == -1 || req4 || req4h) ? idiff_detail::conv_wino4_items(a, d->ks, d->mode, req4 || req4h) : 0;
+    if (items16 > 0) {
+        const long long items8 = (long long)a.ntiles * a.ncob;
+        bool half;
+        if (req4h) half = true;
+        else if (req4) half = false;
+        else if (items16 >= 16) half = w4h_mode == 2 || (w4h_mode == 1 && a.src1 != nullptr);
+        else half = w4h_mode >= 1 && items8 >= 16;
+        if (half) {
+            g_last_algo = IDIFF_CONV_ALGO_WINOGRAD4H;
+            return idiff_detail::launch_conv_wino4h(a, d->mode, st);
+        }
+        if (req4 || items16 >= 16) {
+            g_last_algo = IDIFF_CONV_ALGO_WINOGRAD4;
+            return idiff_detail::launch_conv_wino4(a, d->mode, st);
+        }
     }
-    IDIFF_CHECK_ARG(!hard || req != IDIFF_CONV_ALGO_WINOGRAD4, "conv2d: algo_request F(4x4,3x3) but the shape does not tile for it");
+    IDIFF_CHECK_ARG(!hard || !(req4 || req4h), "conv2d: algo_request F(4x4,3x3) but the shape does not tile for it");
     if ((req == -1 || req == IDIFF_CONV_ALGO_WINOGRAD || !hard) && req != IDIFF_CONV_ALGO_DIRECT && idiff_detail::conv_wino_eligible(a, d->ks, d->mode)) {
         g_last_algo = IDIFF_CONV_ALGO_WINOGRAD;
         return idiff_detail::launch_conv_wino(a, d->mode, st);

@@ -709,30 +709,26 @@ int wino4_mode() {  // IDIFF_WINOGRAD4: 0 = never, 1 (default) = where eligible
     }();
     return m;
 }
-// Small levels stay on the 8x32-patch F(2x2,3x3) kernel, whose items are half the size (fuller grid): the threshold is on the
-// items PER SAMPLE (16x32 pixels x 64 channels each), never on the batch -- which kernel serves a layer, and so every bit of
-// its result, must not depend on the batch a sample sits in.  (A per-call idiff_conv_desc.algo_request waives it.)
-constexpr int MIN_ITEMS = 16;
-
 }  // namespace
 
 namespace idiff_detail {
 
-bool conv_wino4_eligible(const ConvArgs& a, int ks, int mode, bool requested) {
-    if (ks != 3 || !a.wwino4 || (wino4_mode() == 0 && !requested)) return false;
-    if (mode != IDIFF_CONV_NORMAL && mode != IDIFF_CONV_UPSAMPLE2) return false;
-    if (a.Cout % 16 || a.Cin % 8 || a.C0v % CK || (a.Hout & 3) || (a.Wout & 3) || a.Wout < 24) return false;
-    if ((long long)a.Cin * a.Hin * a.Win * 4 >= (1ll << 31)) return false;  // 32-bit byte offsets inside a sample
-    if (mode == IDIFF_CONV_UPSAMPLE2 && (a.pro_a || a.src1)) return false;
-    if (a.pro_a && a.src1) return false;
-    if (a.pro_a && ((a.C0r & 3) || (reinterpret_cast<uintptr_t>(a.pro_a) & 15) || (reinterpret_cast<uintptr_t>(a.pro_b) & 15))) return false;  // s_load_dwordx4
-    if ((reinterpret_cast<uintptr_t>(a.wwino4) & 15) != 0) return false;
+// 0 when the F(4x4,3x3) kernels do not cover the problem (shape, alignment, no weight image, IDIFF_WINOGRAD4=0 unless asked for by
+// name); otherwise the number of 16x32-pixel x 64-channel items PER SAMPLE -- what the choice between the kernels is made on, never
+// the batch: which kernel serves a layer, and so every bit of its result, must not depend on the batch a sample sits in.
+long long conv_wino4_items(const ConvArgs& a, int ks, int mode, bool requested) {
+    if (ks != 3 || !a.wwino4 || (wino4_mode() == 0 && !requested)) return 0;
+    if (mode != IDIFF_CONV_NORMAL && mode != IDIFF_CONV_UPSAMPLE2) return 0;
+    if (a.Cout % 16 || a.Cin % 8 || a.C0v % CK || (a.Hout & 3) || (a.Wout & 3) || a.Wout < 24) return 0;
+    if ((long long)a.Cin * a.Hin * a.Win * 4 >= (1ll << 31)) return 0;  // 32-bit byte offsets inside a sample
+    if (mode == IDIFF_CONV_UPSAMPLE2 && (a.pro_a || a.src1)) return 0;
+    if (a.pro_a && a.src1) return 0;
+    if (a.pro_a && ((a.C0r & 3) || (reinterpret_cast<uintptr_t>(a.pro_a) & 15) || (reinterpret_cast<uintptr_t>(a.pro_b) & 15))) return 0;  // s_load_dwordx4
+    if ((reinterpret_cast<uintptr_t>(a.wwino4) & 15) != 0) return 0;
     // float4 epilogue accesses
-    if ((a.obs & 3) || (a.res && (a.rbs & 3)) || (a.aux && (a.abs_ & 3))) return false;
-    if ((reinterpret_cast<uintptr_t>(a.out) & 15) || (reinterpret_cast<uintptr_t>(a.res) & 15) || (reinterpret_cast<uintptr_t>(a.aux) & 15)) return false;
-    const long long items = (long long)a.tiles_x * ((a.Hout + TH - 1) / TH) * a.ncob;  // per sample
-    if (items < MIN_ITEMS && !requested) return false;
-    return true;
+    if ((a.obs & 3) || (a.res && (a.rbs & 3)) || (a.aux && (a.abs_ & 3))) return 0;
+    if ((reinterpret_cast<uintptr_t>(a.out) & 15) || (reinterpret_cast<uintptr_t>(a.res) & 15) || (reinterpret_cast<uintptr_t>(a.aux) & 15)) return 0;
+    return (long long)a.tiles_x * ((a.Hout + TH - 1) / TH) * a.ncob;
 }
 
 int launch_conv_wino4(const ConvArgs& a, int mode, hipStream_t st) {

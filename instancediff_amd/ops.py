@@ -64,7 +64,7 @@ WINOGRAD4 = WINOGRAD and bool(int(os.environ.get("IDIFF_WINOGRAD4", "1")))
 WINOGRAD4_DGRAD = bool(int(os.environ.get("IDIFF_WINOGRAD4_DGRAD", "1")))
 
 
-CONV_ALGO_DIRECT, CONV_ALGO_WINOGRAD, CONV_ALGO_STREAM1X1, CONV_ALGO_WINOGRAD4 = 0, 1, 2, 3
+CONV_ALGO_DIRECT, CONV_ALGO_WINOGRAD, CONV_ALGO_STREAM1X1, CONV_ALGO_WINOGRAD4, CONV_ALGO_WINOGRAD4H = 0, 1, 2, 3, 4
 _ALGO_REQUEST = threading.local()
 
 

@@ -28,7 +28,7 @@ def main():
     torch.cuda.synchronize()
     agg = collections.OrderedDict()
     for r in ops.PROFILE:
-        k = (r['ks'], r['mode'], r['Cin'], r['Cout'], r['Hout'])
+        k = (r['ks'], r['mode'], r['Cin'], r['Cout'], r['Hout'], r['algo'])
         a = agg.setdefault(k, [0, 0.0, 0.0])
         a[0] += 1
         a[1] += r['e0'].elapsed_time(r['e1'])
@@ -37,7 +37,7 @@ def main():
     tot = 0.0
     for k, (c, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         tot += ms / n
-        print(f"ks={k[0]} mode={k[1]} Cin={k[2]:4d} Cout={k[3]:4d} H={k[4]:4d}  x{c // n:3d}/step  {ms / n:7.3f} ms/step  {ms / c * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s")
+        print(f"ks={k[0]} mode={k[1]} Cin={k[2]:4d} Cout={k[3]:4d} H={k[4]:4d} algo={k[5]}  x{c // n:3d}/step  {ms / n:7.3f} ms/step  {ms / c * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s")
     print(f"all convs: {tot:.2f} ms/step")
 
 

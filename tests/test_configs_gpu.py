@@ -249,7 +249,8 @@ def test_full_1000_step_chain_vs_oracle():
 def test_native_224_chain_vs_oracle_on_the_winograd_path():
     """The reference's native resolution (data/MedSpeckle.py:44-45, drift_noise_model.py:234): 224 = 7 x 32, lower levels 112 / 56 /
     28 are not multiples of the 8x32 / 16x32 patches.  All four levels run on the Winograd kernels with masked partial patches (224 /
-    112 / 56 on F(4x4,3x3), 28x28 -- one patch column wide -- on F(2x2,3x3)); chain parity against the oracle, B=2 batch invariance."""
+    112 / 56 on the 16x32-item F(4x4,3x3) kernel, 28x28 -- one patch column wide -- on its half-patch form); chain parity against the
+    oracle, B=2 batch invariance."""
     T, H = 2, 224
     model, sde = pipeline.build(phase="test", device=torch.device(DEV), T=T, seed=0)
     model.set_eval()
@@ -266,7 +267,7 @@ def test_native_224_chain_vs_oracle_on_the_winograd_path():
         w = ops.pack_conv_weight(torch.randn(C, C, 3, 3, device=DEV) * 0.02)
         ops.conv2d(x, w, None, 3, C, want_stats=True)
         algos[size] = lib.idiff_conv2d_last_algo()
-    assert algos == {224: 3, 112: 3, 56: 3, 28: 1}, algos   # F(4x4,3x3) down to 16 items per sample, F(2x2,3x3) below
+    assert algos == {224: 3, 112: 3, 56: 3, 28: 4}, algos   # F(4x4,3x3): 16x32-pixel items down to 16 per sample, 8x32 items below
     out2 = _chain(model, b2, x_T, noises)
     out1 = _chain(model, {k: v[1:] for k, v in b2.items()}, x_T[1:], noises[:, 1:].contiguous())
     assert torch.equal(out2[1:], out1)

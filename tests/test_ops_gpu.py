@@ -439,12 +439,15 @@ def test_conv_winograd_random_shapes_match_direct():
 # ---------------------------------------------------------------------------------------------------
 # Winograd F(4x4,3x3) kernel (conv_wino4.hip): 16x32-pixel items, 6x6 transforms.  fp32 with transform constants up to 8:
 # about one decimal digit less than F(2x2,3x3) (tolerance 4e-5 of the output range, measured ~1e-5).
-@pytest.fixture
-def force_wino4():
-    """every 3x3 conv of the test asks for the F(4x4,3x3) kernel through the per-call idiff_conv_desc.algo_request (the library's own
-    choice keeps layers with fewer than 16 items per sample on F(2x2,3x3))"""
-    with ops.request_conv3x3_algo(ops.CONV_ALGO_WINOGRAD4):
-        yield ops._lib.load()
+@pytest.fixture(params=[ops.CONV_ALGO_WINOGRAD4, ops.CONV_ALGO_WINOGRAD4H], ids=["patch16x32", "halfpatch8x32"])
+def force_wino4(request):
+    """every 3x3 conv of the test asks for one of the two F(4x4,3x3) kernels (conv_wino4.hip: 16x32-pixel items, one workgroup per
+    CU; conv_wino4h.hip: 8x32-pixel items, two workgroups per CU, weights straight into the A operand) through the per-call
+    idiff_conv_desc.algo_request (the library's own choice keeps small layers on other kernels)"""
+    with ops.request_conv3x3_algo(request.param):
+        lib = ops._lib.load()
+        lib.expected_algo = request.param
+        yield lib
 
 
 @pytest.mark.parametrize("B,C0,C1,Cout,H,W,variant", [
@@ -501,7 +504,7 @@ def test_conv_winograd4_matches_direct_and_fp64(force_wino4, B, C0, C1, Cout, H,
         kw.update(res=res.to(DEV), vec=vec.to(DEV), aux=(aux.to(DEV), aa.to(DEV), ab.to(DEV)))
     wd = w.to(DEV)
     out_w, st_w = ops.conv2d(x0.to(DEV), _pack(wd, True, wino4=True), b.to(DEV), 3, Cout, want_stats=True, **kw)
-    assert lib.idiff_conv2d_last_algo() == 3, "the F(4x4,3x3) kernel did not run"
+    assert lib.idiff_conv2d_last_algo() == lib.expected_algo, "the requested F(4x4,3x3) kernel did not run"
     out_d, st_d = ops.conv2d(x0.to(DEV), _pack(wd, False), b.to(DEV), 3, Cout, want_stats=True, algo=ops.CONV_ALGO_DIRECT, **kw)
     assert lib.idiff_conv2d_last_algo() == 0
     _close(out_w, ref, 4e-5, "winograd4")
@@ -536,9 +539,16 @@ def test_conv_winograd4_policy_and_fallback():
     o_d = ops.conv2d(x, wpk, None, 3, 64, algo=ops.CONV_ALGO_DIRECT)
     assert lib.idiff_conv2d_last_algo() == 0
     _close(o_d, F.conv2d(x.double().cpu(), w.double().cpu(), padding=1), 2e-6, "direct by request")
-    big = torch.randn(16, 32, 64, 64, generator=g).to(DEV)   # 8 items per sample: the batch does not count
-    ops.conv2d(big, wpk, None, 3, 64)
-    assert lib.idiff_conv2d_last_algo() == 1
+    big = torch.randn(16, 32, 64, 64, generator=g).to(DEV)   # 8 items of 16x32 per sample (the batch does not count), 16 of 8x32:
+    ref_big = F.conv2d(big.double().cpu(), w.double().cpu(), padding=1)
+    _close(ops.conv2d(big, wpk, None, 3, 64), ref_big, 4e-5, "half-patch kernel by the library's choice")
+    assert lib.idiff_conv2d_last_algo() == 4               # the half-patch form of the F(4x4,3x3) kernel
+    two = ops.conv2d(big[:, :16].contiguous(), wpk, None, 3, 64, src1=big[:, 16:].contiguous())   # same conv as a virtual concat
+    assert lib.idiff_conv2d_last_algo() == 4
+    _close(two, ref_big, 4e-5, "half-patch kernel, two sources")
+    big3 = torch.randn(2, 32, 128, 128, generator=g).to(DEV)
+    ops.conv2d(big3[:, :16].contiguous(), wpk, None, 3, 64, src1=big3[:, 16:].contiguous())
+    assert lib.idiff_conv2d_last_algo() == 4               # two-source layers take the half-patch kernel at every size
     big = torch.randn(3, 32, 128, 128, generator=g).to(DEV)   # 32 items per sample
     out = ops.conv2d(big, wpk, None, 3, 64)
     assert lib.idiff_conv2d_last_algo() == 3
@@ -580,7 +590,7 @@ def test_conv_winograd4_random_shapes_match_direct(force_wino4):
             kw["aux"] = (torch.randn(B, Cout, Ho, Wo, generator=g).to(DEV), torch.randn(B, Cout, generator=g).to(DEV), torch.randn(B, Cout, generator=g).to(DEV))
         tag = f"case {case}: B={B} C0={C0} C1={C1} Cout={Cout} H={H} W={W} up={up} pro={pro}"
         ow, sw = ops.conv2d(x0, _pack(w, True, wino4=True), bias, 3, Cout, src1=x1, want_stats=True, **kw)
-        assert lib.idiff_conv2d_last_algo() == 3, tag
+        assert lib.idiff_conv2d_last_algo() == lib.expected_algo, tag
         od, sd = ops.conv2d(x0, _pack(w, False), bias, 3, Cout, src1=x1, want_stats=True, **kw)
         assert lib.idiff_conv2d_last_algo() == 0, tag
         _close(ow, od.cpu(), 4e-5, tag)
@@ -599,8 +609,8 @@ def test_conv_winograd4_bits_do_not_depend_on_the_batch(force_wino4):
     pro = (torch.randn(B, C0, generator=g).to(DEV), torch.randn(B, C0, generator=g).to(DEV))
     wp = _pack(w, True, wino4=True)
     full, st = ops.conv2d(x, wp, bias, 3, Cout, pro=pro, want_stats=True)
-    assert lib.idiff_conv2d_last_algo() == 3
+    assert lib.idiff_conv2d_last_algo() == lib.expected_algo
     for b in (0, 3, 4):
         one, s1 = ops.conv2d(x[b:b + 1].contiguous(), wp, bias, 3, Cout, pro=(pro[0][b:b + 1].contiguous(), pro[1][b:b + 1].contiguous()), want_stats=True)
-        assert lib.idiff_conv2d_last_algo() == 3
+        assert lib.idiff_conv2d_last_algo() == lib.expected_algo
         assert torch.equal(one[0], full[b]) and torch.equal(s1[0], st[b]), b

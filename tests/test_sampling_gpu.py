@@ -49,7 +49,8 @@ def make_scoremap_branch_visible(model, gamma=0.3, seed=77):
 
 def _long_chain(T, B, H, seed, what, request=None, expect_wino4=()):
     """T-step injected-noise chain (2 UNet forwards + update per step) against the oracle's CPU chain; expect_wino4 lists
-    (Cin, Cout, Hout) conv shapes that must have been served by the F(4x4,3x3) kernel (idiff_conv2d_last_algo() == 3)."""
+    (Cin, Cout, Hout) conv shapes that must have been served by the F(4x4,3x3) kernels (idiff_conv2d_last_algo() 3 = 16x32-pixel
+    items, 4 = half-patch form)."""
     model, sde = pipeline.build(phase="test", device=torch.device(DEV), T=T, seed=0)
     model.set_eval()
     make_scoremap_branch_visible(model)
@@ -70,8 +71,8 @@ def _long_chain(T, B, H, seed, what, request=None, expect_wino4=()):
         ops.ALGO_TRACE = None
     for cin, cout, hout in expect_wino4:
         served = {k[0] for k in trace if k[1] == 3 and k[2] == cin and k[3] == cout and k[4] == hout}
-        assert served == {3}, f"{what}: conv {cin}->{cout} at {hout} ran on algos {served}, expected F(4x4,3x3) only"
-    n4 = sum(v for k, v in trace.items() if k[0] == 3)
+        assert served and served <= {3, 4}, f"{what}: conv {cin}->{cout} at {hout} ran on algos {served}, expected the F(4x4,3x3) kernels only"
+    n4 = sum(v for k, v in trace.items() if k[0] in (3, 4))
     n2 = sum(v for k, v in trace.items() if k[0] == 1)
     out = torch.from_numpy(model.get_visuals())
     assert out.shape == (B, 1, H, H) and torch.isfinite(out).all()
