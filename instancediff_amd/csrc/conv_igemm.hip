@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     // flattened 1x1 tiles are 256 contiguous pixels per channel: 16-byte staging, and an epilogue that transposes the
     // [BM][256+4] output tile through the (then idle) staging buffers -- the tables below sit past that tile
     constexpr bool VIN = KS == 1 && TWL == 8 && MODE == IDIFF_CONV_NORMAL;
-    constexpr int TABOFF = (VIN && BM * 260 > 2 * BUF) ? BM * 260 : 2 * BUF;
+    constexpr int TABOFF = (VIN && 32 * 260 > 2 * BUF) ? 32 * 260 : 2 * BUF;
     float* protab = smem + TABOFF;  // [2][C0r] GroupNorm/FiLM affine of this sample (only when pro_a)
     float* econst = protab + (a.pro_a ? 2 * a.C0r : 0);  // [4][BM] bias, vec, aux_a, aux_b of this block's channels
 
@@ -336,38 +336,40 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         // global access of the epilogue is a 16-byte-per-lane, 1-KB-per-wave row segment (the C layout itself would give
         // 128-byte segments).  No GroupNorm partials on this path (idiff_conv2d_fwd keeps those layers on 8x32 patches).
         constexpr int OLD = 256 + 4;  // row pitch: 16-byte aligned rows, conflict-free column writes
+        // One 32-channel half at a time ([32][260] floats = 33 KB, inside the staging buffers' 40 KB): the whole [64][260] tile
+        // would make the epilogue, not the main loop, set the workgroup's LDS footprint (66.5 KB: two workgroups per CU).  At
+        // 41.5 KB three are resident -- the registers' limit -- i.e. 48 KB of loads in flight per CU instead of 32 KB, which is what
+        // an HBM-bound kernel is paced by (profiles/r03: 3.0 -> TB/s of the residual 1x1 convs).
         float* const ot = smem;
-        __syncthreads();  // the main loop's last LDS reads are done
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int col = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) ot[col * OLD + wave * 64 + nb * 32 + l31] = acc[mb][nb][r];
-            }
-        __syncthreads();
         const bool has_res = resb != nullptr, has_aux = auxb != nullptr;
         const long long pix0 = (long long)y0 * a.Wout + x0;  // tile start (Hout == 1: x0)
-        auto rows = [&](auto res_tag, auto aux_tag) {
+        auto rows = [&](int mb, auto res_tag, auto aux_tag) {
             constexpr bool RES = decltype(res_tag)::value, AUX = decltype(aux_tag)::value;
-            constexpr int STEPS = BM * 64 / 256;  // float4 per thread
+            constexpr int STEPS = 32 * 64 / 256;  // float4 per thread and half
             floatx4 nres = {0.f, 0.f, 0.f, 0.f}, naux = {0.f, 0.f, 0.f, 0.f};
             auto fetch = [&](int i) {
                 const int f = tid + i * 256;
-                const int row = f >> 6, c4 = (f & 63) * 4;
+                const int row = mb * 32 + (f >> 6), c4 = (f & 63) * 4;
                 const long long o = (co0 + row < a.Cout) ? (long long)(co0 + row) * HWo + pix0 + c4 : pix0 + c4;
                 if (RES) nres = *reinterpret_cast<const floatx4*>(resb + o);
                 if (AUX) naux = *reinterpret_cast<const floatx4*>(auxb + o);
             };
-            fetch(0);
+            fetch(0);  // requested before the barrier below: in flight while the half tile is written to LDS
+            __syncthreads();  // every wave is done reading the buffers this half overwrites (main loop / previous half)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) ot[col * OLD + wave * 64 + nb * 32 + l31] = mb ? acc[MB - 1][nb][r] : acc[0][nb][r];
+            }
+            __syncthreads();
 #pragma unroll
             for (int i = 0; i < STEPS; ++i) {
                 const int f = tid + i * 256;
-                const int row = f >> 6, c4 = (f & 63) * 4;
+                const int lrow = f >> 6, row = mb * 32 + lrow, c4 = (f & 63) * 4;
                 const floatx4 cres = nres, caux = naux;
                 if (i + 1 < STEPS) fetch(i + 1);
-                floatx4 v = *reinterpret_cast<const floatx4*>(ot + row * OLD + c4);
+                floatx4 v = *reinterpret_cast<const floatx4*>(ot + lrow * OLD + c4);
                 const float add = econst[row] + econst[BM + row];  // bias + per-(b,c) vector
                 v = floatx4{v.x + add, v.y + add, v.z + add, v.w + add};
                 if (RES) v = floatx4{v.x + cres.x, v.y + cres.y, v.z + cres.z, v.w + cres.w};
@@ -379,12 +381,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                 if (co0 + row < a.Cout) *reinterpret_cast<floatx4*>(outb + (long long)(co0 + row) * HWo + pix0 + c4) = v;
             }
         };
+        auto halves = [&](auto res_tag, auto aux_tag) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) rows(mb, res_tag, aux_tag);
+        };
         if (has_res) {
-            if (has_aux) rows(std::true_type{}, std::true_type{});
-            else rows(std::true_type{}, std::false_type{});
+            if (has_aux) halves(std::true_type{}, std::true_type{});
+            else halves(std::true_type{}, std::false_type{});
         } else {
-            if (has_aux) rows(std::false_type{}, std::true_type{});
-            else rows(std::false_type{}, std::false_type{});
+            if (has_aux) halves(std::false_type{}, std::true_type{});
+            else halves(std::false_type{}, std::false_type{});
         }
         return;
     }
@@ -496,7 +502,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     constexpr int IN_TILE = ((CK * TRH * RS + 3) / 4) * 4;
     constexpr int W_TILE = KS * KS * CK * BM;
     size_t taboff = (size_t)2 * (IN_TILE + W_TILE);
-    if (KS == 1 && TWL == 8 && MODE == IDIFF_CONV_NORMAL && (size_t)BM * 260 > taboff) taboff = (size_t)BM * 260;  // = TABOFF of the kernel
+    if (KS == 1 && TWL == 8 && MODE == IDIFF_CONV_NORMAL && (size_t)32 * 260 > taboff) taboff = (size_t)32 * 260;  // = TABOFF of the kernel
     const size_t lds = (taboff + (a.pro_a ? 2 * (size_t)a.C0r : 0) + 4 * BM) * sizeof(float);
     if (lds > 160 * 1024) IDIFF_FAIL(IDIFF_E_UNSUPPORTED, "conv2d: LDS budget exceeded (%zu bytes)", lds);
     static size_t attr_set = 0;
