@@ -287,6 +287,59 @@ __global__ __launch_bounds__(256) void scoremap_kernel(const float* __restrict__
     }
 }
 
+// Streaming form: 4 consecutive pixels per thread (16-byte loads, a 1-KB row segment per wave and channel), four channels of loads
+// in flight per thread.  The one-pixel-per-thread form above walked the channels with one dependent 4-byte load each and ran at
+// 1.25 TB/s (profiles/r03/pmc_kernels); it stays for shapes whose rows are not 16-byte aligned.
+__global__ __launch_bounds__(256) void scoremap4_kernel(const float* __restrict__ feat, long long fbs, const float* __restrict__ tv,
+                                                        float* __restrict__ out, const int* __restrict__ idx, float* __restrict__ sel, int C,
+                                                        int HW, int K) {
+    extern __shared__ float tvn[];  // [K][C]
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = wave; k < K; k += 4) {
+        const float* tr = tv + ((long long)b * K + k) * C;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += tr[c] * tr[c];
+        const float nrm = fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+        for (int c = lane; c < C; c += 64) tvn[k * C + c] = tr[c] / nrm;
+    }
+    __syncthreads();
+    const int p = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (p >= HW) return;  // HW % 4 == 0
+    const float* fb = feat + (long long)b * fbs + p;
+    floatx4 dot[SM_KMAX];
+#pragma unroll
+    for (int k = 0; k < SM_KMAX; ++k) dot[k] = floatx4{0.f, 0.f, 0.f, 0.f};
+    floatx4 n2 = {0.f, 0.f, 0.f, 0.f};
+    auto step = [&](const floatx4 f, int c) {  // same per-pixel operation order as the scalar kernel: c ascending
+        n2 += f * f;
+#pragma unroll
+        for (int k = 0; k < SM_KMAX; ++k)
+            if (k < K) dot[k] += f * tvn[k * C + c];
+    };
+    int c = 0;
+    for (; c + 4 <= C; c += 4) {
+        const floatx4 f0 = *reinterpret_cast<const floatx4*>(fb + (long long)c * HW);
+        const floatx4 f1 = *reinterpret_cast<const floatx4*>(fb + (long long)(c + 1) * HW);
+        const floatx4 f2 = *reinterpret_cast<const floatx4*>(fb + (long long)(c + 2) * HW);
+        const floatx4 f3 = *reinterpret_cast<const floatx4*>(fb + (long long)(c + 3) * HW);
+        step(f0, c), step(f1, c + 1), step(f2, c + 2), step(f3, c + 3);
+    }
+    for (; c < C; ++c) step(*reinterpret_cast<const floatx4*>(fb + (long long)c * HW), c);
+    floatx4 rn;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rn[e] = fmaxf(sqrtf(n2[e]), 1e-12f);
+    const int ksel = idx ? idx[b] : -1;
+#pragma unroll
+    for (int k = 0; k < SM_KMAX; ++k) {
+        if (k < K) {
+            const floatx4 v = floatx4{dot[k].x / rn.x, dot[k].y / rn.y, dot[k].z / rn.z, dot[k].w / rn.w};
+            *reinterpret_cast<floatx4*>(out + ((long long)b * K + k) * HW + p) = v;
+            if (k == ksel) *reinterpret_cast<floatx4*>(sel + (long long)b * HW + p) = v;
+        }
+    }
+}
+
 __global__ void gather_channel_kernel(const float* __restrict__ x, const int* __restrict__ idx, float* __restrict__ out, int B, int C, int HW) {
     const long long total = (long long)B * HW;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -370,8 +423,14 @@ extern "C" int idiff_scoremap_fwd(const float* feat, int64_t feat_bstride, const
     IDIFF_CHECK_ARG(feat && tv && out && B > 0 && C > 0 && HW > 0, "scoremap: bad args");
     IDIFF_CHECK_ARG(K > 0 && K <= SM_KMAX, "scoremap: K must be in 1..%d", SM_KMAX);
     IDIFF_CHECK_ARG((idx == nullptr) == (sel == nullptr), "scoremap: idx/sel must both be set");
-    hipLaunchKernelGGL(scoremap_kernel, dim3((HW + 255) / 256, B), dim3(256), (size_t)K * C * sizeof(float), (hipStream_t)stream, feat,
-                       (long long)feat_bstride, tv, out, idx, sel, C, HW, K);
+    const bool vec4 = HW % 4 == 0 && feat_bstride % 4 == 0 && ((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(out) |
+                                                                reinterpret_cast<uintptr_t>(sel)) & 15) == 0;
+    if (vec4)
+        hipLaunchKernelGGL(scoremap4_kernel, dim3((HW / 4 + 255) / 256, B), dim3(256), (size_t)K * C * sizeof(float), (hipStream_t)stream, feat,
+                           (long long)feat_bstride, tv, out, idx, sel, C, HW, K);
+    else
+        hipLaunchKernelGGL(scoremap_kernel, dim3((HW + 255) / 256, B), dim3(256), (size_t)K * C * sizeof(float), (hipStream_t)stream, feat,
+                           (long long)feat_bstride, tv, out, idx, sel, C, HW, K);
     IDIFF_CHECK_LAUNCH("scoremap");
     return IDIFF_OK;
 }

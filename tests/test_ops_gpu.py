@@ -185,6 +185,23 @@ def test_chan_layernorm_scoremap_gather():
     _close(ops.gather_channel(x.to(DEV), idx.to(DEV)), x[torch.arange(B), idx.long()][:, None], 0, "gather")
 
 
+@pytest.mark.parametrize("B,C,H,W,K,sliced", [(2, 64, 32, 32, 5, True), (1, 130, 8, 12, 5, False), (2, 64, 7, 9, 5, False), (3, 256, 8, 8, 8, True)])
+def test_scoremap_streaming_and_scalar_forms(B, C, H, W, K, sliced):
+    """rows of 16-byte-aligned length take the 4-pixels-per-thread streaming kernel (also on a channel slice of a wider buffer, as the
+    UNet's skip produces it), odd sizes the one-pixel form; both against fp64, and the selected map equals the gathered channel"""
+    g = _g(60 + C)
+    xw = torch.randn(B, C + (16 if sliced else 0), H, W, generator=g) * 1.5 + 0.3
+    tv = torch.randn(B, K, C, generator=g)
+    idx = torch.randint(0, K, (B,), generator=g).to(torch.int32)
+    x = xw[:, :C]
+    ref = torch.einsum('bchw,bkc->bkhw', F.normalize(x.double(), dim=1), F.normalize(tv.double(), dim=2))
+    sm, sel = ops.scoremap(xw.to(DEV)[:, :C], tv.to(DEV), idx.to(DEV))
+    _close(sm, ref, 3e-6, "scoremap")
+    assert torch.equal(sel, ops.gather_channel(sm, idx.to(DEV)))
+    sm2, none = ops.scoremap(xw.to(DEV)[:, :C], tv.to(DEV))
+    assert none is None and torch.equal(sm2, sm)
+
+
 def _attn_ref(q, k, v, heads, scale):
     B, N, C = q.shape
     M = k.shape[1]
