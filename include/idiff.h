@@ -153,6 +153,28 @@ int idiff_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, c
 int idiff_linear_t_fwd(const float* x, int64_t ldx, const float* wT, int64_t ldw, const float* bias, const float* res,
                        int64_t ldr, const float* gscale, float* out, int64_t ldo, int R, int K, int N, int act_in,
                        int act_out, idiff_stream_t stream);
+/* Up to IDIFF_LINEAR_MAX_GROUPS independent idiff_linear_t_fwd / idiff_linear_t_ln_fwd problems (own operands and shapes; ln_g == NULL:
+ * no LayerNorm) in ONE launch: the same token-side linear of the ScoreMapModules of all four UNet levels, or of the heads of one
+ * folded projection.  Latency-bound launches of ~10 us each: one grouped launch costs what one of them did.  The descriptors are
+ * copied into the kernel arguments (nothing is retained).  Matrix-core form only: N % 4 == 0, ldw % 4 == 0, wT 16-byte aligned. */
+#define IDIFF_LINEAR_MAX_GROUPS 16
+typedef struct {
+    const float* x;       /* [R, K], row stride ldx */
+    int64_t ldx;
+    const float* wT;      /* [K, N] pre-transposed weight, row stride ldw */
+    int64_t ldw;
+    const float* bias;    /* [N] or NULL */
+    const float* res;     /* [R, N] residual (row stride ldr) or NULL */
+    int64_t ldr;
+    const float* gscale;  /* [N] per-column gain or NULL */
+    float* out;           /* [R, N], row stride ldo */
+    int64_t ldo;
+    const float* ln_g;    /* LayerNorm over K in front of the product (with ln_b; act_in must be IDIFF_ACT_NONE) or NULL */
+    const float* ln_b;
+    float ln_eps;
+    int32_t R, K, N, act_in, act_out;
+} idiff_linear_group;
+int idiff_linear_t_grouped_fwd(const idiff_linear_group* groups, int ngroups, idiff_stream_t stream);
 /* idiff_linear_t_fwd on LayerNorm(x) (per row over K, parameters ln_g / ln_b [K]): the LayerNorm runs on the rows the
  * kernel has staged anyway -- the LayerNorm -> Linear pairs of the ScoreMapModule decoder in one launch each. */
 int idiff_linear_t_ln_fwd(const float* x, int64_t ldx, const float* ln_g, const float* ln_b, float ln_eps, const float* wT,
@@ -211,6 +233,9 @@ int idiff_attn_ctx_fwd(const float* q, const float* k, const float* v, float* ou
  * (row stride ldkv) -- strides let q/k/v be slices of one packed qkv projection; out [B,Nq,C] dense; Nq,M <= 64 */
 int idiff_attn_tokens_fwd(const float* q, const float* k, const float* v, float* out, int B, int Nq, int M, int C,
                           int heads, float scale, int64_t ldq, int64_t ldkv, idiff_stream_t stream);
+/* idiff_attn_tokens_fwd for ngroups (<= IDIFF_LINEAR_MAX_GROUPS) operand sets of one shape in ONE launch (host arrays of device pointers) */
+int idiff_attn_tokens_grouped_fwd(const float* const* q, const float* const* k, const float* const* v, float* const* out, int ngroups,
+                                  int B, int Nq, int M, int C, int heads, float scale, int64_t ldq, int64_t ldkv, idiff_stream_t stream);
 /* ScoreMapModule cross-attention, K/V projections folded onto the query side:
  *   S[b,h,q,n] = scale * sum_c qf[b,q,h,c] * mem[b,c,n];  P = softmax_n(S);  o[b,q,h,c] = sum_n P * mem[b,c,n]
  * qf, o: [B, Nq, heads, Cm];  mem: [B, Cm, N] channel-major;  Nq*heads <= 32, Cm in {72, 136, 256}.

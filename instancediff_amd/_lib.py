@@ -35,6 +35,13 @@ class ConvDesc(C.Structure):
     ]
 
 
+class LinearGroup(C.Structure):  # idiff_linear_group
+    _fields_ = [("x", C.c_void_p), ("ldx", C.c_int64), ("wT", C.c_void_p), ("ldw", C.c_int64), ("bias", C.c_void_p), ("res", C.c_void_p),
+                ("ldr", C.c_int64), ("gscale", C.c_void_p), ("out", C.c_void_p), ("ldo", C.c_int64), ("ln_g", C.c_void_p), ("ln_b", C.c_void_p),
+                ("ln_eps", C.c_float), ("R", C.c_int32), ("K", C.c_int32), ("N", C.c_int32), ("act_in", C.c_int32), ("act_out", C.c_int32)]
+
+
+LINEAR_MAX_GROUPS = 16
 P, I, I64, F, U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 
 # name -> (restype, argtypes); must list every function declared in include/idiff.h
@@ -55,6 +62,8 @@ SIGNATURES = {
     "idiff_linear_fwd": (I, [P, I64, P, I64, P, P, I64, P, P, I64, I, I, I, I, I, c_stream]),
     "idiff_linear_t_fwd": (I, [P, I64, P, I64, P, P, I64, P, P, I64, I, I, I, I, I, c_stream]),
     "idiff_linear_t_ln_fwd": (I, [P, I64, P, P, F, P, I64, P, P, I64, P, P, I64, I, I, I, I, c_stream]),
+    "idiff_linear_t_grouped_fwd": (I, [C.POINTER(LinearGroup), I, c_stream]),
+    "idiff_attn_tokens_grouped_fwd": (I, [C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P), I, I, I, I, I, I, F, I64, I64, c_stream]),
     "idiff_linear_t_heads_fwd": (I, [P, I64, I64, P, I64, I64, P, I64, P, I64, I64, I, I, I, I, c_stream]),
     "idiff_smm_memproj_fwd": (I, [P, I64, P, P, P, P, P, P, P, I, I, I, F, c_stream]),
     "idiff_smm_memproj_compact_fwd": (I, [P, I64, P, P, P, P, F, P, I, I, I, I, F, F, c_stream]),

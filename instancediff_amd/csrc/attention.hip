@@ -346,6 +346,41 @@ __global__ __launch_bounds__(64) void attn_tokens_kernel(const float* __restrict
     }
 }
 
+// grouped form (idiff_attn_tokens_grouped_fwd): blockIdx.y picks one of up to IDIFF_LINEAR_MAX_GROUPS operand sets of the same shape
+struct AttnTokGroups {
+    const float* q[IDIFF_LINEAR_MAX_GROUPS];
+    const float* k[IDIFF_LINEAR_MAX_GROUPS];
+    const float* v[IDIFF_LINEAR_MAX_GROUPS];
+    float* out[IDIFF_LINEAR_MAX_GROUPS];
+};
+__global__ __launch_bounds__(64) void attn_tokens_grouped_kernel(const AttnTokGroups g, int Nq, int M, int C, int heads, float scale, long long ldq,
+                                                                 long long ldkv) {
+    const float* __restrict__ q = g.q[blockIdx.y];
+    const float* __restrict__ k = g.k[blockIdx.y];
+    const float* __restrict__ v = g.v[blockIdx.y];
+    float* __restrict__ out = g.out[blockIdx.y];
+    const int dh = C / heads;
+    const int n = blockIdx.x % Nq, h = (blockIdx.x / Nq) % heads, b = blockIdx.x / (Nq * heads);
+    const int lane = threadIdx.x;
+    const float* qp = q + ((long long)b * Nq + n) * ldq + h * dh;
+    float s = -INFINITY;
+    if (lane < M) {
+        const float* kp = k + ((long long)b * M + lane) * ldkv + h * dh;
+        float acc = 0.f;
+        for (int d = 0; d < dh; ++d) acc += qp[d] * kp[d];
+        s = acc * scale;
+    }
+    const float mx = wave_max(s);
+    const float p = lane < M ? __expf(s - mx) : 0.f;
+    const float l = wave_sum(p);
+    const float pn = p / l;
+    float* op = out + ((long long)b * Nq + n) * C + h * dh;
+    for (int d = 0; d < dh; ++d) {
+        const float t = wave_sum(lane < M ? pn * v[((long long)b * M + lane) * ldkv + h * dh + d] : 0.f);
+        if (lane == 0) op[d] = t;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // ScoreMapModule cross attention, Cm = 4*XCW in {72, 136, 256}, rows = Nq*heads <= 32.  XCW = channels per wave
 // (even); the P.V product runs on whole 32-channel blocks, so a wave's LDS slice is padded to XCB*32 rows
@@ -570,6 +605,24 @@ extern "C" int idiff_attn_tokens_fwd(const float* q, const float* k, const float
     hipLaunchKernelGGL(attn_tokens_kernel, dim3(B * heads * Nq), dim3(64), 0, (hipStream_t)stream, q, k, v, out, Nq, M, C, heads, scale,
                        (long long)ldq, (long long)ldkv);
     IDIFF_CHECK_LAUNCH("attn_tokens_fwd");
+    return IDIFF_OK;
+}
+
+extern "C" int idiff_attn_tokens_grouped_fwd(const float* const* q, const float* const* k, const float* const* v, float* const* out, int ngroups,
+                                             int B, int Nq, int M, int C, int heads, float scale, int64_t ldq, int64_t ldkv, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(q && k && v && out && ngroups >= 1 && ngroups <= IDIFF_LINEAR_MAX_GROUPS, "attn_tokens_grouped: 1..%d groups", IDIFF_LINEAR_MAX_GROUPS);
+    IDIFF_CHECK_ARG(B > 0 && Nq > 0 && C > 0 && heads > 0 && C % heads == 0, "attn_tokens_grouped: bad args");
+    IDIFF_CHECK_ARG(M >= 1 && M <= 64, "attn_tokens_grouped: M must be in 1..64 (got %d)", M);
+    IDIFF_CHECK_ARG(ldq >= C && ldkv >= C, "attn_tokens_grouped: row strides must be >= C");
+    AttnTokGroups g;
+    memset(&g, 0, sizeof(g));
+    for (int i = 0; i < ngroups; ++i) {
+        IDIFF_CHECK_ARG(q[i] && k[i] && v[i] && out[i], "attn_tokens_grouped: group %d: null pointer", i);
+        g.q[i] = q[i], g.k[i] = k[i], g.v[i] = v[i], g.out[i] = out[i];
+    }
+    hipLaunchKernelGGL(attn_tokens_grouped_kernel, dim3(B * heads * Nq, ngroups), dim3(64), 0, (hipStream_t)stream, g, Nq, M, C, heads, scale,
+                       (long long)ldq, (long long)ldkv);
+    IDIFF_CHECK_LAUNCH("attn_tokens_grouped_fwd");
     return IDIFF_OK;
 }
 

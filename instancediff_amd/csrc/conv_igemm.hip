@@ -26,6 +26,7 @@ using idiff_detail::ConvArgs;
 
 namespace {
 
+typedef float floatx2 __attribute__((ext_vector_type(2)));
 
 // SPEC: 0 = generic (prologue / second source decided at run time); 1 = single source, no prologue;
 //       2 = single source + GN/SiLU prologue; 3 = two sources, no prologue.  The specialised forms drop the per-element
@@ -127,6 +128,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 
     const int nchunks = (a.Cin + CK - 1) / CK;
     const float* const sample0 = a.src0 + (long long)b * a.bs0;  // always-valid address for masked lanes
+    // 8-byte gathers of the pixel-unshuffle path need even strides and an 8-byte-aligned base (uniform)
+    const bool un2 = MODE == IDIFF_CONV_UNSHUFFLE2 && ((reinterpret_cast<uintptr_t>(a.src0) & 7) == 0) && (a.bs0 & 1) == 0 && (a.Win & 1) == 0 &&
+                     (NL & 1) == 0;
 
     // issue the global loads of chunk cc (no dependent arithmetic here: the MFMAs of the current chunk run
     // while these are in flight).  Masked elements load a valid dummy address and are zeroed at write time.
@@ -152,6 +156,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                 const bool v = gval[i] && ch < a.Cin;
                 const float* p = v ? (ch < a.C0v ? base0 : base1) + goff[i] : sample0;
                 rin[i] = *p;
+            }
+        } else if (MODE == IDIFF_CONV_UNSHUFFLE2 && KS == 1 && un2) {
+            // pixel-unshuffle: virtual channels 2j and 2j+1 of a chunk are the two x-neighbours of one input row, element i of a
+            // thread is channel i of its pixel (PS = 256): one 8-byte load serves both (lanes then read contiguous 8-byte pieces;
+            // the 4-byte form read every line twice at a stride of two floats: 1.6 TB/s, profiles/r03/pmc_kernels)
+#pragma unroll
+            for (int i = 0; i + 1 < NL; i += 2) {
+                const int off = (gval[i] && cb + i < a.Cin) ? goff[i] : 0;
+                const floatx2 v = *reinterpret_cast<const floatx2*>(base0 + off);
+                rin[i] = v.x;
+                rin[i + 1] = v.y;
             }
         } else {
             // single source: uniform (scalar) base + 32-bit per-lane offset; masked lanes read base0[0] (in range: cb < Cin)

@@ -343,22 +343,19 @@ __global__ __launch_bounds__(256) void linear_t_kernel(const float* __restrict__
 //   (each output element is one fixed-order chain), so a token row's result does not depend on the batch around it.
 // ---------------------------------------------------------------------------------------------------
 constexpr int LM_ROWS = 16, LM_WAVES = 8, LM_KPAD = 4;
-__global__ __launch_bounds__(512) void linear_t_mfma_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ wT, long long ldw,
-                                                            const float* __restrict__ bias, const float* __restrict__ res, long long ldr,
-                                                            const float* __restrict__ gscale, float* __restrict__ out, long long ldo, int R, int K,
-                                                            int N, int act_in, int act_out, long long x_hs, long long w_hs, long long b_hs,
-                                                            long long o_hs, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
-                                                            float ln_eps) {
-    x += blockIdx.z * x_hs;
-    wT += blockIdx.z * w_hs;
-    if (bias) bias += blockIdx.z * b_hs;
-    out += blockIdx.z * o_hs;
+// body shared by the single launch (blockIdx.z = head of a per-head batch) and the grouped launch (blockIdx.z = group): bx / by are
+// the 64-feature block and the 16-row block of this workgroup
+__device__ __forceinline__ void linear_t_mfma_body(const float* __restrict__ x, long long ldx, const float* __restrict__ wT, long long ldw,
+                                                   const float* __restrict__ bias, const float* __restrict__ res, long long ldr,
+                                                   const float* __restrict__ gscale, float* __restrict__ out, long long ldo, int R, int K, int N,
+                                                   int act_in, int act_out, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                   float ln_eps, int bx, int by) {
     extern __shared__ __attribute__((aligned(16))) float lm_smem[];
     const int KS = K + LM_KPAD;                         // padded row stride: rows land 4 banks apart
     float* xs = lm_smem;                                // [16][KS] activated (and normalised) input rows
     float* red = lm_smem + LM_ROWS * KS;                // [8 waves][4 mfma][64 lanes][4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r0 = blockIdx.y * LM_ROWS, n0 = blockIdx.x * 64;
+    const int r0 = by * LM_ROWS, n0 = bx * 64;
     for (int i = tid; i < LM_ROWS * K; i += 512) {
         const int r = i / K, k = i - r * K;
         const int rr = r0 + r < R ? r0 + r : R - 1;
@@ -440,7 +437,63 @@ __global__ __launch_bounds__(512) void linear_t_mfma_kernel(const float* __restr
     }
 }
 
+__global__ __launch_bounds__(512) void linear_t_mfma_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ wT, long long ldw,
+                                                            const float* __restrict__ bias, const float* __restrict__ res, long long ldr,
+                                                            const float* __restrict__ gscale, float* __restrict__ out, long long ldo, int R, int K,
+                                                            int N, int act_in, int act_out, long long x_hs, long long w_hs, long long b_hs,
+                                                            long long o_hs, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                            float ln_eps) {
+    x += blockIdx.z * x_hs;
+    wT += blockIdx.z * w_hs;
+    if (bias) bias += blockIdx.z * b_hs;
+    out += blockIdx.z * o_hs;
+    linear_t_mfma_body(x, ldx, wT, ldw, bias, res, ldr, gscale, out, ldo, R, K, N, act_in, act_out, ln_g, ln_b, ln_eps, blockIdx.x, blockIdx.y);
+}
+
+// Grouped launch (idiff_linear_t_grouped_fwd): blockIdx.z picks one of up to IDIFF_LINEAR_MAX_GROUPS independent problems -- own
+// operands, own shape -- from a descriptor array that travels in the kernel arguments (uniform scalar loads; no device-side table
+// to keep alive or to update under HIP-graph capture).  The grid covers the largest problem; blocks outside a smaller one exit.
+struct LinGroups {
+    idiff_linear_group g[IDIFF_LINEAR_MAX_GROUPS];
+};
+__global__ __launch_bounds__(512) void linear_t_mfma_grouped_kernel(const LinGroups args) {
+    const idiff_linear_group& d = args.g[blockIdx.z];
+    if ((int)blockIdx.x * 64 >= d.N || (int)blockIdx.y * LM_ROWS >= d.R) return;  // uniform
+    linear_t_mfma_body(d.x, d.ldx, d.wT, d.ldw, d.bias, d.res, d.ldr, d.gscale, d.out, d.ldo, d.R, d.K, d.N, d.act_in, d.act_out, d.ln_g, d.ln_b,
+                       d.ln_eps, blockIdx.x, blockIdx.y);
+}
+
 }  // namespace
+
+extern "C" int idiff_linear_t_grouped_fwd(const idiff_linear_group* groups, int ngroups, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(groups && ngroups >= 1 && ngroups <= IDIFF_LINEAR_MAX_GROUPS, "linear_t_grouped: 1..%d groups", IDIFF_LINEAR_MAX_GROUPS);
+    LinGroups args;
+    memset(&args, 0, sizeof(args));
+    int gx = 0, gy = 0, kmax = 0;
+    for (int i = 0; i < ngroups; ++i) {
+        const idiff_linear_group& d = groups[i];
+        IDIFF_CHECK_ARG(d.x && d.wT && d.out && d.R > 0 && d.K > 0 && d.N > 0, "linear_t_grouped: group %d: bad args", i);
+        IDIFF_CHECK_ARG(d.ldx >= d.K && d.ldw >= d.N && d.ldo >= d.N && (!d.res || d.ldr >= d.N), "linear_t_grouped: group %d: bad leading dims", i);
+        IDIFF_CHECK_ARG((d.ln_g == nullptr) == (d.ln_b == nullptr) && !(d.ln_g && d.act_in != IDIFF_ACT_NONE), "linear_t_grouped: group %d: LayerNorm", i);
+        IDIFF_CHECK_ARG(d.N % 4 == 0 && d.ldw % 4 == 0 && (reinterpret_cast<uintptr_t>(d.wT) & 15) == 0,
+                        "linear_t_grouped: group %d: the grouped launch is the matrix-core form (N %% 4 == 0, 16-byte aligned weight rows)", i);
+        args.g[i] = d;
+        gx = max(gx, (d.N + 63) / 64);
+        gy = max(gy, (d.R + LM_ROWS - 1) / LM_ROWS);
+        kmax = max(kmax, d.K);
+    }
+    const size_t lds = ((size_t)LM_ROWS * (kmax + LM_KPAD) + (size_t)LM_WAVES * 4 * 64 * 4) * sizeof(float);
+    IDIFF_CHECK_ARG(lds <= 160 * 1024, "linear_t_grouped: K too large (%d)", kmax);
+    static size_t attr = 0;
+    if (lds > 64 * 1024 && lds > attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_t_mfma_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "linear_t_grouped: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr = lds;
+    }
+    hipLaunchKernelGGL(linear_t_mfma_grouped_kernel, dim3(gx, gy, ngroups), dim3(512), lds, (hipStream_t)stream, args);
+    IDIFF_CHECK_LAUNCH("linear_t_grouped_fwd");
+    return IDIFF_OK;
+}
 
 extern "C" int idiff_smm_memproj_fwd(const float* feat, int64_t feat_bstride, const float* ln1_g, const float* ln1_b, const float* wpk,
                                      const float* bias, const float* ln2_g, const float* ln2_b, float* out, int B, int C, int N, float eps,

@@ -13,7 +13,6 @@ include/idiff.h via instancediff_amd.ops.  There is no ATen fallback: on a machi
 library or without a GPU, forward() raises.
 """
 import math
-import os
 import weakref
 
 import torch
@@ -57,17 +56,18 @@ class _Prepared:
         slot[name] = (sig, val)
         return val
 
+    def peek(self, key, params):
+        """the cached value if it is current, else None (nothing is built)"""
+        owner, name = key[1], key[0]
+        sig = (_weight_epoch(),) + tuple((p.data_ptr(), p._version) for p in params)
+        hit = self.store.get(owner, {}).get(name)
+        return hit[1] if hit is not None and hit[0] == sig else None
+
     def clear(self):
         self.store = weakref.WeakKeyDictionary()
 
 
 _PREP = _Prepared()
-
-# IDIFF_SMM_SIDE_STREAM=1 moves each net's ScoreMapModules to a side stream.  Off by default: with the two nets already on
-# two streams it measured slower (40.1 vs 38.2 ms/step at c2: four streams contend for the CUs the persistent conv
-# workgroups hold); it only pays when the nets share one stream (41.6 vs 42.3 ms/step).
-SMM_SIDE_STREAM = bool(int(os.environ.get("IDIFF_SMM_SIDE_STREAM", "0")))
-
 
 def packed(conv):
     return _PREP.get(("pk", conv), (conv.weight,), lambda: ops.pack_conv_weight(conv.weight.detach().contiguous()))
@@ -223,86 +223,148 @@ class ScoreMapModule(nn.Module):
 
     def _decoder_tokens(self, feat, text, cache_prefix=True, plain_out=False):
         """tv [B*K, C] = text_to_visual(text) + gamma * out_proj(LN(x_L)) with x_L the decoder state after the last
-        TransformerDecoderLayer (plain_out: out_proj(LN(x_L)) alone).  Launches: the fused memory projection, then per layer one
-        cross-attention over the feature map (idiff_smm_xattn_fwd) and the token-side linears on the matrix cores (idiff_linear_t*:
-        80 workgroups per launch; a one-workgroup-per-sample fusion of the whole chain was measured and is slower)."""
-        B, C, H, W = feat.shape
-        K = text.shape[1]
-        dec = self.context_decoder
-        Wd, heads = dec.width, dec.heads
-        dh = Wd // heads
-        t2d = text.reshape(B * K, self.text_dim)
-        # memory = LN(Linear(LN(feature tokens))), one fused pass (channel-major: [B, Wd, h*w])
+        TransformerDecoderLayer (plain_out: out_proj(LN(x_L)) alone): decoder_tokens_grouped for this module alone."""
+        return decoder_tokens_grouped([self], [feat], [text], cache_prefix=cache_prefix, plain_out=plain_out)[0]
+
+
+def decoder_tokens_grouped(smms, feats, texts, cache_prefix=True, plain_out=False):
+    """The ContextDecoder token chains of SEVERAL ScoreMapModules (the four UNet levels of a net) advanced in lock step: every
+    token-side operation -- the same [B*K, 256]-row linear / attention of each module, with its own weights and, where the level's
+    channel count enters, its own shape -- is ONE grouped launch for all modules (idiff_linear_t_grouped_fwd,
+    idiff_attn_tokens_grouped_fwd: the descriptors travel in the kernel arguments).  These launches are latency-bound (~10 us each
+    whatever the row count), so a net's four chains cost 23 token launches instead of 92.  Per module and layer there remain the
+    passes over the feature map: the fused memory projection and the cross-attention (idiff_smm_xattn_fwd).
+    Returns, per module, tv [B*K, C] = text_to_visual(text) + gamma * out_proj(LN(x_L))   (plain_out: out_proj(LN(x_L)))."""
+    L = len(smms)
+    dec0 = smms[0].context_decoder
+    Wd, heads, nlayers = dec0.width, dec0.heads, len(dec0.decoder)
+    dh = Wd // heads
+    for m in smms:
+        d = m.context_decoder
+        assert (d.width, d.heads, len(d.decoder)) == (Wd, heads, nlayers), "grouped ScoreMapModules must share the decoder geometry"
+    dev = feats[0].device
+    B = feats[0].shape[0]
+    K = texts[0].shape[1]
+    R = B * K
+
+    st = []  # per module: dict(dec, C, Cm, compact, mem, mp)
+    for m, feat, text in zip(smms, feats, texts):
+        Bm, C, H, W = feat.shape
+        assert Bm == B and text.shape[1] == K
+        dec = m.context_decoder
         mp = dec.memory_proj
-        wmp = _PREP.get(("mp", mp[1]), (mp[1].weight,),
-                        lambda: ops.pack_conv_weight(mp[1].weight.detach().reshape(Wd, C, 1, 1).contiguous()))
         # Narrow feature maps: LN_256(W.xhat + b) = g2 * ((Wc.xhat + bc) * rstd) + b2 is an affine image of the (C+1)-vector
         # m = [xhat*rstd ; rstd], so the cross-attention streams m (Cm = 72 / 136 rows) instead of the 256-row memory and
         # g2.[Wc|bc] is folded into its query / value projections (b2 drops out of the softmax and returns as a bias).
         Cm = Wd if C + 1 > 136 else (72 if C + 1 <= 72 else 136)
         compact = Cm < Wd
         if compact:
-            gram, hvec, evar = _PREP.get(("mpvar", mp[1]), (mp[1].weight, mp[1].bias), lambda: ops.memory_variance_form(mp[1].weight, mp[1].bias))
+            gram, hvec, evar = _PREP.get(("mpvar", mp[1]), (mp[1].weight, mp[1].bias), lambda mp=mp: ops.memory_variance_form(mp[1].weight, mp[1].bias))
             mem = ops.smm_memproj_compact(feat, mp[0].weight, mp[0].bias, gram, hvec, evar, Cm, eps1=mp[0].eps, eps2=mp[2].eps)
         else:
+            wmp = _PREP.get(("mp", mp[1]), (mp[1].weight,),
+                            lambda mp=mp, C=C: ops.pack_conv_weight(mp[1].weight.detach().reshape(Wd, C, 1, 1).contiguous()))
             mem = ops.smm_memproj(feat, mp[0].weight, mp[0].bias, wmp, mp[1].bias, mp[2].weight, mp[2].bias, eps=mp[0].eps)
-        def fold_weights(ca):
-            if compact:
-                return _PREP.get(("xfold", ca, Cm), (mp[1].weight, mp[1].bias, mp[2].weight, mp[2].bias, ca.k_proj.weight, ca.v_proj.weight),
-                                 lambda: _fold_memory_affine(mp[1], mp[2], ca, Cm))
-            return ca.k_proj.weight, wT(ca.v_proj), None  # [Wd(dh blocks), Wd], [Wd (c), Wd (n)]
+        st.append(dict(m=m, dec=dec, C=C, Cm=Cm, compact=compact, mem=mem, mp=mp, t2d=text.reshape(R, m.text_dim)))
 
-        def self_attn_and_query(x, layer):
-            """x -> (x + self-attention, folded cross-attention queries qf [B*K, heads*Cm]); nothing here sees the image"""
-            sa, ca = layer.self_attn, layer.cross_attn
-            wqkvT = _PREP.get(("qkvT", sa), (sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight),
-                              lambda: torch.cat([sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight], 0).detach().t().contiguous())
-            qkv = ops.linear_t(x, wqkvT, ln=(layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)).reshape(B, K, 3 * Wd)
-            a = ops.attn_tokens_packed(qkv, heads, sa.scale)
-            x = ops.linear_t(a.reshape(B * K, Wd), wT(sa.proj), sa.proj.bias, res=x)
-            # cross attention, k/v projections folded onto the (few) queries:
-            #   qf[:, h, :] = q_h @ Wk[h*dh:(h+1)*dh, :]   (Wk's row block IS the transposed-weight form [K=dh][N=Wd])
-            qc = ops.linear_t(x, wT(ca.q_proj), ln=(layer.norm2.weight, layer.norm2.bias, layer.norm2.eps))
-            wkf = fold_weights(ca)[0]
-            # per head: qf[:, h-block] = qc[:, h-block] @ wkf[h row block]  ([dh, Cm]);  one launch for all heads
-            qf = torch.empty((B * K, heads * Cm), device=feat.device, dtype=torch.float32)
-            ops.linear_t_heads(qc, wkf, None, qf, heads, dh, Cm, x_hs=dh, w_hs=dh * wkf.stride(0), b_hs=0, o_hs=Cm)
-            return x, qf
+    def fold_weights(s, ca):
+        mp, Cm = s["mp"], s["Cm"]
+        if s["compact"]:
+            return _PREP.get(("xfold", ca, Cm), (mp[1].weight, mp[1].bias, mp[2].weight, mp[2].bias, ca.k_proj.weight, ca.v_proj.weight),
+                             lambda: _fold_memory_affine(mp[1], mp[2], ca, Cm))
+        return ca.k_proj.weight, wT(ca.v_proj), None  # [Wd(dh blocks), Wd], [Wd (c), Wd (n)]
 
-        def text_prefix():
-            """Everything up to the first cross-attention depends on the text embeddings and weights only: text_proj, the
-            first layer's self-attention and folded queries, and text_to_visual.  Cached across denoising steps."""
-            tp = dec.text_proj
-            x0 = ops.linear_t(t2d, wT(tp[1]), tp[1].bias, ln=(tp[0].weight, tp[0].bias, tp[0].eps))  # LayerNorm fused; [B*K, Wd]
-            x1, qf1 = self_attn_and_query(x0, dec.decoder[0])
-            return x1, qf1, ops.linear_t(t2d, wT(self.text_to_visual), self.text_to_visual.bias)
+    def self_attn_and_query(sel, xs, li):
+        """modules sel (indices into st), states xs -> (xs + self-attention, folded cross-attention queries qf [B*K, heads*Cm]);
+        nothing here sees the image.  Five grouped launches."""
+        lay = [st[i]["dec"].decoder[li] for i in sel]
+        qkv = ops.linear_t_grouped([dict(x=x, wT=_PREP.get(("qkvT", l.self_attn), (l.self_attn.q_proj.weight, l.self_attn.k_proj.weight, l.self_attn.v_proj.weight),
+                                                             lambda sa=l.self_attn: torch.cat([sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight], 0).detach().t().contiguous()),
+                                         ln=(l.norm1.weight, l.norm1.bias, l.norm1.eps)) for x, l in zip(xs, lay)])
+        att = ops.attn_tokens_packed_grouped([q.reshape(B, K, 3 * Wd) for q in qkv], heads, lay[0].self_attn.scale)
+        xs = ops.linear_t_grouped([dict(x=a.reshape(R, Wd), wT=wT(l.self_attn.proj), bias=l.self_attn.proj.bias, res=x) for a, l, x in zip(att, lay, xs)])
+        qc = ops.linear_t_grouped([dict(x=x, wT=wT(l.cross_attn.q_proj), ln=(l.norm2.weight, l.norm2.bias, l.norm2.eps)) for x, l in zip(xs, lay)])
+        # cross attention, k/v projections folded onto the (few) queries, per head:
+        #   qf[:, h-block] = qc[:, h-block] @ wkf[h row block]   (Wk's row block IS the transposed-weight form [K=dh][N=Cm])
+        qfs, groups = [], []
+        for i, q, l in zip(sel, qc, lay):
+            Cm = st[i]["Cm"]
+            wkf = fold_weights(st[i], l.cross_attn)[0]
+            qf = torch.empty((R, heads * Cm), device=dev, dtype=torch.float32)
+            qfs.append(qf)
+            groups += [dict(x=q[:, h * dh:(h + 1) * dh], wT=wkf[h * dh:(h + 1) * dh], out=qf[:, h * Cm:(h + 1) * Cm]) for h in range(heads)]
+        _grouped_chunks(groups)
+        return xs, qfs
 
+    def text_prefix(sel):
+        """Everything up to the first cross-attention depends on the text embeddings and weights only: text_proj, the first layer's
+        self-attention and folded queries, and text_to_visual.  Cached across denoising steps."""
+        x0 = ops.linear_t_grouped([dict(x=st[i]["t2d"], wT=wT(st[i]["dec"].text_proj[1]), bias=st[i]["dec"].text_proj[1].bias,
+                                        ln=(st[i]["dec"].text_proj[0].weight, st[i]["dec"].text_proj[0].bias, st[i]["dec"].text_proj[0].eps)) for i in sel])
+        x1, qf1 = self_attn_and_query(sel, x0, 0)
+        t2v = ops.linear_t_grouped([dict(x=st[i]["t2d"], wT=wT(st[i]["m"].text_to_visual), bias=st[i]["m"].text_to_visual.bias) for i in sel])
+        return list(zip(x1, qf1, t2v))
+
+    # ---- prefix: from the per-module cache where it is valid, the rest computed together ------------------------------------------
+    def prefix_params(s, text):
+        dec, m, mp = s["dec"], s["m"], s["mp"]
         l0 = dec.decoder[0]
-        prefix_params = [text, dec.text_proj[0].weight, dec.text_proj[0].bias, dec.text_proj[1].weight, dec.text_proj[1].bias,
-                         l0.norm1.weight, l0.norm1.bias, l0.self_attn.q_proj.weight, l0.self_attn.k_proj.weight, l0.self_attn.v_proj.weight,
-                         l0.self_attn.proj.weight, l0.self_attn.proj.bias, l0.norm2.weight, l0.norm2.bias, l0.cross_attn.q_proj.weight,
-                         l0.cross_attn.k_proj.weight, mp[1].weight, mp[1].bias, mp[2].weight, self.text_to_visual.weight, self.text_to_visual.bias]
-        if torch.is_grad_enabled() or not cache_prefix:
-            x, qf, t2v = text_prefix()
-        else:
-            x, qf, t2v = _PREP.get(("prefix", self, Cm), prefix_params, text_prefix)
-        for li, layer in enumerate(dec.decoder):
-            ca = layer.cross_attn
-            if li > 0:
-                x, qf = self_attn_and_query(x, layer)
-            _, wvf, bvf = fold_weights(ca)
-            o = ops.smm_xattn(qf.reshape(B, K, heads, Cm), mem, ca.scale).reshape(B * K, heads * Cm)
+        return [text, dec.text_proj[0].weight, dec.text_proj[0].bias, dec.text_proj[1].weight, dec.text_proj[1].bias, l0.norm1.weight, l0.norm1.bias,
+                l0.self_attn.q_proj.weight, l0.self_attn.k_proj.weight, l0.self_attn.v_proj.weight, l0.self_attn.proj.weight, l0.self_attn.proj.bias,
+                l0.norm2.weight, l0.norm2.bias, l0.cross_attn.q_proj.weight, l0.cross_attn.k_proj.weight, mp[1].weight, mp[1].bias, mp[2].weight,
+                m.text_to_visual.weight, m.text_to_visual.bias]
+
+    if torch.is_grad_enabled() or not cache_prefix:
+        pre = text_prefix(list(range(L)))
+    else:
+        pre = [None] * L
+        todo = []
+        for i, (s, text) in enumerate(zip(st, texts)):
+            hit = _PREP.peek(("prefix", s["m"], s["Cm"]), prefix_params(s, text))
+            if hit is None:
+                todo.append(i)
+            else:
+                pre[i] = hit
+        if todo:
+            for i, val in zip(todo, text_prefix(todo)):
+                pre[i] = _PREP.get(("prefix", st[i]["m"], st[i]["Cm"]), prefix_params(st[i], texts[i]), lambda val=val: val)
+    xs = [p[0] for p in pre]
+    qfs = [p[1] for p in pre]
+    t2vs = [p[2] for p in pre]
+
+    every = list(range(L))
+    for li in range(nlayers):
+        lay = [s["dec"].decoder[li] for s in st]
+        if li > 0:
+            xs, qfs = self_attn_and_query(every, xs, li)
+        avs, groups = [], []
+        for s, l, qf in zip(st, lay, qfs):
+            Cm, ca = s["Cm"], l.cross_attn
+            _, wvf, bvf = fold_weights(s, ca)
+            o = ops.smm_xattn(qf.reshape(B, K, heads, Cm), s["mem"], ca.scale).reshape(R, heads * Cm)
             # per head: av[:, h-block] = o[:, h-block] @ wvf[:, h column block] (+ bvf[h-block])  ([Cm, dh])
-            av = torch.empty((B * K, Wd), device=feat.device, dtype=torch.float32)
-            ops.linear_t_heads(o, wvf, bvf, av, heads, Cm, dh, x_hs=Cm, w_hs=dh, b_hs=dh, o_hs=dh)
-            x = ops.linear_t(av, wT(ca.proj), ca.proj.bias, res=x)
-            hm = ops.linear_t(x, wT(layer.mlp[0]), layer.mlp[0].bias, act_out=ops.ACT_GELU, ln=(layer.norm3.weight, layer.norm3.bias, layer.norm3.eps))
-            x = ops.linear_t(hm, wT(layer.mlp[3]), layer.mlp[3].bias, res=x)
-        op = dec.out_proj
-        if plain_out:
-            return ops.linear_t(x, wT(op[1]), op[1].bias, ln=(op[0].weight, op[0].bias, op[0].eps))
-        # residual, per-column gain and LayerNorm fused into the last linear
-        return ops.linear_t(x, wT(op[1]), op[1].bias, res=t2v, gscale=self.gamma, ln=(op[0].weight, op[0].bias, op[0].eps))
+            av = torch.empty((R, Wd), device=dev, dtype=torch.float32)
+            avs.append(av)
+            groups += [dict(x=o[:, h * Cm:(h + 1) * Cm], wT=wvf[:, h * dh:(h + 1) * dh], bias=None if bvf is None else bvf[h * dh:(h + 1) * dh],
+                            out=av[:, h * dh:(h + 1) * dh]) for h in range(heads)]
+        _grouped_chunks(groups)
+        xs = ops.linear_t_grouped([dict(x=av, wT=wT(l.cross_attn.proj), bias=l.cross_attn.proj.bias, res=x) for av, l, x in zip(avs, lay, xs)])
+        hm = ops.linear_t_grouped([dict(x=x, wT=wT(l.mlp[0]), bias=l.mlp[0].bias, act_out=ops.ACT_GELU, ln=(l.norm3.weight, l.norm3.bias, l.norm3.eps))
+                                   for x, l in zip(xs, lay)])
+        xs = ops.linear_t_grouped([dict(x=h_, wT=wT(l.mlp[3]), bias=l.mlp[3].bias, res=x) for h_, l, x in zip(hm, lay, xs)])
+    if plain_out:
+        return ops.linear_t_grouped([dict(x=x, wT=wT(s["dec"].out_proj[1]), bias=s["dec"].out_proj[1].bias,
+                                          ln=(s["dec"].out_proj[0].weight, s["dec"].out_proj[0].bias, s["dec"].out_proj[0].eps)) for x, s in zip(xs, st)])
+    # residual, per-column gain and LayerNorm fused into the last linear
+    return ops.linear_t_grouped([dict(x=x, wT=wT(s["dec"].out_proj[1]), bias=s["dec"].out_proj[1].bias, res=t2v, gscale=s["m"].gamma,
+                                      ln=(s["dec"].out_proj[0].weight, s["dec"].out_proj[0].bias, s["dec"].out_proj[0].eps)) for x, s, t2v in zip(xs, st, t2vs)])
+
+
+def _grouped_chunks(groups):
+    """a grouped launch takes at most 16 problems (the heads of four modules); longer lists go in as many launches as needed"""
+    n = ops._lib.LINEAR_MAX_GROUPS
+    for i in range(0, len(groups), n):
+        ops.linear_t_grouped(groups[i:i + n])
 
 
 def _fold_memory_affine(lin, ln2, ca, Cm):
@@ -502,7 +564,6 @@ class LearnableForwardUNet_MultiScoreMap(nn.Module):
         self.final_res = ResBlock(nf * 2, nf, time_dim, gn_groups)
         self.final_conv = nn.Conv2d(nf, out_nc, 3, padding=1)
         self._ctx_cache = None
-        self._side_stream = None
         self._idx_cache = {}
 
     # ---- helpers ---------------------------------------------------------------------------------
@@ -597,13 +658,7 @@ class LearnableForwardUNet_MultiScoreMap(nn.Module):
         x_ = x
         hs, sms = [], []
         use_sm = self.CLIP_ScoreMapModule is not None
-        # A level's ScoreMapModule only feeds the skip connection (and the returned score maps), so its latency-bound token
-        # chain runs on a side stream while the conv path goes on down the encoder; joined before the decoder reads a skip.
-        side = None
-        if use_sm and SMM_SIDE_STREAM and x.is_cuda:
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream()
-            side, cur = self._side_stream, torch.cuda.current_stream()
+        sm_feats, sm_skips = [], []
         for i, lv in enumerate(self.downs):
             din, dout, smc = self.level_dims[i]
             Hi, Wi = x.shape[2], x.shape[3]
@@ -620,28 +675,29 @@ class LearnableForwardUNet_MultiScoreMap(nn.Module):
             if general:
                 x = lv.ca2.run(x, ctx, out=xo)
             if use_sm:
-                if side is not None:
-                    side.wait_stream(cur)  # x (= skip[:, :din]) is complete
-                    with torch.cuda.stream(side):
-                        score, sel = self.CLIP_ScoreMapModule[i](x, text_encoder, idx)
-                        ops.conv2d(score, packed(self.sm_embed[i]), self.sm_embed[i].bias, 3, smc, out=skip[:, din:])
-                    if sel is not None:
-                        sel.record_stream(cur)
-                else:
-                    score, sel = self.CLIP_ScoreMapModule[i](x, text_encoder, idx)
-                    ops.conv2d(score, packed(self.sm_embed[i]), self.sm_embed[i].bias, 3, smc, out=skip[:, din:])
-                sms.append(sel)
+                sm_feats.append(x)      # = skip[:, :din]; the score-map channels skip[:, din:] are filled below
+                sm_skips.append(skip)
                 hs.append(skip)
             else:
                 hs.append(x)
             x = lv.down.run(x)
+        if use_sm:
+            # A level's ScoreMapModule only feeds its skip connection (and the returned score maps), which the decoder reads much
+            # later: the four modules run here, together -- every latency-bound token-side launch of their decoder chains serves all
+            # four levels at once (decoder_tokens_grouped), 23 launches per net instead of 92.
+            smms = list(self.CLIP_ScoreMapModule)
+            texts = [m.text_embeddings(text_encoder, B) for m in smms]
+            tvs = decoder_tokens_grouped(smms, sm_feats, texts)
+            for i, (m, feat, tv, skip) in enumerate(zip(smms, sm_feats, tvs, sm_skips)):
+                din, dout, smc = self.level_dims[i]
+                score, sel = ops.scoremap(feat, tv.reshape(B, m.n_cls, feat.shape[1]), idx)
+                ops.conv2d(score, packed(self.sm_embed[i]), self.sm_embed[i].bias, 3, smc, out=skip[:, din:])
+                sms.append(sel)
         x = self.mid_res1.run(x, None, films[id(self.mid_res1)])
         x = self.mid_attn.run(x, vec=ca_vec("mid_ca", self))
         if general:
             x = self.mid_ca.run(x, ctx)
         x = self.mid_res2.run(x, None, films[id(self.mid_res2)])
-        if side is not None:
-            cur.wait_stream(side)  # the skips carry the score-map embeddings from here on
         for up in self.ups:
             x = up.res1.run(x, hs.pop(), films[id(up.res1)], vec=ca_vec("ca1", up))
             if general:

@@ -248,6 +248,62 @@ def linear_t(x, wT, bias=None, res=None, gscale=None, act_in=ACT_NONE, act_out=A
     return out
 
 
+def linear_t_grouped(groups):
+    """ONE launch for up to 16 independent linear_t problems (idiff_linear_t_grouped_fwd).  Each group is a dict with the keyword
+    arguments of linear_t: x, wT, bias=None, res=None, gscale=None, act_in, act_out, out=None, ln=None.  Returns the outputs."""
+    lib = _lib.load()
+    n = len(groups)
+    assert 1 <= n <= _lib.LINEAR_MAX_GROUPS, n
+    arr = (_lib.LinearGroup * n)()
+    outs = []
+    for d, g in zip(arr, groups):
+        x, wT = g["x"], g["wT"]
+        _chk(x, "x"), _chk(wT, "wT")
+        assert x.dim() == 2 and wT.dim() == 2 and x.stride(1) == 1 and wT.stride(1) == 1 and x.shape[1] == wT.shape[0]
+        R, K = x.shape
+        N = wT.shape[1]
+        out = g.get("out")
+        if out is None:
+            out = torch.empty((R, N), device=x.device, dtype=torch.float32)
+        assert out.stride(1) == 1 and tuple(out.shape) == (R, N)
+        res, bias, gs, ln = g.get("res"), g.get("bias"), g.get("gscale"), g.get("ln")
+        d.x, d.ldx, d.wT, d.ldw = x.data_ptr(), x.stride(0), wT.data_ptr(), wT.stride(0)
+        d.bias = _c(bias, "bias").data_ptr() if bias is not None else None
+        if res is not None:
+            assert res.stride(1) == 1 and tuple(res.shape) == (R, N)
+            d.res, d.ldr = res.data_ptr(), res.stride(0)
+        d.gscale = _c(gs, "gscale").data_ptr() if gs is not None else None
+        d.out, d.ldo = out.data_ptr(), out.stride(0)
+        if ln is not None:
+            assert g.get("act_in", ACT_NONE) == ACT_NONE
+            d.ln_g, d.ln_b, d.ln_eps = _c(ln[0], "ln_g").data_ptr(), _c(ln[1], "ln_b").data_ptr(), float(ln[2])
+        d.R, d.K, d.N, d.act_in, d.act_out = R, K, N, g.get("act_in", ACT_NONE), g.get("act_out", ACT_NONE)
+        outs.append(out)
+    check(lib.idiff_linear_t_grouped_fwd(arr, n, _stream()), "linear_t_grouped_fwd")
+    return outs
+
+
+def attn_tokens_packed_grouped(qkvs, heads, scale):
+    """attn_tokens_packed for several packed projections of one shape [B,N,3C] in ONE launch -> list of [B,N,C]"""
+    lib = _lib.load()
+    n = len(qkvs)
+    assert 1 <= n <= _lib.LINEAR_MAX_GROUPS
+    B, Nq, C3 = qkvs[0].shape
+    Cc = C3 // 3
+    PA = C.c_void_p * n
+    q, k, v, o = PA(), PA(), PA(), PA()
+    outs = []
+    for i, t in enumerate(qkvs):
+        _c(t, "qkv")
+        assert tuple(t.shape) == (B, Nq, C3)
+        out = torch.empty((B, Nq, Cc), device=t.device, dtype=torch.float32)
+        base = t.data_ptr()
+        q[i], k[i], v[i], o[i] = base, base + 4 * Cc, base + 8 * Cc, out.data_ptr()
+        outs.append(out)
+    check(lib.idiff_attn_tokens_grouped_fwd(q, k, v, o, n, B, Nq, Nq, Cc, heads, scale, C3, C3, _stream()), "attn_tokens_grouped_fwd")
+    return outs
+
+
 def linear_t_heads(x, wT, bias, out, heads, K, N, x_hs, w_hs, b_hs, o_hs):
     """heads independent [R,K] x [K,N] products in one launch: head h reads x[:, h*x_hs : h*x_hs+K], the [K,N] block of wT
     starting w_hs elements further per head, bias[h*b_hs : h*b_hs+N], and writes out[:, h*o_hs : h*o_hs+N]."""

@@ -214,3 +214,47 @@ def test_attn_self_bf16_variant_close_to_fp32_kernel():
         e16 = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
         print(f"attn_self N={H * W}: fp32 kernel {e32:.2e}, bf16 variant {e16:.2e}")
         assert e32 < 1e-5 and e16 < 2e-2
+
+
+def test_linear_t_grouped_equals_single_launches():
+    """idiff_linear_t_grouped_fwd: problems of different shapes, with / without LayerNorm, residual, gain, activations and strided
+    views, in ONE launch -- bit for bit what the single launches give (same kernel body, same per-element chain)."""
+    g = torch.Generator().manual_seed(71)
+    groups, singles = [], []
+    for R, K, N, ln, res, gs, act in ((80, 256, 768, True, False, False, 0), (80, 256, 256, False, True, False, 0), (25, 1024, 256, False, True, True, 0),
+                                       (80, 64, 72, False, False, False, 0), (80, 256, 1024, True, False, False, 2), (7, 136, 64, False, False, False, 1)):
+        x = torch.randn(R, K + 8, generator=g).to(DEV)[:, :K]          # row-strided view
+        wT = (torch.randn(K, N, generator=g) / math.sqrt(K)).to(DEV)
+        b = torch.randn(N, generator=g).to(DEV)
+        kw = dict(x=x, wT=wT, bias=b)
+        if ln:
+            kw["ln"] = (torch.randn(K, generator=g).to(DEV), torch.randn(K, generator=g).to(DEV), 1e-5)
+        if res:
+            kw["res"] = torch.randn(R, N, generator=g).to(DEV)
+        if gs:
+            kw["gscale"] = torch.randn(N, generator=g).to(DEV)
+        if act == 2:
+            kw["act_out"] = ops.ACT_GELU
+        if act == 1:
+            kw["act_in"] = ops.ACT_SILU
+        groups.append(kw)
+        singles.append(ops.linear_t(**kw))
+    outs = ops.linear_t_grouped(groups)
+    for i, (a, b) in enumerate(zip(outs, singles)):
+        assert torch.equal(a, b), i
+    # into caller-provided strided outputs
+    big = torch.zeros(80, 4 * 72, device=DEV)
+    x = torch.randn(80, 256, generator=g).to(DEV)
+    w = torch.randn(256, 72, generator=g).to(DEV)
+    ops.linear_t_grouped([dict(x=x[:, h * 64:(h + 1) * 64], wT=w[h * 64:(h + 1) * 64], out=big[:, h * 72:(h + 1) * 72]) for h in range(4)])
+    for h in range(4):
+        _close(big[:, h * 72:(h + 1) * 72], x[:, h * 64:(h + 1) * 64].double() @ w[h * 64:(h + 1) * 64].double(), 3e-6, f"head {h}")
+
+
+def test_attn_tokens_grouped_equals_single_launches():
+    g = torch.Generator().manual_seed(72)
+    B, N, C, heads = 3, 5, 256, 4
+    qkvs = [torch.randn(B, N, 3 * C, generator=g).to(DEV) for _ in range(4)]
+    outs = ops.attn_tokens_packed_grouped(qkvs, heads, 0.125)
+    for q, o in zip(qkvs, outs):
+        assert torch.equal(o, ops.attn_tokens_packed(q, heads, 0.125))
