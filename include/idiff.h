@@ -82,6 +82,24 @@ typedef struct {
     const float* wwino4;    /* optional F(4x4,3x3)-domain copy (idiff_pack_conv_weight_wino4): preferred over wwino when
                                Hout % 4 == 0, Wout % 4 == 0, Wout >= 24, Cin % 8 == 0, Cout % 16 == 0 and a sample has at
                                least 16 items of 16x32 pixels x 64 channels (4x fewer matrix-core flops than direct) */
+    /* Optional GroupNorm finalize of `stats` behind this conv (gn_out_a != NULL; requires stats): the per-(sample, channel) affine
+       idiff_gn_finalize would compute, written by this call -- as the tail of the conv launch itself where the kernel supports it
+       (the F(4x4,3x3) kernels with gn_ticket set: the last workgroups to arrive reduce the partials, bit-identical to the separate
+       launch), otherwise by an idiff_gn_finalize launch enqueued behind the conv.  Arguments as idiff_gn_finalize. */
+    const float* gn_gamma;
+    const float* gn_beta;
+    const float* gn_film;
+    int64_t gn_film_ld;
+    float gn_eps;
+    int32_t gn_groups;
+    float* gn_out_a;
+    float* gn_out_b;
+    float* gn_mean_rstd;    /* optional [B, groups, 2] */
+    uint32_t* gn_ticket;    /* 4 zero-initialised words owned by the LAYER (not shared with a conv that may run concurrently); the
+                               kernel leaves them zero again; NULL: the separate finalize launch.  Measured at c2 (two nets on two
+                               streams, HIP graph): the fused tail saves 76 launches per step and COSTS 0.45 ms of 26.0 -- every
+                               workgroup has to drain its output stores before it may signal, and holds its CU meanwhile -- so the
+                               host code leaves it off unless IDIFF_GN_FUSED=1 (profiles/r03/x_gn_fused_finalize.txt) */
     int32_t algo_request;   /* 0 = the library picks (by the layer's per-sample shape only, never by the batch); 1 + IDIFF_CONV_ALGO_x =
                                run exactly that kernel or fail with IDIFF_E_ARG if the shape does not tile for it (a per-call
                                request: profiling, parity tests of a kernel at small sizes; a request for the F(4x4,3x3) kernel

@@ -4,6 +4,21 @@
 
 namespace idiff_detail {
 
+// GroupNorm finalize fused behind the launch that writes the partials (gn_tail.h); ticket == nullptr: not requested
+struct GnTail {
+    const float* gamma;
+    const float* beta;
+    const float* film;
+    long long film_ld;
+    float eps;
+    int groups;
+    float* out_a;
+    float* out_b;
+    float* mean_rstd;
+    unsigned* ticket;  // [4] zero-initialised words owned by the layer: arrivals, finalizers done, timeout flag, spare
+    unsigned max_finalizers;  // upper bound on the workgroups that stay for the finalize (they hold their CUs until the last arrival)
+};
+
 struct ConvArgs {
     const float* src0;
     const float* src1;
@@ -29,6 +44,7 @@ struct ConvArgs {
     const float* aux_a;
     const float* aux_b;
     float* stats;
+    GnTail gn;
     int tiles_x, ntiles, ncob;
     unsigned total_wg;
 };

@@ -629,6 +629,21 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
     a.aux_a = d->aux_a;
     a.aux_b = d->aux_b;
     a.stats = d->stats;
+    memset(&a.gn, 0, sizeof(a.gn));
+    const bool want_gn = d->gn_out_a != nullptr;
+    if (want_gn) {
+        IDIFF_CHECK_ARG(d->stats && d->gn_out_b && d->gn_groups > 0 && d->Cout % d->gn_groups == 0 && d->Cout / d->gn_groups <= 256,
+                        "conv2d: GroupNorm finalize needs stats, gn_out_b and groups dividing Cout (<= 256 channels per group)");
+        a.gn.gamma = d->gn_gamma, a.gn.beta = d->gn_beta, a.gn.film = d->gn_film, a.gn.film_ld = d->gn_film_ld, a.gn.eps = d->gn_eps;
+        a.gn.groups = d->gn_groups, a.gn.out_a = d->gn_out_a, a.gn.out_b = d->gn_out_b, a.gn.mean_rstd = d->gn_mean_rstd;
+        a.gn.ticket = nullptr;  // set below for the kernels that finish the job themselves
+    }
+    // the separate finalize launch behind kernels without the fused tail
+    auto finalize_after = [&](int rc) -> int {
+        if (rc != IDIFF_OK || !want_gn) return rc;
+        return idiff_gn_finalize(d->stats, a.ntiles, a.B, a.Cout, d->gn_groups, a.Hout * a.Wout, d->gn_gamma, d->gn_beta, d->gn_film, d->gn_film_ld,
+                                 d->gn_eps, d->gn_out_a, d->gn_out_b, d->gn_mean_rstd, stream);
+    };
     if (d->mode == IDIFF_CONV_UNSHUFFLE2) {
         IDIFF_CHECK_ARG(d->ks == 1 && d->C1 == 0, "conv2d: unshuffle mode needs ks=1 and a single source");
         IDIFF_CHECK_ARG(d->Hin % 2 == 0 && d->Win % 2 == 0, "conv2d: unshuffle needs even H, W");
@@ -697,33 +712,43 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
         else if (req4) half = false;
         else if (items16 >= 16) half = w4h_mode == 2 || (w4h_mode == 1 && a.src1 != nullptr);
         else half = w4h_mode >= 1 && items8 >= 16;
+        const bool fuse = want_gn && d->gn_ticket != nullptr;  // the caller's choice: a ticket buffer asks for the fused tail
+        static const unsigned gn_nfin = [] {  // IDIFF_GN_FINALIZERS: workgroups kept for the finalize (default 32)
+            const char* e = getenv("IDIFF_GN_FINALIZERS");
+            const int v = e ? atoi(e) : 32;
+            return (unsigned)(v < 1 ? 1 : v);
+        }();
+        if (fuse) a.gn.ticket = d->gn_ticket, a.gn.max_finalizers = gn_nfin;
         if (half) {
             g_last_algo = IDIFF_CONV_ALGO_WINOGRAD4H;
-            return idiff_detail::launch_conv_wino4h(a, d->mode, st);
+            const int rc = idiff_detail::launch_conv_wino4h(a, d->mode, st);
+            return fuse ? rc : finalize_after(rc);
         }
         if (req4 || items16 >= 16) {
             g_last_algo = IDIFF_CONV_ALGO_WINOGRAD4;
-            return idiff_detail::launch_conv_wino4(a, d->mode, st);
+            const int rc = idiff_detail::launch_conv_wino4(a, d->mode, st);
+            return fuse ? rc : finalize_after(rc);
         }
+        a.gn.ticket = nullptr;
     }
     IDIFF_CHECK_ARG(!hard || !(req4 || req4h), "conv2d: algo_request F(4x4,3x3) but the shape does not tile for it");
     if ((req == -1 || req == IDIFF_CONV_ALGO_WINOGRAD || !hard) && req != IDIFF_CONV_ALGO_DIRECT && idiff_detail::conv_wino_eligible(a, d->ks, d->mode)) {
         g_last_algo = IDIFF_CONV_ALGO_WINOGRAD;
-        return idiff_detail::launch_conv_wino(a, d->mode, st);
+        return finalize_after(idiff_detail::launch_conv_wino(a, d->mode, st));
     }
     IDIFF_CHECK_ARG(!hard || req != IDIFF_CONV_ALGO_WINOGRAD, "conv2d: algo_request F(2x2,3x3) but the shape does not tile for it");
     g_last_algo = IDIFF_CONV_ALGO_DIRECT;
     if (d->ks == 3) {
-        if (d->mode == IDIFF_CONV_NORMAL) return dispatch_mb<3, 8, IDIFF_CONV_NORMAL>(a, twl, mb, vecw, st);
-        return dispatch_mb<3, 8, IDIFF_CONV_UPSAMPLE2>(a, twl, mb, vecw, st);
+        if (d->mode == IDIFF_CONV_NORMAL) return finalize_after(dispatch_mb<3, 8, IDIFF_CONV_NORMAL>(a, twl, mb, vecw, st));
+        return finalize_after(dispatch_mb<3, 8, IDIFF_CONV_UPSAMPLE2>(a, twl, mb, vecw, st));
     }
     if (d->ks == 1) {
         IDIFF_CHECK_ARG(d->mode != IDIFF_CONV_UPSAMPLE2, "conv2d: upsample mode needs ks=3");
-        if (d->mode == IDIFF_CONV_NORMAL) return dispatch_mb<1, 16, IDIFF_CONV_NORMAL>(a, twl, mb, vecw, st);
-        return dispatch_mb<1, 16, IDIFF_CONV_UNSHUFFLE2>(a, twl, mb, vecw, st);
+        if (d->mode == IDIFF_CONV_NORMAL) return finalize_after(dispatch_mb<1, 16, IDIFF_CONV_NORMAL>(a, twl, mb, vecw, st));
+        return finalize_after(dispatch_mb<1, 16, IDIFF_CONV_UNSHUFFLE2>(a, twl, mb, vecw, st));
     }
     IDIFF_CHECK_ARG(d->mode == IDIFF_CONV_NORMAL, "conv2d: ks=7 needs normal mode");
-    return dispatch_mb<7, 2, IDIFF_CONV_NORMAL>(a, twl, mb, vecw, st);
+    return finalize_after(dispatch_mb<7, 2, IDIFF_CONV_NORMAL>(a, twl, mb, vecw, st));
 }
 
 static int pack_common(const float* w, float* wpk, int Cout, int Cin, int ks, int tr, idiff_stream_t stream) {

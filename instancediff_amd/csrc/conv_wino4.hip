@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "conv_args.h"
+#include "gn_tail.h"
 
 using idiff_detail::ConvArgs;
 
@@ -566,7 +567,7 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
                     if (!inside) ssum = 0.f, ssq = 0.f;
                     ssum = row_sum16(ssum);
                     ssq = row_sum16(ssq);
-                    if (j == 15) *reinterpret_cast<floatx2*>(stp + 2 * r) = floatx2{ssum, ssq};
+                    if (j == 15) idiff_detail::gn_store_partial(stp + 2 * r, ssum, ssq);  // write-through: read by another workgroup (gn_tail.h)
                 }
                 const float add = ebase[64 + r];
                 float aa = 0.f, ab = 0.f;
@@ -593,6 +594,7 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
         TRACE_MARK(7)
         TRACE_MARK(8)
     }
+    if (a.gn.ticket) idiff_detail::gn_arrive_and_finalize(a, Rb);  // GroupNorm finalize as the tail of this launch (gn_tail.h)
     TRACE_FINI
     SLOT_FINI
 }

@@ -17,6 +17,9 @@ SDE_STEP, SDE_MEAN, SDE_ODE = 0, 1, 2
 
 # bench.py sets this to a list to time every conv launch with events on the launch stream (roofline leg)
 PROFILE = None
+# IDIFF_GN_FUSED=1: GroupNorm finalize as the tail of the producing conv launch (gn_tail.h) instead of a finalize launch behind it.
+# Off by default: 270 instead of 346 launches per step, but +0.45 ms per step at c2 (profiles/r03/x_gn_fused_finalize.txt).
+GN_FUSED = bool(int(os.environ.get("IDIFF_GN_FUSED", "0")))
 # tests set this to a collections.Counter: (algo, ks, Cin, Cout, Hout, Wout) -> calls, to assert which kernel served a layer
 ALGO_TRACE = None
 
@@ -108,10 +111,13 @@ def conv_num_tiles(Hout, Wout):
 
 
 def conv2d(src0, wpk, bias, ks, Cout, src1=None, mode=CONV_NORMAL, pro=None, out=None, res=None, vec=None, aux=None,
-           want_stats=False, algo=None):
+           want_stats=False, algo=None, gn=None):
     """Implicit-GEMM conv.  pro=(a,b): per-(b,c) affine+SiLU applied to src0 while it is gathered;
     aux=(tensor,a,b): adds silu(a*tensor+b) in the epilogue.  Returns out or (out, stats).
-    algo: None = the library picks; CONV_ALGO_x = that kernel or an error (idiff_conv_desc.algo_request)."""
+    algo: None = the library picks; CONV_ALGO_x = that kernel or an error (idiff_conv_desc.algo_request).
+    gn = dict(groups, gamma, beta, film=None, eps=1e-5, ticket=None, want_mean_rstd=False): the GroupNorm(+FiLM) finalize of this conv's
+    statistics rides on the call (as the tail of the conv launch where the kernel supports it and `ticket` -- 4 zeroed int32 words
+    owned by the layer -- is given, else as a finalize launch enqueued by the library): returns (out, (a, b)) or (out, (a, b, mean_rstd))."""
     lib = _lib.load()
     B, C0, Hin, Win = src0.shape
     d = ConvDesc()
@@ -159,10 +165,30 @@ def conv2d(src0, wpk, bias, ks, Cout, src1=None, mode=CONV_NORMAL, pro=None, out
         d.aux, d.aux_bstride = t.data_ptr(), _bs(t, "aux")
         d.aux_a, d.aux_b = _c(a, "aux_a").data_ptr(), _c(b, "aux_b").data_ptr()
     stats = None
-    if want_stats:
+    if want_stats or gn is not None:
         nt = lib.idiff_conv2d_num_tiles(Hout, Wout)
         stats = torch.empty((B, nt, Cout, 2), device=src0.device, dtype=torch.float32)
         d.stats = stats.data_ptr()
+    gn_out = None
+    if gn is not None:
+        ga, gb = torch.empty((B, Cout), device=src0.device, dtype=torch.float32), torch.empty((B, Cout), device=src0.device, dtype=torch.float32)
+        d.gn_groups, d.gn_eps = int(gn["groups"]), float(gn.get("eps", 1e-5))
+        d.gn_gamma, d.gn_beta = _c(gn["gamma"], "gn gamma").data_ptr(), _c(gn["beta"], "gn beta").data_ptr()
+        film = gn.get("film")
+        if film is not None:
+            _chk(film, "film")
+            assert film.shape[0] == B and film.shape[1] == 2 * Cout and film.stride(1) == 1
+            d.gn_film, d.gn_film_ld = film.data_ptr(), film.stride(0)
+        d.gn_out_a, d.gn_out_b = ga.data_ptr(), gb.data_ptr()
+        gn_out = (ga, gb)
+        if gn.get("want_mean_rstd"):
+            mr = torch.empty((B, d.gn_groups, 2), device=src0.device, dtype=torch.float32)
+            d.gn_mean_rstd = mr.data_ptr()
+            gn_out = (ga, gb, mr)
+        tk = gn.get("ticket")
+        if tk is not None:
+            assert tk.dtype == torch.int32 and tk.numel() >= 4 and tk.is_cuda and tk.is_contiguous()
+            d.gn_ticket = tk.data_ptr()
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -176,6 +202,8 @@ def conv2d(src0, wpk, bias, ks, Cout, src1=None, mode=CONV_NORMAL, pro=None, out
     if ALGO_TRACE is not None:
         Cin = (C0 * 4 if mode == CONV_UNSHUFFLE2 else C0) + (src1.shape[1] if src1 is not None else 0)
         ALGO_TRACE[(lib.idiff_conv2d_last_algo(), ks, Cin, Cout, Hout, Wout)] += 1
+    if gn is not None:
+        return (out, gn_out, stats) if want_stats else (out, gn_out)
     return (out, stats) if want_stats else out
 
 

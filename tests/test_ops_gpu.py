@@ -631,3 +631,45 @@ def test_conv_winograd4_bits_do_not_depend_on_the_batch(force_wino4):
         one, s1 = ops.conv2d(x[b:b + 1].contiguous(), wp, bias, 3, Cout, pro=(pro[0][b:b + 1].contiguous(), pro[1][b:b + 1].contiguous()), want_stats=True)
         assert lib.idiff_conv2d_last_algo() == lib.expected_algo
         assert torch.equal(one[0], full[b]) and torch.equal(s1[0], st[b]), b
+
+
+@pytest.mark.parametrize("B,C0,C1,Cout,H,W,G,film,pro,algo", [
+    (16, 64, 0, 64, 64, 64, 8, True, False, None),    # half-patch kernel by the library's choice; 128 pairs, 256 workgroups
+    (16, 64, 0, 64, 64, 64, 8, True, False, 3),       # the same on the 16x32-item kernel (128 workgroups = 128 finalizers)
+    (3, 64, 0, 64, 128, 128, 8, False, True, None),   # 16x32-item kernel, prologue instantiation
+    (2, 32, 48, 128, 32, 64, 8, True, False, None),   # two sources: half-patch kernel, 2 workgroups per CU
+    (5, 128, 0, 256, 32, 32, 8, True, False, None),   # half-patch kernel below 16 items of 16x32 per sample
+    (1, 16, 0, 32, 28, 28, 8, False, False, 4),       # 4 workgroups, 8 (sample, group) pairs: a finalizer takes several pairs
+    (1, 16, 0, 32, 28, 28, 4, False, False, None),    # F(2x2,3x3): the library enqueues the separate finalize launch
+    (2, 16, 0, 32, 16, 16, 8, True, False, None),     # direct kernel: likewise
+])
+def test_conv_groupnorm_finalize_fused_equals_separate_launch(B, C0, C1, Cout, H, W, G, film, pro, algo):
+    """idiff_conv_desc.gn_*: the GroupNorm(+FiLM) finalize as the tail of the conv launch (last-arriving workgroups reduce the partials,
+    gn_tail.h) gives the SAME BITS as idiff_gn_finalize on the conv's statistics, launch after launch (the arrival counters clean
+    themselves), with and without a ticket (= fused / library-enqueued finalize)."""
+    lib = ops._lib.load()
+    g = _g(500 + B + Cout)
+    x0 = torch.randn(B, C0, H, W, generator=g).to(DEV)
+    x1 = torch.randn(B, C1, H, W, generator=g).to(DEV) if C1 else None
+    w = (torch.randn(Cout, C0 + C1, 3, 3, generator=g) / math.sqrt(9 * (C0 + C1))).to(DEV)
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    gamma, beta = torch.randn(Cout, generator=g).to(DEV), torch.randn(Cout, generator=g).to(DEV)
+    fl = (torch.randn(B, 2 * Cout + 8, generator=g) * 0.3).to(DEV)[:, :2 * Cout] if film else None   # row-strided, as the UNet's films are
+    kw = dict(src1=x1, algo=algo)
+    if pro:
+        kw["pro"] = (torch.rand(B, C0, generator=g).to(DEV) + 0.5, torch.randn(B, C0, generator=g).to(DEV) * 0.1)
+    wp = ops.pack_conv_weight(w)
+    out_ref, st = ops.conv2d(x0, wp, bias, 3, Cout, want_stats=True, **kw)
+    algo = lib.idiff_conv2d_last_algo()
+    a_ref, b_ref, mr_ref = ops.gn_finalize(st, G, H * W, gamma, beta, film=fl, eps=1e-5, want_mean_rstd=True)
+    ticket = torch.zeros(4, dtype=torch.int32, device=DEV)
+    for rep in range(3):
+        out, (a, b, mr) = ops.conv2d(x0, wp, bias, 3, Cout, gn=dict(groups=G, gamma=gamma, beta=beta, film=fl, eps=1e-5, ticket=ticket,
+                                                                        want_mean_rstd=True), **kw)
+        assert lib.idiff_conv2d_last_algo() == algo
+        assert torch.equal(out, out_ref)
+        assert torch.equal(a, a_ref) and torch.equal(b, b_ref) and torch.equal(mr, mr_ref), (rep, algo)
+        assert ticket.tolist() == [0, 0, 0, 0], (rep, ticket.tolist())   # counters back to zero, no timeout flag
+    out, (a, b) = ops.conv2d(x0, wp, bias, 3, Cout, gn=dict(groups=G, gamma=gamma, beta=beta, film=fl, eps=1e-5), **kw)   # no ticket
+    assert torch.equal(a, a_ref) and torch.equal(b, b_ref)
+    print(f"conv algo {algo}: fused finalize == separate launch (bitwise), B={B} Cout={Cout} {H}x{W}")
