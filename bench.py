@@ -15,14 +15,15 @@ update, fp32, random-init weights (seed 0), inputs resident in HBM, on-device Ph
 independent replicas (sampling shards by image, no data-path collective) -> weak scaling.
 
 Prints ONE JSON line: metric/value/... plus
-  roofline     : dominant kernel = the Winograd conv with the larger share of the step (F(4x4,3x3) conv_wino4_kernel at the
-                 default workload; `kernels` lists both).  `achieved` = the matrix-core FLOP the kernel's algorithm EXECUTES per
+  roofline     : dominant kernel = the Winograd conv kernel with the largest share of the step (`kernels` lists all three: the
+                 F(4x4,3x3) kernels conv_wino4_kernel / conv_wino4h_kernel and the F(2x2,3x3) conv_wino_kernel).  `achieved` = the matrix-core FLOP the kernel's algorithm EXECUTES per
                  launch (36 multiply-adds per 4x4 output tile and channel pair = 1/4 of the direct form; F(2x2,3x3): 16/36) /
                  average launch duration (HIP events on the launch stream, a second single-stream eager pass over the same K
                  steps); `peak` = 157.3 TFLOP/s f32 MFMA (MI355X_MICROARCH.md); `frac` = achieved / peak = the share of the matrix
                  pipe in use.  `effective_tflops` is the direct-form rate (x `algorithmic_speedup`), `step_frac` the executed
-                 conv FLOP of a whole step / ms_per_step / peak.  `traffic` comes from a rocprofv3 --pmc pass stored under
-                 profiles/ together with a hash of the kernel sources; a stale file (sources changed since) is not reported.
+                 conv FLOP of a whole step / ms_per_step / peak.  `traffic`, `hbm_kernels` (every HBM-side kernel with >= 2 % of the
+                 step: bytes per launch, GB/s, fraction of 8 TB/s) and `step_hbm_bytes` come from rocprofv3 --pmc passes stored
+                 under profiles/ with a hash of the kernel sources; a stale file (sources changed since) is not reported.
   cpu_baseline : the oracle (plain PyTorch fp32 restatement of the same step) on the host cores, at the named batch when one
                  step fits the time budget (else a stated fraction of the batch), 1 warm + >= 1 timed step.
   graph / launches_per_step : whether the timed loop replayed a captured HIP graph, and how many kernels one step enqueues.
@@ -234,25 +235,42 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of the dominant kernel from the newest profiles/r*/pmc_traffic.json (written by scripts/pmc_traffic.py
-    from separate rocprofv3 --pmc passes of this command).  Reported only if the file was measured on the same kernel sources."""
+def pmc_evidence(kernel):
+    """Counter evidence from the newest profiles/r*/pmc_kernels.json (scripts/collect_pmc_table.sh: counter-free trace + separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command's single-stream eager step, reduced per kernel by
+    scripts/pmc_table.py): `traffic` of the dominant kernel (launch-weighted mean over its template instantiations), the HBM-side
+    kernels of the step with their measured bound, and the step's HBM bytes.  Reported only if measured on the same kernel sources."""
     import glob
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_kernels.json")))
     if not cands:
         return {"traffic": None, "traffic_note": "no PMC pass stored"}
+    src = os.path.relpath(cands[-1], ROOT)
     try:
         with open(cands[-1]) as f:
-            pmc = json.load(f)
-        if pmc.get("kernel") not in kernel:
-            return {"traffic": None, "traffic_note": "stored PMC pass (%s) is of %s, not of the dominant kernel" % (os.path.relpath(cands[-1], ROOT), pmc.get("kernel"))}
-        if pmc.get("kernel_source_hash") != kernel_source_hash():
-            return {"traffic": None, "traffic_note": "stored PMC pass (%s) is stale: kernel sources changed since (%s != %s)"
-                    % (os.path.relpath(cands[-1], ROOT), pmc.get("kernel_source_hash"), kernel_source_hash())}
-        return {"traffic": pmc["hbm_bytes_per_launch"], "traffic_unit": "bytes/launch (%s)" % pmc.get("formula", "2*FETCH_SIZE + WRITE_SIZE"),
-                "traffic_source": os.path.relpath(cands[-1], ROOT), "traffic_commit": pmc.get("commit"),
-                "traffic_from_profile": True}
-    except (OSError, KeyError, ValueError) as e:
+            doc = json.load(f)
+        if doc.get("kernel_source_hash") != kernel_source_hash():
+            return {"traffic": None, "traffic_note": "stored PMC passes (%s) are stale: kernel sources changed since (%s != %s)"
+                    % (src, doc.get("kernel_source_hash"), kernel_source_hash())}
+        short = kernel.split(" ")[0]
+        mine = [k for k in doc["kernels"] if k["kernel"].startswith(short + "<") and "hbm_bytes_per_launch" in k]
+        out = {"traffic_unit": "bytes/launch (%s)" % doc.get("formula", "2*FETCH_SIZE + WRITE_SIZE"), "traffic_source": src, "traffic_from_profile": True}
+        if mine:
+            n = sum(k["launches_per_step"] for k in mine)
+            out["traffic"] = int(sum(k["hbm_bytes_per_launch"] * k["launches_per_step"] for k in mine) / n)
+            out["traffic_GBps"] = round(sum(k["hbm_bytes_per_launch"] * k["launches_per_step"] for k in mine) /
+                                        sum(k["avg_us"] * 1e3 * k["launches_per_step"] for k in mine), 1)
+        else:
+            out["traffic"] = None
+            out["traffic_note"] = "the stored PMC passes (%s) hold no launch of %s" % (src, short)
+        # every kernel with >= 2 % of the step's kernel time that is not a 3x3 Winograd conv: measured HBM bound
+        out["hbm_kernels"] = [{"kernel": k["kernel"], "bound": "hbm", "launches_per_step": k["launches_per_step"], "avg_us": k["avg_us"],
+                               "share_of_step_kernel_time": k["share_of_step_kernel_time"], "bytes_per_launch": k["hbm_bytes_per_launch"],
+                               "achieved": k["achieved_GBps"], "peak": k["peak_GBps"], "unit": "GB/s", "frac": k["frac"]}
+                              for k in doc["kernels"] if "frac" in k and not k["kernel"].startswith("conv_wino") and k["share_of_step_kernel_time"] >= 0.02]
+        out["step_hbm_bytes"] = doc.get("step_hbm_bytes")
+        out["step_hbm_GBps_over_kernel_time"] = doc.get("step_hbm_GBps_over_kernel_time")
+        return out
+    except (OSError, KeyError, ValueError, ZeroDivisionError) as e:
         return {"traffic": None, "traffic_note": repr(e)}
 
 
@@ -531,7 +549,7 @@ def main():
                 "wino_ms_per_step_single_stream": round(sum(g["_ms"] for g in groups.values()) / args.steps, 3),
                 "step_conv_gflop_direct_form": round(all_fl / args.steps / 1e9, 1),
                 "kernels": [{k: v for k, v in groups[a].items() if not k.startswith("_")} for a in sorted(groups, key=lambda a: -groups[a]["_ms"])]}
-        roof.update(pmc_traffic(d["kernel"]))
+        roof.update(pmc_evidence(d["kernel"]))
     if world > 1:
         barrier()
 

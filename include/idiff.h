@@ -325,6 +325,11 @@ int idiff_drift_reverse_step_dev(float* x, const float* r_hat, const float* e_ha
                                  uint64_t nper, uint64_t offset_base, idiff_stream_t stream);
 /* t <- t-1 (back to T once t <= t_stop), both counters += 1, tdev[0..B) = (float)t   (the UNets' timestep input) */
 int idiff_step_state_advance(int32_t* state, float* tdev, int B, int T, int t_stop, idiff_stream_t stream);
+/* Inverted dropout (training mode of the ScoreMapModule decoder blocks: nn.Dropout(0.1) in TransformerDecoderLayer / Attention.proj_drop,
+ * models/_modified_BiomedCLIP.py:448-478,520-549): out[i] = x[i] / (1-p) where u_i >= p, else 0, with u_i = (w >> 8) * 2^-24 from word
+ * i % 4 of Philox counter offset + i / 4 under `seed`.  The mask is a function of (seed, offset, i) alone: the backward pass is the SAME
+ * call on the gradient (nothing is stored), x == out allowed. */
+int idiff_dropout(const float* x, float* out, int64_t n, float p, uint64_t seed, uint64_t offset, idiff_stream_t stream);
 /* standard normals (Philox4x32-10, Box-Muller), element i uses counter (offset + i/4) lane i%4 */
 int idiff_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, idiff_stream_t stream);
 /* raw Philox4x32-10 words for tests: out[4*i..4*i+3] = philox(counter = offset+i, key = seed) */

@@ -87,6 +87,7 @@ SIGNATURES = {
     "idiff_drift_reverse_step_dev": (I, [P, P, P, P, P, P, I64, P, I, P, U64, U64, U64, c_stream]),
     "idiff_step_state_advance": (I, [P, P, I, I, I, c_stream]),
     "idiff_randn": (I, [P, I64, U64, U64, c_stream]),
+    "idiff_dropout": (I, [P, P, I64, F, U64, U64, c_stream]),
     "idiff_philox_raw": (I, [P, I64, U64, U64, c_stream]),
     "idiff_axpby": (I, [P, P, P, I64, F, F, c_stream]),
     "idiff_mix3_per_sample": (I, [P, P, P, P, P, P, P, I, I64, c_stream]),

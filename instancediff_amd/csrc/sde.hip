@@ -177,6 +177,27 @@ __global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, lon
         st4(out, v * 4, n, philox_normal4(offset + (uint64_t)v, seed));
 }
 
+// Inverted dropout keyed by the Philox stream: element i is kept iff the 24 high bits of word i % 4 of counter offset + i / 4,
+// as u in [0, 1), are >= p; kept elements are scaled by 1 / (1 - p).  The mask is a pure function of (seed, offset, i): the backward
+// pass applies the same launch to the gradient instead of storing a mask.
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ out, long long n, float p, float scale,
+                                                      uint64_t seed, uint64_t offset) {
+    const long long nv = (n + 3) / 4;
+    for (long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x; v < nv; v += (long long)gridDim.x * blockDim.x) {
+        uint32_t w[4];
+        const uint64_t ctr = offset + (uint64_t)v;
+        philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long i = v * 4 + k;
+            if (i < n) {
+                const float u = (float)(w[k] >> 8) * (1.0f / 16777216.0f);
+                out[i] = u >= p ? __fmul_rn(x[i], scale) : 0.f;
+            }
+        }
+    }
+}
+
 __global__ void philox_raw_kernel(uint32_t* __restrict__ out, long long nc, uint64_t seed, uint64_t offset) {
     for (long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x; v < nc; v += (long long)gridDim.x * blockDim.x) {
         uint32_t w[4];
@@ -398,6 +419,14 @@ extern "C" int idiff_randn(float* out, int64_t n, uint64_t seed, uint64_t offset
     IDIFF_CHECK_ARG(out && n > 0, "randn: bad args");
     hipLaunchKernelGGL(randn_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, (long long)n, seed, offset);
     IDIFF_CHECK_LAUNCH("randn");
+    return IDIFF_OK;
+}
+
+extern "C" int idiff_dropout(const float* x, float* out, int64_t n, float p, uint64_t seed, uint64_t offset, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(x && out && n > 0 && p >= 0.f && p < 1.f, "dropout: bad args (p must be in [0, 1))");
+    hipLaunchKernelGGL(dropout_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, out, (long long)n, p, 1.0f / (1.0f - p),
+                       seed, offset);
+    IDIFF_CHECK_LAUNCH("dropout");
     return IDIFF_OK;
 }
 

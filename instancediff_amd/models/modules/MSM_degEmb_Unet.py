@@ -104,9 +104,10 @@ class TransformerDecoderLayer(nn.Module):  # :520-549
 
 
 class ContextDecoder(nn.Module):  # :1194-1244
-    def __init__(self, transformer_width=256, transformer_heads=4, transformer_layers=3, visual_dim=512, text_dim=512):
+    def __init__(self, transformer_width=256, transformer_heads=4, transformer_layers=3, visual_dim=512, text_dim=512, dropout=0.1):
         super().__init__()
         self.width, self.heads = transformer_width, transformer_heads
+        self.dropout = float(dropout)  # :1200 (training mode only: unet_autograd._smm; the sampling path never drops)
         self.memory_proj = nn.Sequential(nn.LayerNorm(visual_dim), nn.Linear(visual_dim, transformer_width),
                                          nn.LayerNorm(transformer_width))
         self.text_proj = nn.Sequential(nn.LayerNorm(text_dim), nn.Linear(text_dim, transformer_width))
@@ -148,7 +149,7 @@ class ScoreMapModule(nn.Module):
     feature (ContextDecoder) added back to the text emb; text (x) feature -> score map [B,K,h,w]."""
 
     def __init__(self, visual_dim=64, CLIP_Type="CLIP", token_embed_dim=512, text_dim=512, n_ctx=8, n_cls=5, prompt_len=10,
-                 decoder_layers=3, decoder_width=256, decoder_heads=4, tokenizer=None, class_names=ARTIFACT_TYPES):
+                 decoder_layers=3, decoder_width=256, decoder_heads=4, tokenizer=None, class_names=ARTIFACT_TYPES, dropout=0.1):
         super().__init__()
         self.visual_dim, self.n_cls, self.text_dim = visual_dim, n_cls, text_dim
         self.contexts = nn.Parameter(torch.zeros(1, n_ctx, token_embed_dim))
@@ -160,7 +161,7 @@ class ScoreMapModule(nn.Module):
         self.register_buffer("tokens", _class_tokens(n_cls, prompt_len) if tokenizer is None else
                              torch.as_tensor(tokenizer(list(class_names)[:n_cls])).long())
         self.text_to_visual = nn.Linear(text_dim, visual_dim)
-        self.context_decoder = ContextDecoder(decoder_width, decoder_heads, decoder_layers, visual_dim, text_dim)
+        self.context_decoder = ContextDecoder(decoder_width, decoder_heads, decoder_layers, visual_dim, text_dim, dropout=dropout)
         self.gamma = nn.Parameter(torch.ones(visual_dim) * 1e-4)
         self._text_cache = None
 

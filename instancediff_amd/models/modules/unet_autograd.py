@@ -6,7 +6,7 @@ import torch
 
 from ... import ops
 from ...train_ops import (ActFn, AddFn, AddVecFn, BgemmFn, ChanLayerNormFn, ChanNormalizeFn, ConvFn, GatherChannelFn, LayerNormRowsFn,
-                          LinearFn, ResBlockFn, ScaleColsFn, SoftmaxRowsFn)
+                          LinearFn, ResBlockFn, ScaleColsFn, SoftmaxRowsFn, dropout)
 
 
 def _resblock(rb, src0, src1, temb_act, vec=None):
@@ -91,6 +91,9 @@ def _smm(smm, feat, text_encoder, idx):
     tp = dec.text_proj
     x = LinearFn.apply(LayerNormRowsFn.apply(t2d, tp[0].weight, tp[0].bias, tp[0].eps), tp[1].weight, tp[1].bias)
     R = B * K
+    # training-mode dropout of the decoder blocks (TransformerDecoderLayer(dropout=0.1): Attention.proj_drop on both attentions, the
+    # MLP's inner Dropout and the block's output Dropout, models/_modified_BiomedCLIP.py:448-478,520-549); identity in eval()
+    pd, tr = dec.dropout, smm.training
     for layer in dec.decoder:
         sa, ca = layer.self_attn, layer.cross_attn
         n1 = LayerNormRowsFn.apply(x, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
@@ -98,7 +101,7 @@ def _smm(smm, feat, text_encoder, idx):
         k = LinearFn.apply(n1, sa.k_proj.weight, None).reshape(B, K, Wd)
         v = LinearFn.apply(n1, sa.v_proj.weight, None).reshape(B, K, Wd)
         a = _heads_attention(q, k, v, heads, sa.scale).reshape(R, Wd)
-        x = AddFn.apply(x, LinearFn.apply(a, sa.proj.weight, sa.proj.bias), 1.0)
+        x = AddFn.apply(x, dropout(LinearFn.apply(a, sa.proj.weight, sa.proj.bias), pd, tr), 1.0)
         n2 = LayerNormRowsFn.apply(x, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
         qc = LinearFn.apply(n2, ca.q_proj.weight, None)  # [R, Wd]
         # k/v projections folded onto the queries: qf_h = q_h Wk_h ; S = qf mem ; o = P mem^T ; av_h = o_h Wv_h^T.
@@ -114,10 +117,10 @@ def _smm(smm, feat, text_encoder, idx):
             oh = o[:, h * K:(h + 1) * K].reshape(1, R, Wd)
             avs.append(BgemmFn.apply(oh, ca.v_proj.weight[h * dh:(h + 1) * dh].unsqueeze(0), False, True).reshape(R, dh))
         av = torch.cat(avs, dim=-1)
-        x = AddFn.apply(x, LinearFn.apply(av, ca.proj.weight, ca.proj.bias), 1.0)
+        x = AddFn.apply(x, dropout(LinearFn.apply(av, ca.proj.weight, ca.proj.bias), pd, tr), 1.0)
         n3 = LayerNormRowsFn.apply(x, layer.norm3.weight, layer.norm3.bias, layer.norm3.eps)
-        hm = ActFn.apply(LinearFn.apply(n3, layer.mlp[0].weight, layer.mlp[0].bias), ops.ACT_GELU)
-        x = AddFn.apply(x, LinearFn.apply(hm, layer.mlp[3].weight, layer.mlp[3].bias), 1.0)
+        hm = dropout(ActFn.apply(LinearFn.apply(n3, layer.mlp[0].weight, layer.mlp[0].bias), ops.ACT_GELU), pd, tr)
+        x = AddFn.apply(x, dropout(LinearFn.apply(hm, layer.mlp[3].weight, layer.mlp[3].bias), pd, tr), 1.0)
     op = dec.out_proj
     diff = LinearFn.apply(LayerNormRowsFn.apply(x, op[0].weight, op[0].bias, op[0].eps), op[1].weight, op[1].bias)  # [R, C]
     t2v = LinearFn.apply(t2d, smm.text_to_visual.weight, smm.text_to_visual.bias)

@@ -603,6 +603,16 @@ def randn(shape, device, seed, offset=0):
     return out
 
 
+def dropout(x, p, seed, offset, out=None):
+    """inverted dropout with the Philox-keyed mask of (seed, offset): x / (1-p) where kept, else 0 (the backward is the same call)"""
+    lib = _lib.load()
+    _c(x, "x")
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.idiff_dropout(_p(x), _p(out), x.numel(), float(p), int(seed), int(offset), _stream()), "dropout")
+    return out
+
+
 def philox_raw(ncounters, device, seed, offset=0):
     lib = _lib.load()
     out = torch.empty((ncounters, 4), device=device, dtype=torch.int32)

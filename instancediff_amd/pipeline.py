@@ -16,13 +16,17 @@ def load_options(path=DEFAULT_YAML, is_train=False):
     return option.dict_to_nonedict(option.parse(path, is_train=is_train))
 
 
-def build(opt=None, phase="test", device=None, T=None, seed=0, dist=False, sde_overrides=None):
-    """-> (model: CLIPDriftModel, sde).  Random-init weights (seed) as the reference does for a fresh run."""
+def build(opt=None, phase="test", device=None, T=None, seed=0, dist=False, sde_overrides=None, score_map_dropout=None):
+    """-> (model: CLIPDriftModel, sde).  Random-init weights (seed) as the reference does for a fresh run.
+    score_map_dropout: overrides the model option of that name (training-mode dropout of the ScoreMapModule decoder blocks; 0.1)."""
     opt = opt or load_options()
     train_opt = copy.deepcopy(dict(opt['train']))
     train_opt['dist'] = dist
     which = (opt['test'] or {}).get('which_model') if phase == 'test' and opt['test'] else None
     model_opt = opt['models'][which or train_opt['which_model']]
+    if score_map_dropout is not None:
+        model_opt = copy.copy(model_opt)
+        model_opt['score_map_dropout'] = float(score_map_dropout)
     torch.manual_seed(seed)
     from .models.drift_noise_model import create_CLIPDriftModel  # registry target, imported for the device kwarg
     model = create_CLIPDriftModel(train_opt, model_opt, phase=phase, device=device) if device is not None else \

@@ -377,6 +377,47 @@ class ActFn(torch.autograd.Function):
         return dx, None
 
 
+class DropoutState:
+    """Philox stream of the training-mode dropouts (one per process: seed + a cumulative counter offset, so successive dropouts of any
+    sizes use disjoint counter ranges).  `record`, when set to a list, collects (shape, seed, offset, p) of every dropout in call
+    order -- tests use it to inject the very same masks into the oracle."""
+    seed = 20240
+    offset = 0
+    record = None
+
+    @classmethod
+    def reset(cls, seed):
+        cls.seed, cls.offset = int(seed), 0
+
+    @classmethod
+    def next(cls, numel):
+        off = cls.offset
+        cls.offset += (numel + 3) // 4
+        return cls.seed, off
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout(p) in training mode on the HIP dropout kernel: the mask is regenerated from (seed, offset) in the backward pass"""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        x = x.contiguous()
+        ctx.p = float(p)
+        ctx.seed, ctx.offset = DropoutState.next(x.numel())
+        if DropoutState.record is not None:
+            DropoutState.record.append((tuple(x.shape), ctx.seed, ctx.offset, ctx.p))
+        return ops.dropout(x, ctx.p, ctx.seed, ctx.offset)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.dropout(dy.contiguous(), ctx.p, ctx.seed, ctx.offset), None
+
+
+def dropout(x, p, training):
+    """identity unless training with p > 0 (so eval() and dropout: 0 are bit-identical to the path without it)"""
+    return DropoutFn.apply(x, p) if (training and p > 0.0) else x
+
+
 class AddFn(torch.autograd.Function):
     """a + alpha*b (same shape, contiguous)"""
 

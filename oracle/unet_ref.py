@@ -56,23 +56,42 @@ class Attention(nn.Module):  # _modified_BiomedCLIP.py:448-478 (qkv_bias=False, 
         return self.proj(x)
 
 
-class TransformerDecoderLayer(nn.Module):  # :520-549, dropout = 0 (spec)
-    def __init__(self, d_model, nhead):
+class InjectedDropout(nn.Module):
+    """nn.Dropout(p) whose masks come from outside: in training mode each call takes the next mask of the class-level queue (a
+    0/1 tensor of the input's shape; the tests fill it with the masks the product's Philox stream produced, in call order) and
+    returns x * mask / (1 - p).  With an empty queue, in eval() or at p = 0 it is the identity."""
+    queue = []
+
+    def __init__(self, p):
+        super().__init__()
+        self.p = float(p)
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0 or not InjectedDropout.queue:
+            return x
+        mask = InjectedDropout.queue.pop(0)
+        assert mask.numel() == x.numel(), (mask.shape, x.shape)
+        return x * mask.reshape(x.shape).to(x.dtype) / (1.0 - self.p)
+
+
+class TransformerDecoderLayer(nn.Module):  # :520-549; dropout sites as the reference: both attentions' proj_drop, the MLP's, the block's
+    def __init__(self, d_model, nhead, dropout=0.1):
         super().__init__()
         self.self_attn = Attention(d_model, nhead)
         self.cross_attn = Attention(d_model, nhead)
         self.norm1 = nn.LayerNorm(d_model)
         self.norm2 = nn.LayerNorm(d_model)
         self.norm3 = nn.LayerNorm(d_model)
-        self.mlp = nn.Sequential(nn.Linear(d_model, d_model * 4), nn.GELU(), nn.Identity(),
+        self.sa_drop, self.ca_drop, self.dropout = InjectedDropout(dropout), InjectedDropout(dropout), InjectedDropout(dropout)
+        self.mlp = nn.Sequential(nn.Linear(d_model, d_model * 4), nn.GELU(), InjectedDropout(dropout),
                                  nn.Linear(d_model * 4, d_model))
 
     def forward(self, x, mem):
         q = k = v = self.norm1(x)
-        x = x + self.self_attn(q, k, v)
+        x = x + self.sa_drop(self.self_attn(q, k, v))     # Attention.proj_drop (:476-477)
         q = self.norm2(x)
-        x = x + self.cross_attn(q, mem, mem)
-        x = x + self.mlp(self.norm3(x))
+        x = x + self.ca_drop(self.cross_attn(q, mem, mem))
+        x = x + self.dropout(self.mlp(self.norm3(x)))
         return x
 
 

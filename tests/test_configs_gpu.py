@@ -146,7 +146,7 @@ def _flat_grads(model):
 
 def test_c3_train_step_256_vs_oracle_autograd():
     B, H, T_ = 2, 256, 100
-    model, sde = pipeline.build(phase="train", device=torch.device(DEV), T=T_, seed=0)
+    model, sde = pipeline.build(phase="train", device=torch.device(DEV), T=T_, seed=0, score_map_dropout=0.0)
     model.set_train()
     with torch.no_grad():  # let the score-map branch carry gradient signal (gamma is 1e-4 at init)
         for net in (model.drift_net, model.noise_net):
@@ -196,7 +196,7 @@ def test_c3_train_step_256_vs_oracle_autograd():
 
 def test_c3_batch32_gradient_is_mean_of_microbatch_gradients():
     B, H, T_, MB = 32, 256, 100, 2
-    model, sde = pipeline.build(phase="train", device=torch.device(DEV), T=T_, seed=0)
+    model, sde = pipeline.build(phase="train", device=torch.device(DEV), T=T_, seed=0, score_map_dropout=0.0)
     model.set_train()
     with torch.no_grad():
         for net in (model.drift_net, model.noise_net):

@@ -74,13 +74,13 @@ def test_train_step_with_rccl_exchange_overlapped(rccl_world1):
     g = torch.Generator().manual_seed(7)
     t = torch.tensor([[[[5]]], [[[17]]]])
     eps = torch.randn(batch['input'].shape, generator=g)
-    ref_model, ref_sde = pipeline.build(phase="train", device=torch.device(DEV), T=T_, seed=0)
+    ref_model, ref_sde = pipeline.build(phase="train", device=torch.device(DEV), T=T_, seed=0, score_map_dropout=0.0)
     ref_model.set_train()
     _train_inputs(ref_model, ref_sde, batch, t, eps)
     train_ops.forward_backward_inputRes(ref_model)
     ref = _grads(ref_model)
     for wire in ("fp32", "bf16"):
-        model, sde = pipeline.build(phase="train", device=torch.device(DEV), T=T_, seed=0, dist=True)
+        model, sde = pipeline.build(phase="train", device=torch.device(DEV), T=T_, seed=0, dist=True, score_map_dropout=0.0)
         assert model.grad_sync is not None  # built because a process group is alive
         model.grad_sync = GradSync(single_rank_collectives=True, wire=wire)
         model.grad_sync.broadcast_parameters(list(model.drift_net.parameters()) + list(model.noise_net.parameters()))

@@ -203,7 +203,7 @@ def _oracle_pair(model):
 
 def test_unet_param_gradients_and_train_steps_vs_oracle():
     B, H, T_ = 2, 32, 20
-    model, sde = pipeline.build(phase="train", device=torch.device(DEV), T=T_, seed=0)
+    model, sde = pipeline.build(phase="train", device=torch.device(DEV), T=T_, seed=0, score_map_dropout=0.0)
     model.set_train()
     with torch.no_grad():  # make the tiny-gamma / zero-bias paths carry signal
         for net in (model.drift_net, model.noise_net):
@@ -387,3 +387,102 @@ def test_optimize_score_map_by_name_with_the_reference_size_argument():
         assert float((gh.cpu() - leaf.grad).abs().max()) < 2e-6 * float(leaf.grad.abs().max()) + 1e-12  # the /2 of :240 included
     # default size = the label's own
     assert float(model.optimize_score_map([s.to(DEV) for s in sms], label.to(DEV))) == float(loss)
+
+
+def test_dropout_kernel_mask_is_a_function_of_seed_and_offset():
+    """idiff_dropout: kept iff (w >> 8) * 2^-24 >= p on the Philox words of (seed, offset + i / 4); kept values scaled by 1 / (1 - p);
+    the backward is the same call (same mask); p = 0 keeps everything."""
+    n, p, seed, off = 80 * 1024 + 3, 0.1, 77, 1234
+    g = _g(81)
+    x = torch.randn(n, generator=g).to(DEV)
+    y = ops.dropout(x, p, seed, off)
+    words = ops.philox_raw((n + 3) // 4, DEV, seed, off).reshape(-1)[:n].to(torch.int64) & 0xFFFFFFFF
+    keep = ((words >> 8).double() * 2.0 ** -24) >= p
+    assert torch.equal(y != 0, keep & (x != 0))
+    assert torch.equal(y[keep], x[keep] * torch.tensor(1.0 / (1.0 - p), dtype=torch.float32, device=DEV))
+    frac = float(keep.float().mean())
+    assert abs(frac - 0.9) < 5e-3, frac
+    assert torch.equal(ops.dropout(x, p, seed, off), y) and not torch.equal(ops.dropout(x, p, seed, off + 1), y)
+    assert torch.equal(ops.dropout(x, 0.0, seed, off), x)
+    # autograd Function: the backward regenerates the mask of the forward
+    T.DropoutState.reset(5)
+    xr = x.clone().requires_grad_(True)
+    out = T.dropout(xr, p, True)
+    out.backward(torch.ones_like(out))
+    assert torch.equal(xr.grad != 0, out != 0) or float(((xr.grad != 0) ^ (out != 0)).sum()) <= float((x == 0).sum())
+    assert T.dropout(xr, p, False) is xr and T.dropout(xr, 0.0, True) is xr
+
+
+def test_training_dropout_of_the_decoder_blocks_vs_oracle_with_the_same_masks():
+    """set_train() trains the function the reference trains: TransformerDecoderLayer(dropout=0.1) -- Attention.proj_drop on both
+    attentions, the MLP's inner Dropout and the block's Dropout (models/_modified_BiomedCLIP.py:448-478,520-549).  The product's
+    masks (Philox, regenerated in the backward) are recorded in call order and injected into the oracle's autograd: loss and every
+    parameter gradient must agree; eval() is untouched by the option."""
+    B, H, T_ = 2, 32, 20
+    model, sde = pipeline.build(phase="train", device=torch.device(DEV), T=T_, seed=0)   # default: the reference's 0.1
+    assert all(m.context_decoder.dropout == 0.1 for m in model.drift_net.CLIP_ScoreMapModule)
+    model.set_train()
+    with torch.no_grad():
+        for net in (model.drift_net, model.noise_net):
+            for m in net.CLIP_ScoreMapModule:
+                m.gamma.fill_(0.3)
+    rd, rn = _oracle_pair(model)
+    rd.train(), rn.train()
+    te = unet_ref.StubTextEncoder()
+    batch = make_batch(B, H, seed=13)
+    g = _g(17)
+    t = torch.tensor([[[[5]]], [[[17]]]])
+    eps = torch.randn(batch['input'].shape, generator=g)
+    model.input, model.target = batch['input'].to(DEV), batch['target'].to(DEV)
+    model.names, model.A_emb = batch['names'], batch['A_emb'].to(DEV)
+    model.t, model.drift_noised_x, _, model.std_noise, _ = sde.forward_diffusion(model.target, model.input, t=t, eps=eps.to(DEV))
+    T.DropoutState.reset(4242)
+    T.DropoutState.record = []
+    try:
+        rec, _, _, _ = T.forward_backward_inputRes(model)
+        record = T.DropoutState.record
+    finally:
+        T.DropoutState.record = None
+    n_sites = 2 * 4 * 3 * 4   # nets x ScoreMapModules x decoder layers x dropout sites
+    assert len(record) == n_sites, len(record)
+    r = rec.cpu()
+    loss = float(r[0] + r[1] + r[2:6].sum() / 2 + r[6:10].sum() / 2)
+    # the same masks, as 0/1 tensors, in the oracle's call order (drift net then noise net; level, layer, site -- the product's order)
+    unet_ref.InjectedDropout.queue = [(ops.dropout(torch.ones(shape, device=DEV), p, seed, off) != 0).float().cpu() for shape, seed, off, p in record]
+    kept = sum(float(m.sum()) for m in unet_ref.InjectedDropout.queue) / sum(m.numel() for m in unet_ref.InjectedDropout.queue)
+    assert 0.88 < kept < 0.92, kept
+    osde = sde_ref.DriftSDERef(T_, rd, rn, max_sigma=0.4)
+    _, x_t, _, std_noise, _ = osde.forward_diffusion(batch['target'], batch['input'], t, eps)
+    tt = t.reshape(-1)
+    pd, dsm = rd(x_t - batch['input'], batch['input'], tt, batch['names'], te, image_context=batch['A_emb'])
+    pn, nsm = rn(x_t - batch['input'], x_t, tt, batch['names'], te, image_context=batch['A_emb'])
+    assert not unet_ref.InjectedDropout.queue, "the oracle consumed a different number of dropout masks"
+    tgt = batch['input'] - batch['target']
+
+    def pyr(sms, lab):
+        tot = 0
+        for i, sm in enumerate(sms):
+            lb = lab if i == 0 else F.interpolate(lab, size=(H >> i, H >> i), mode="bilinear", align_corners=False, antialias=False)
+            tot = tot + F.mse_loss(sm, lb)
+        return tot / 2.0
+    l0 = F.mse_loss(pd, tgt) + F.mse_loss(pn, std_noise) + pyr(dsm, tgt) + pyr(nsm, std_noise)
+    l0.backward()
+    assert abs(loss - float(l0.detach())) < 2e-5 * abs(float(l0.detach())), (loss, float(l0.detach()))
+    worst = 0.0
+    for net, ref in ((model.drift_net, rd), (model.noise_net, rn)):
+        refg = dict(ref.named_parameters())
+        for k, p_ in net.named_parameters():
+            rg = refg[k].grad
+            scale = float(rg.abs().max())
+            if scale < 1e-12:
+                assert float(p_.grad.abs().max()) < 1e-9, k
+                continue
+            e = float((p_.grad.cpu() - rg).abs().max()) / scale
+            worst = max(worst, e)
+            assert e < 2e-3, (k, e)
+    print(f"decoder dropout 0.1: {n_sites} masks, kept {kept:.4f}; loss {loss:.6f} (oracle {float(l0.detach()):.6f}), worst relative gradient error {worst:.2e}")
+    # a second backward with other masks gives other gradients (the masks matter), eval() ignores the option
+    g1 = torch.cat([p_.grad.reshape(-1) for p_ in model.drift_net.CLIP_ScoreMapModule.parameters() if p_.grad is not None]).clone()
+    T.forward_backward_inputRes(model)
+    g2 = torch.cat([p_.grad.reshape(-1) for p_ in model.drift_net.CLIP_ScoreMapModule.parameters() if p_.grad is not None])
+    assert not torch.equal(g1, g2)
