@@ -506,7 +506,8 @@ __global__ __launch_bounds__(256) void smm_xattn_kernel(const float* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void smm_xattn_combine_kernel(const float* __restrict__ ws, float* __restrict__ o, int rows, int nsplit, int XCM) {
+__global__ __launch_bounds__(256) void smm_xattn_combine_kernel(const float* __restrict__ ws, float* __restrict__ o, int rows, int nsplit, int XCM,
+                                                                float* __restrict__ lse) {
     // thread = (channel c, row): the partials are laid out [c][32 rows], so a wave reads two full 128-byte lines per split
     const int b = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over XCM * 32
@@ -530,6 +531,188 @@ __global__ __launch_bounds__(256) void smm_xattn_combine_kernel(const float* __r
         acc += w[c * 32 + row] * f;
     }
     o[((long long)b * rows + row) * XCM + c] = acc / L;
+    if (lse && c == 0) lse[(long long)b * rows + row] = M + __logf(L);  // log-sum-exp of the scaled scores (training: saved for the backward)
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Backward of the ScoreMapModule cross-attention over the full 256-row memory (training path), one pass over the keys:
+//   S = scale * qf mem,  P = exp(S - lse),  o = P mem^T          (forward; lse saved)
+//   dP = do mem,  D = rowsum(do * o),  G = scale * P * (dP - D)
+//   dqf = G mem^T          (per key split; summed over the splits in a fixed order by smm_xattn_bwd_combine_kernel)
+//   dmem = do^T P + qf^T G
+// replacing, per decoder layer, seven batched-GEMM / softmax launches that each streamed the [B, 256, N] memory or the [B, rows, N]
+// score matrices through HBM (91 ms of a 400-ms training step at 256x256, batch 32).  Same tiling as the forward kernel: 4 waves
+// split the 256 channels (partial S / dP tiles meet in LDS), 32-key blocks, f32 MFMA 32x32x2 throughout; P and G are taken straight
+// from the accumulators as B operands for dqf, and through a 32x32 LDS transpose (keys onto the lanes) for dmem.
+//   LDS: mem tile 4 x [64][33]; qf and do as [32 rows][257]; exchange / transpose area 4 x 2304; row constants.
+__global__ __launch_bounds__(256) void smm_xattn_bwd_kernel(const float* __restrict__ qf, const float* __restrict__ mem, const float* __restrict__ o,
+                                                            const float* __restrict__ lse, const float* __restrict__ d_o, float* __restrict__ ws,
+                                                            float* __restrict__ dmem, int rows, int N, int nsplit, int kps, float scale) {
+    constexpr int XCW = 64, XCM = 256, XTILE = 64 * 33, XP = 257, XREG = 2304;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tile = smem + (threadIdx.x >> 6) * XTILE;  // private per wave: [64 c][33]
+    float* qL = smem + 4 * XTILE;                     // [32][257]
+    float* dL = qL + 32 * XP;                         // [32][257]
+    float* xch = dL + 32 * XP;                        // [4][2304]: partial S | dP tiles, then each wave's transposed P | G
+    float* rowc = xch + 4 * XREG;                     // [2][32]: lse, D
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y, sp = blockIdx.x;
+    const int c0 = wave * XCW;
+    const float* memb = mem + (long long)b * XCM * N + (long long)c0 * N;
+    float* dmemb = dmem + (long long)b * XCM * N + (long long)c0 * N;
+
+    // qf, do -> LDS (rows beyond `rows` are zero); D = rowsum(do * o): 8 threads per row, 32 channels each
+    for (int i = tid; i < 32 * XCM; i += 256) {
+        const int r = i >> 8, c = i & 255;
+        const bool v = r < rows;
+        qL[r * XP + c] = v ? qf[((long long)b * rows + r) * XCM + c] : 0.f;
+        dL[r * XP + c] = v ? d_o[((long long)b * rows + r) * XCM + c] : 0.f;
+    }
+    {
+        const int r = tid >> 3, part = tid & 7;
+        float acc = 0.f;
+        if (r < rows)
+            for (int c = part * 32; c < part * 32 + 32; ++c) acc += d_o[((long long)b * rows + r) * XCM + c] * o[((long long)b * rows + r) * XCM + c];
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        if (part == 0) {
+            rowc[32 + r] = acc;
+            rowc[r] = r < rows ? lse[(long long)b * rows + r] : INFINITY;  // padding rows: P = exp(-inf) = 0
+        }
+    }
+    __syncthreads();
+    const float my_lse = rowc[l31], my_D = rowc[32 + l31];
+
+    floatx16 Oq[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Oq[m][r] = 0.f;
+
+    const int nkb = (N + 31) / 32;
+    const int kb_begin = sp * kps;
+    const int kb_end = min(nkb, kb_begin + kps);
+    floatx4 rt[8];  // 64 c x 32 keys / 64 lanes
+    auto load_tile = [&](int kbi) {
+        const int key0 = kbi * 32;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = lane + i * 64;  // float4 index in [64][8]
+            const int c = f >> 3, j4 = (f & 7) * 4;
+            floatx4 z = {0.f, 0.f, 0.f, 0.f};
+            if (key0 + j4 + 3 < N)
+                z = *reinterpret_cast<const floatx4*>(memb + (long long)c * N + key0 + j4);
+            else
+                for (int e = 0; e < 4; ++e)
+                    if (key0 + j4 + e < N) z[e] = memb[(long long)c * N + key0 + j4 + e];
+            rt[i] = z;
+        }
+    };
+    auto write_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = lane + i * 64;
+            const int c = f >> 3, j4 = (f & 7) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[c * 33 + j4 + e] = rt[i][e];
+        }
+    };
+    if (kb_begin < kb_end) {
+        load_tile(kb_begin);
+        write_tile();
+    }
+    const float* qB = qL + l31 * XP + c0 + half;  // B operand of the S product: X[row = l31][c0 + 2t + half]
+    const float* dB = dL + l31 * XP + c0 + half;
+    for (int kbi = kb_begin; kbi < kb_end; ++kbi) {
+        if (kbi + 1 < kb_end) load_tile(kbi + 1);
+        // ---- partial S and dP over this wave's 64 channels: [32 keys][32 rows] ----
+        floatx16 S, dP;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f, dP[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < XCW / 2; ++t) {
+            const float a = tile[(2 * t + half) * 33 + l31];
+            S = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qB[2 * t], S, 0, 0, 0);
+            dP = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dB[2 * t], dP, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            xch[wave * XREG + r * 64 + lane] = S[r];
+            xch[wave * XREG + 1024 + r * 64 + lane] = dP[r];
+        }
+        __syncthreads();
+        const int key0 = kbi * 32 + 4 * half;
+        floatx16 G;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float sv = ((xch[r * 64 + lane] + xch[XREG + r * 64 + lane]) + xch[2 * XREG + r * 64 + lane]) + xch[3 * XREG + r * 64 + lane];
+            const float dv = ((xch[1024 + r * 64 + lane] + xch[XREG + 1024 + r * 64 + lane]) + xch[2 * XREG + 1024 + r * 64 + lane]) +
+                             xch[3 * XREG + 1024 + r * 64 + lane];
+            const float p = (key0 + KAPPA(r) < N) ? __expf(sv * scale - my_lse) : 0.f;
+            S[r] = p;
+            G[r] = scale * p * (dv - my_D);
+        }
+        __syncthreads();  // every wave has read the partial tiles: the area now takes the transposed P | G of each wave
+        // ---- dqf^T[c][row] += sum_key mem[c][key] G[key][row]  (G straight from the accumulator layout) ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                Oq[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(tile[(m * 32 + l31) * 33 + KAPPA(r) + 4 * half], G[r], Oq[m], 0, 0, 0);
+        // ---- dmem[c][key] = sum_row do[row][c] P[key][row] + qf[row][c] G[key][row]: P, G with the keys on the lanes ----
+        float* pt = xch + wave * XREG;   // [32 rows][33]
+        float* gt = pt + 32 * 33;        // [32 rows][33]   (2 * 1056 = 2112 <= 2304)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            pt[l31 * 33 + KAPPA(r) + 4 * half] = S[r];
+            gt[l31 * 33 + KAPPA(r) + 4 * half] = G[r];
+        }
+        // (wave-private area: the reads below follow the writes in program order; LDS is in order within a wave)
+        floatx16 Dm[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Dm[m][r] = 0.f;
+#pragma unroll
+        for (int sidx = 0; sidx < 16; ++sidx) {
+            const int row = 2 * sidx + half;
+            const float pb = pt[row * 33 + l31], gb = gt[row * 33 + l31];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                Dm[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(dL[row * XP + c0 + m * 32 + l31], pb, Dm[m], 0, 0, 0);
+                Dm[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(qL[row * XP + c0 + m * 32 + l31], gb, Dm[m], 0, 0, 0);
+            }
+        }
+        const int key = kbi * 32 + l31;
+        if (key < N) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dmemb[(long long)(m * 32 + KAPPA(r) + 4 * half) * N + key] = Dm[m][r];
+        }
+        if (kbi + 1 < kb_end) write_tile();
+        __syncthreads();  // the tile and the exchange area are rewritten by the next block
+    }
+    // partial dqf: ws[b][sp][c][row]
+    float* wp = ws + ((long long)b * nsplit + sp) * XCM * 32;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wp[(c0 + m * 32 + KAPPA(r) + 4 * half) * 32 + l31] = Oq[m][r];
+}
+
+// dqf[b][row][c] = sum over the key splits, in order
+__global__ __launch_bounds__(256) void smm_xattn_bwd_combine_kernel(const float* __restrict__ ws, float* __restrict__ dqf, int rows, int nsplit) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 256 * 32
+    const int c = i >> 5, row = i & 31;
+    if (c >= 256 || row >= rows) return;
+    const float* wb = ws + (long long)b * nsplit * 256 * 32;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int s = 0; s < nsplit; ++s) acc += wb[(long long)s * 256 * 32 + c * 32 + row];
+    dqf[((long long)b * rows + row) * 256 + c] = acc;
 }
 
 inline void smm_split(int B, int N, int* nsplit, int* kps) {
@@ -634,8 +817,8 @@ extern "C" int64_t idiff_smm_xattn_ws_floats(int B, int Nq, int heads, int Cm, i
     return (int64_t)B * ns * (Cm + 2) * 32;
 }
 
-extern "C" int idiff_smm_xattn_fwd(const float* qf, const float* mem, float* o, float* ws, int B, int Nq, int heads, int Cm, int N, float scale,
-                                   idiff_stream_t stream) {
+static int smm_xattn_fwd_impl(const float* qf, const float* mem, float* o, float* lse, float* ws, int B, int Nq, int heads, int Cm, int N, float scale,
+                              idiff_stream_t stream) {
     IDIFF_CHECK_ARG(qf && mem && o && ws && B > 0 && Nq > 0 && heads > 0 && N > 0, "smm_xattn: bad args");
     IDIFF_CHECK_ARG(Cm == 256 || Cm == 136 || Cm == 72, "smm_xattn: Cm must be 72, 136 or 256 (got %d)", Cm);
     IDIFF_CHECK_ARG(Nq * heads <= 32, "smm_xattn: Nq*heads must be <= 32 (got %d)", Nq * heads);
@@ -653,7 +836,40 @@ extern "C" int idiff_smm_xattn_fwd(const float* qf, const float* mem, float* o, 
     else
         hipLaunchKernelGGL(smm_xattn_kernel<18>, dim3(ns, B), dim3(256), lds, st, qf, mem, ws, rows, N, ns, kps, scale);
     IDIFF_CHECK_LAUNCH("smm_xattn_fwd");
-    hipLaunchKernelGGL(smm_xattn_combine_kernel, dim3((32 * Cm + 255) / 256, B), dim3(256), 0, st, ws, o, rows, ns, Cm);
+    hipLaunchKernelGGL(smm_xattn_combine_kernel, dim3((32 * Cm + 255) / 256, B), dim3(256), 0, st, ws, o, rows, ns, Cm, lse);
     IDIFF_CHECK_LAUNCH("smm_xattn_combine");
+    return IDIFF_OK;
+}
+
+extern "C" int idiff_smm_xattn_fwd(const float* qf, const float* mem, float* o, float* ws, int B, int Nq, int heads, int Cm, int N, float scale,
+                                   idiff_stream_t stream) {
+    return smm_xattn_fwd_impl(qf, mem, o, nullptr, ws, B, Nq, heads, Cm, N, scale, stream);
+}
+
+extern "C" int idiff_smm_xattn_lse_fwd(const float* qf, const float* mem, float* o, float* lse, float* ws, int B, int rows, int N, float scale,
+                                       idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(lse, "smm_xattn_lse_fwd: null lse");
+    return smm_xattn_fwd_impl(qf, mem, o, lse, ws, B, rows, 1, 256, N, scale, stream);
+}
+
+extern "C" int idiff_smm_xattn_bwd(const float* qf, const float* mem, const float* o, const float* lse, const float* d_o, float* dqf, float* dmem,
+                                   float* ws, int B, int rows, int N, float scale, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(qf && mem && o && lse && d_o && dqf && dmem && ws && B > 0 && N > 0, "smm_xattn_bwd: bad args");
+    IDIFF_CHECK_ARG(rows >= 1 && rows <= 32, "smm_xattn_bwd: rows must be in 1..32 (got %d)", rows);
+    IDIFF_CHECK_ARG(N % 4 == 0, "smm_xattn_bwd: N must be a multiple of 4");
+    int ns, kps;
+    smm_split(B, N, &ns, &kps);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)(4 * 64 * 33 + 2 * 32 * 257 + 4 * 2304 + 64) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(smm_xattn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "smm_xattn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr = true;
+    }
+    hipLaunchKernelGGL(smm_xattn_bwd_kernel, dim3(ns, B), dim3(256), lds, st, qf, mem, o, lse, d_o, ws, dmem, rows, N, ns, kps, scale);
+    IDIFF_CHECK_LAUNCH("smm_xattn_bwd");
+    hipLaunchKernelGGL(smm_xattn_bwd_combine_kernel, dim3(32, B), dim3(256), 0, st, ws, dqf, rows, ns);
+    IDIFF_CHECK_LAUNCH("smm_xattn_bwd_combine");
     return IDIFF_OK;
 }

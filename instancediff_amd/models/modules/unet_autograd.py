@@ -6,7 +6,12 @@ import torch
 
 from ... import ops
 from ...train_ops import (ActFn, AddFn, AddVecFn, BgemmFn, ChanLayerNormFn, ChanNormalizeFn, ConvFn, GatherChannelFn, LayerNormRowsFn,
-                          LinearFn, ResBlockFn, ScaleColsFn, SoftmaxRowsFn, dropout)
+                          LinearFn, ResBlockFn, ScaleColsFn, SmmXattnFn, SoftmaxRowsFn, dropout)
+
+
+# IDIFF_FUSED_XATTN=0: the ScoreMapModule cross-attention of the training path as batched GEMMs + softmax (autograd-derived backward)
+import os  # noqa: E402
+FUSED_XATTN = bool(int(os.environ.get("IDIFF_FUSED_XATTN", "1")))
 
 
 def _resblock(rb, src0, src1, temb_act, vec=None):
@@ -109,9 +114,12 @@ def _smm(smm, feat, text_encoder, idx):
         qfs = [BgemmFn.apply(qc[:, h * dh:(h + 1) * dh].unsqueeze(0), ca.k_proj.weight[h * dh:(h + 1) * dh].unsqueeze(0), False, False)
                .reshape(B, K, Wd) for h in range(heads)]
         qf = torch.cat(qfs, dim=1)                                   # [B, heads*K, Wd], row = h*K + k
-        s = BgemmFn.apply(qf, mem, False, False)                     # [B, heads*K, N]
-        p = SoftmaxRowsFn.apply(s, ca.scale)
-        o = BgemmFn.apply(p, mem, False, True)                       # [B, heads*K, Wd]
+        if FUSED_XATTN and heads * K <= 32 and Wd == 256 and N % 4 == 0:
+            o = SmmXattnFn.apply(qf, mem, ca.scale)                  # one fused forward, one fused backward pass over the keys
+        else:
+            s = BgemmFn.apply(qf, mem, False, False)                 # [B, heads*K, N]
+            p = SoftmaxRowsFn.apply(s, ca.scale)
+            o = BgemmFn.apply(p, mem, False, True)                   # [B, heads*K, Wd]
         avs = []
         for h in range(heads):
             oh = o[:, h * K:(h + 1) * K].reshape(1, R, Wd)

@@ -232,6 +232,43 @@ class BgemmFn(torch.autograd.Function):
         return dA, dB, None, None
 
 
+class SmmXattnFn(torch.autograd.Function):
+    """ScoreMapModule cross-attention with the K/V projections folded onto the queries, over the 256-row memory:
+    o[b,r,:] = softmax_n(scale * qf[b,r,:] . mem[b,:,n]) . mem[b,:,n]^T  with qf, o [B, rows <= 32, 256], mem [B, 256, N].
+    Forward = the sampling path's flash-decoding kernel (+ log-sum-exp), backward = ONE fused pass over the keys
+    (idiff_smm_xattn_bwd) instead of the seven batched-GEMM / softmax launches autograd derived per decoder layer."""
+
+    @staticmethod
+    def forward(ctx, qf, mem, scale):
+        lib = _lib.load()
+        qf, mem = qf.contiguous(), mem.contiguous()
+        _c(qf), _c(mem)
+        B, R, Cm = qf.shape
+        N = mem.shape[2]
+        assert Cm == 256 and tuple(mem.shape[:2]) == (B, 256) and R <= 32
+        o = torch.empty_like(qf)
+        lse = torch.empty((B, R), device=qf.device, dtype=torch.float32)
+        ws = torch.empty((lib.idiff_smm_xattn_ws_floats(B, R, 1, 256, N),), device=qf.device, dtype=torch.float32)
+        check(lib.idiff_smm_xattn_lse_fwd(_p(qf), _p(mem), _p(o), _p(lse), _p(ws), B, R, N, scale, _stream()), "smm_xattn_lse_fwd")
+        ctx.save_for_backward(qf, mem, o, lse)
+        ctx.scale = scale
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        lib = _lib.load()
+        qf, mem, o, lse = ctx.saved_tensors
+        d_o = d_o.contiguous()
+        B, R, _ = qf.shape
+        N = mem.shape[2]
+        dqf = torch.empty_like(qf)
+        dmem = torch.empty_like(mem)
+        ws = torch.empty((lib.idiff_smm_xattn_ws_floats(B, R, 1, 256, N),), device=qf.device, dtype=torch.float32)
+        check(lib.idiff_smm_xattn_bwd(_p(qf), _p(mem), _p(o), _p(lse), _p(d_o), _p(dqf), _p(dmem), _p(ws), B, R, N, ctx.scale, _stream()),
+              "smm_xattn_bwd")
+        return dqf, dmem, None
+
+
 class SoftmaxRowsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, scale):

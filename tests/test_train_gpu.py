@@ -486,3 +486,25 @@ def test_training_dropout_of_the_decoder_blocks_vs_oracle_with_the_same_masks():
     T.forward_backward_inputRes(model)
     g2 = torch.cat([p_.grad.reshape(-1) for p_ in model.drift_net.CLIP_ScoreMapModule.parameters() if p_.grad is not None])
     assert not torch.equal(g1, g2)
+
+
+@pytest.mark.parametrize("B,R,N", [(2, 20, 1024), (1, 20, 4096 + 32), (3, 7, 96), (2, 32, 65536)])
+def test_fused_scoremap_cross_attention_forward_backward_vs_fp64(B, R, N):
+    """SmmXattnFn (training path): o and lse of the flash-decoding forward, dqf and dmem of the one-pass fused backward, against
+    fp64 autograd of softmax(scale * qf mem) mem^T; the key split of the big case covers 64 splits with the fixed-order combine."""
+    g = _g(90 + R)
+    qf = (torch.randn(B, R, 256, generator=g) * 0.3)
+    mem = torch.randn(B, 256, N, generator=g)
+    do = torch.randn(B, R, 256, generator=g)
+    scale = 0.125
+    q64, m64 = qf.double().requires_grad_(True), mem.double().requires_grad_(True)
+    s = torch.einsum('brc,bcn->brn', q64, m64) * scale
+    o64 = torch.einsum('brn,bcn->brc', s.softmax(-1), m64)
+    o64.backward(do.double())
+    qd, md = qf.to(DEV).requires_grad_(True), mem.to(DEV).requires_grad_(True)
+    o = T.SmmXattnFn.apply(qd, md, scale)
+    o.backward(do.to(DEV))
+    for name, got, ref, tol in (("o", o, o64, 2e-5), ("dqf", qd.grad, q64.grad, 5e-5), ("dmem", md.grad, m64.grad, 5e-5)):
+        e = float((got.detach().cpu().double() - ref.detach()).abs().max() / ref.detach().abs().max())
+        print(f"fused cross-attention B={B} R={R} N={N}: {name} rel err {e:.2e}")
+        assert e < tol, (name, e)
