@@ -265,11 +265,12 @@ int idiff_smm_xattn_fwd(const float* qf, const float* mem, float* o, float* ws, 
  * the forward also returns lse [B, rows] (log-sum-exp of the scaled scores); the backward makes ONE pass over the keys,
  *   dP = do mem, D = rowsum(do*o), G = scale * P * (dP - D), dqf = G mem^T, dmem = do^T P + qf^T G     (P = exp(scale*qf mem - lse)),
  * replacing the batched-GEMM / softmax chains autograd derived (each of which streamed the [B,256,N] memory or [B,rows,N] scores).
- * ws: idiff_smm_xattn_ws_floats(B, rows, 1, 256, N) floats for either call; dmem [B,256,N] is overwritten. */
+ * ws: idiff_smm_xattn_ws_floats(B, rows, 1, 256, N) floats for either call; dmem [B,256,N] is overwritten, or added to when
+ * accumulate != 0 (the decoder layers of a ScoreMapModule attend to one memory: their gradients are summed in place, in call order). */
 int idiff_smm_xattn_lse_fwd(const float* qf, const float* mem, float* o, float* lse, float* ws, int B, int rows, int N, float scale,
                             idiff_stream_t stream);
 int idiff_smm_xattn_bwd(const float* qf, const float* mem, const float* o, const float* lse, const float* d_o, float* dqf, float* dmem,
-                        float* ws, int B, int rows, int N, float scale, idiff_stream_t stream);
+                        int accumulate, float* ws, int B, int rows, int N, float scale, idiff_stream_t stream);
 /* score map: out[b,k,p] = <feat[b,:,p]/max(|feat[b,:,p]|,eps), tv[b,k,:]/max(|tv[b,k,:]|,eps)>; K <= 8
  * sel (optional) [B, HW] = out[b, idx[b], :]  (idx int32 [B]) */
 int idiff_scoremap_fwd(const float* feat, int64_t feat_bstride, const float* tv, float* out, const int32_t* idx,

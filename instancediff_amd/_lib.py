@@ -79,7 +79,7 @@ SIGNATURES = {
     "idiff_smm_xattn_ws_floats": (I64, [I, I, I, I, I]),
     "idiff_smm_xattn_fwd": (I, [P, P, P, P, I, I, I, I, I, F, c_stream]),
     "idiff_smm_xattn_lse_fwd": (I, [P, P, P, P, P, I, I, I, F, c_stream]),
-    "idiff_smm_xattn_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, F, c_stream]),
+    "idiff_smm_xattn_bwd": (I, [P, P, P, P, P, P, P, I, P, I, I, I, F, c_stream]),
     "idiff_scoremap_fwd": (I, [P, I64, P, P, P, P, I, I, I, I, c_stream]),
     "idiff_gather_channel": (I, [P, P, P, I, I, I, c_stream]),
     "idiff_conv3x3_select_fwd": (I, [P, I64, P, P, P, P, I, I, I, I, I, c_stream]),

@@ -547,7 +547,8 @@ __global__ __launch_bounds__(256) void smm_xattn_combine_kernel(const float* __r
 //   LDS: mem tile 4 x [64][33]; qf and do as [32 rows][257]; exchange / transpose area 4 x 2304; row constants.
 __global__ __launch_bounds__(256) void smm_xattn_bwd_kernel(const float* __restrict__ qf, const float* __restrict__ mem, const float* __restrict__ o,
                                                             const float* __restrict__ lse, const float* __restrict__ d_o, float* __restrict__ ws,
-                                                            float* __restrict__ dmem, int rows, int N, int nsplit, int kps, float scale) {
+                                                            float* __restrict__ dmem, int rows, int N, int nsplit, int kps, float scale,
+                                                            int accumulate) {
     constexpr int XCW = 64, XCM = 256, XTILE = 64 * 33, XP = 257, XREG = 2304;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tile = smem + (threadIdx.x >> 6) * XTILE;  // private per wave: [64 c][33]
@@ -686,6 +687,12 @@ __global__ __launch_bounds__(256) void smm_xattn_bwd_kernel(const float* __restr
         }
         const int key = kbi * 32 + l31;
         if (key < N) {
+            if (accumulate) {  // uniform: dmem += (the gradients of the decoder layers that share this memory meet here, in a fixed order)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Dm[m][r] += dmemb[(long long)(m * 32 + KAPPA(r) + 4 * half) * N + key];
+            }
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -853,7 +860,7 @@ extern "C" int idiff_smm_xattn_lse_fwd(const float* qf, const float* mem, float*
 }
 
 extern "C" int idiff_smm_xattn_bwd(const float* qf, const float* mem, const float* o, const float* lse, const float* d_o, float* dqf, float* dmem,
-                                   float* ws, int B, int rows, int N, float scale, idiff_stream_t stream) {
+                                   int accumulate, float* ws, int B, int rows, int N, float scale, idiff_stream_t stream) {
     IDIFF_CHECK_ARG(qf && mem && o && lse && d_o && dqf && dmem && ws && B > 0 && N > 0, "smm_xattn_bwd: bad args");
     IDIFF_CHECK_ARG(rows >= 1 && rows <= 32, "smm_xattn_bwd: rows must be in 1..32 (got %d)", rows);
     IDIFF_CHECK_ARG(N % 4 == 0, "smm_xattn_bwd: N must be a multiple of 4");
@@ -867,7 +874,7 @@ extern "C" int idiff_smm_xattn_bwd(const float* qf, const float* mem, const floa
         if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "smm_xattn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr = true;
     }
-    hipLaunchKernelGGL(smm_xattn_bwd_kernel, dim3(ns, B), dim3(256), lds, st, qf, mem, o, lse, d_o, ws, dmem, rows, N, ns, kps, scale);
+    hipLaunchKernelGGL(smm_xattn_bwd_kernel, dim3(ns, B), dim3(256), lds, st, qf, mem, o, lse, d_o, ws, dmem, rows, N, ns, kps, scale, accumulate);
     IDIFF_CHECK_LAUNCH("smm_xattn_bwd");
     hipLaunchKernelGGL(smm_xattn_bwd_combine_kernel, dim3(32, B), dim3(256), 0, st, ws, dqf, rows, ns);
     IDIFF_CHECK_LAUNCH("smm_xattn_bwd_combine");

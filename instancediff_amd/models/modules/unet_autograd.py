@@ -24,16 +24,19 @@ def _resblock(rb, src0, src1, temb_act, vec=None):
 
 
 def _heads_attention(q3, k3, v3, heads, scale):
-    """token-major attention from batched GEMMs: q3 [B,Nq,C], k3/v3 [B,M,C] -> [B,Nq,C]"""
-    C = q3.shape[-1]
+    """token-major attention from batched GEMMs: q3 [B,Nq,C], k3/v3 [B,M,C] -> [B,Nq,C].  All heads in one batch ([B*heads, ., dh]
+    through two permutes) instead of a slice per head: autograd's backward of a slice is a zero-filled full-size tensor plus an add
+    per head -- hundreds of tiny ATen launches per step."""
+    B, Nq, C = q3.shape
+    M = k3.shape[1]
     dh = C // heads
-    outs = []
-    for h in range(heads):
-        sl = slice(h * dh, (h + 1) * dh)
-        s = BgemmFn.apply(q3[:, :, sl], k3[:, :, sl], False, True)  # [B,Nq,M]
-        p = SoftmaxRowsFn.apply(s, scale)
-        outs.append(BgemmFn.apply(p, v3[:, :, sl], False, False))   # [B,Nq,dh]
-    return torch.cat(outs, dim=-1)
+
+    def split(x, n):
+        return x.reshape(B, n, heads, dh).permute(0, 2, 1, 3).reshape(B * heads, n, dh)
+    s = BgemmFn.apply(split(q3, Nq), split(k3, M), False, True)     # [B*heads, Nq, M]
+    p = SoftmaxRowsFn.apply(s, scale)
+    o = BgemmFn.apply(p, split(v3, M), False, False)                  # [B*heads, Nq, dh]
+    return o.reshape(B, heads, Nq, dh).permute(0, 2, 1, 3).reshape(B, Nq, C)
 
 
 def _ca_vec(ca, ctx):
@@ -99,6 +102,7 @@ def _smm(smm, feat, text_encoder, idx):
     # training-mode dropout of the decoder blocks (TransformerDecoderLayer(dropout=0.1): Attention.proj_drop on both attentions, the
     # MLP's inner Dropout and the block's output Dropout, models/_modified_BiomedCLIP.py:448-478,520-549); identity in eval()
     pd, tr = dec.dropout, smm.training
+    mem_grad = {}  # the layers' gradients w.r.t. the shared memory are summed inside the fused backward kernel (SmmXattnFn)
     for layer in dec.decoder:
         sa, ca = layer.self_attn, layer.cross_attn
         n1 = LayerNormRowsFn.apply(x, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
@@ -111,20 +115,19 @@ def _smm(smm, feat, text_encoder, idx):
         qc = LinearFn.apply(n2, ca.q_proj.weight, None)  # [R, Wd]
         # k/v projections folded onto the queries: qf_h = q_h Wk_h ; S = qf mem ; o = P mem^T ; av_h = o_h Wv_h^T.
         # All heads' query rows are stacked ([B, heads*K, Wd]) so `mem` is read once per product, not once per head.
-        qfs = [BgemmFn.apply(qc[:, h * dh:(h + 1) * dh].unsqueeze(0), ca.k_proj.weight[h * dh:(h + 1) * dh].unsqueeze(0), False, False)
-               .reshape(B, K, Wd) for h in range(heads)]
-        qf = torch.cat(qfs, dim=1)                                   # [B, heads*K, Wd], row = h*K + k
+        # (every head in one batched GEMM: batch = heads, through permutes -- no per-head slices, see _heads_attention)
+        qh = qc.reshape(R, heads, dh).permute(1, 0, 2)                                   # [heads, R, dh]
+        qf = BgemmFn.apply(qh, ca.k_proj.weight.reshape(heads, dh, Wd), False, False)    # [heads, R, Wd]
+        qf = qf.reshape(heads, B, K, Wd).permute(1, 0, 2, 3).reshape(B, heads * K, Wd)   # row = h*K + k
         if FUSED_XATTN and heads * K <= 32 and Wd == 256 and N % 4 == 0:
-            o = SmmXattnFn.apply(qf, mem, ca.scale)                  # one fused forward, one fused backward pass over the keys
+            o = SmmXattnFn.apply(qf, mem, ca.scale, mem_grad)        # one fused forward, one fused backward pass over the keys
         else:
             s = BgemmFn.apply(qf, mem, False, False)                 # [B, heads*K, N]
             p = SoftmaxRowsFn.apply(s, ca.scale)
             o = BgemmFn.apply(p, mem, False, True)                   # [B, heads*K, Wd]
-        avs = []
-        for h in range(heads):
-            oh = o[:, h * K:(h + 1) * K].reshape(1, R, Wd)
-            avs.append(BgemmFn.apply(oh, ca.v_proj.weight[h * dh:(h + 1) * dh].unsqueeze(0), False, True).reshape(R, dh))
-        av = torch.cat(avs, dim=-1)
+        oh = o.reshape(B, heads, K, Wd).permute(1, 0, 2, 3).reshape(heads, R, Wd)        # [heads, R, Wd]
+        av = BgemmFn.apply(oh, ca.v_proj.weight.reshape(heads, dh, Wd), False, True)     # [heads, R, dh]
+        av = av.permute(1, 0, 2).reshape(R, Wd)
         x = AddFn.apply(x, dropout(LinearFn.apply(av, ca.proj.weight, ca.proj.bias), pd, tr), 1.0)
         n3 = LayerNormRowsFn.apply(x, layer.norm3.weight, layer.norm3.bias, layer.norm3.eps)
         hm = dropout(ActFn.apply(LinearFn.apply(n3, layer.mlp[0].weight, layer.mlp[0].bias), ops.ACT_GELU), pd, tr)

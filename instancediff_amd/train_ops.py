@@ -4,6 +4,8 @@ include/idiff.h, the fused Adam optimizer and the `optimize_parameters_inputRes`
 gradient arithmetic runs in ATen except autograd's own accumulation of fan-in gradients."""
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib, ops
@@ -239,10 +241,16 @@ class SmmXattnFn(torch.autograd.Function):
     (idiff_smm_xattn_bwd) instead of the seven batched-GEMM / softmax launches autograd derived per decoder layer."""
 
     @staticmethod
-    def forward(ctx, qf, mem, scale):
+    def forward(ctx, qf, mem, scale, shared=None):
+        """shared: a dict common to the calls that attend to the SAME `mem` (the decoder layers of one ScoreMapModule), with
+        shared["uses"] = their number.  Their memory gradients are then summed inside the backward kernel, in backward order, into
+        one buffer that the last of them to run hands to autograd (the others return None): no [B,256,N] adds between them."""
         lib = _lib.load()
         qf, mem = qf.contiguous(), mem.contiguous()
         _c(qf), _c(mem)
+        ctx.shared = shared
+        if shared is not None:
+            shared["pending"] = shared.get("pending", 0) + 1
         B, R, Cm = qf.shape
         N = mem.shape[2]
         assert Cm == 256 and tuple(mem.shape[:2]) == (B, 256) and R <= 32
@@ -262,11 +270,23 @@ class SmmXattnFn(torch.autograd.Function):
         B, R, _ = qf.shape
         N = mem.shape[2]
         dqf = torch.empty_like(qf)
-        dmem = torch.empty_like(mem)
+        sh = ctx.shared
+        acc = 0
+        if sh is None:
+            dmem = torch.empty_like(mem)
+        else:
+            acc = 1 if sh.get("buf") is not None else 0
+            dmem = sh["buf"] if acc else torch.empty_like(mem)
+            sh["buf"] = dmem
+            sh["pending"] -= 1
         ws = torch.empty((lib.idiff_smm_xattn_ws_floats(B, R, 1, 256, N),), device=qf.device, dtype=torch.float32)
-        check(lib.idiff_smm_xattn_bwd(_p(qf), _p(mem), _p(o), _p(lse), _p(d_o), _p(dqf), _p(dmem), _p(ws), B, R, N, ctx.scale, _stream()),
+        check(lib.idiff_smm_xattn_bwd(_p(qf), _p(mem), _p(o), _p(lse), _p(d_o), _p(dqf), _p(dmem), acc, _p(ws), B, R, N, ctx.scale, _stream()),
               "smm_xattn_bwd")
-        return dqf, dmem, None
+        if sh is not None:
+            if sh["pending"] > 0:
+                return dqf, None, None, None   # the sum is still growing: the last call to run returns it
+            sh["buf"] = None
+        return dqf, dmem, None, None
 
 
 class SoftmaxRowsFn(torch.autograd.Function):
@@ -674,6 +694,9 @@ def score_map_losses(score_maps, label, loss_rec, slot0, mult=(1, 2, 4, 8), size
     return grads
 
 
+TRAIN_TWO_STREAMS = bool(int(os.environ.get("IDIFF_TRAIN_TWO_STREAMS", "1")))
+
+
 def forward_backward_inputRes(model):
     """Forward of both nets, the reference's active objective and its backward (drift_noise_model.py:242-294):
        pred_drift, dsm = drift_net(x_t - LQ, LQ, t, ...) ; pred_noise, nsm = noise_net(x_t - LQ, x_t, t, ...)
@@ -690,26 +713,55 @@ def forward_backward_inputRes(model):
     t = m.t.reshape(-1).to(torch.float32)
     use_dsm = m.dnet_settings.get("use_dsm", True) and m.dnet_settings["text_module"] == "scoremap"
     use_nsm = m.nnet_settings.get("use_nsm", True) and m.nnet_settings["text_module"] == "scoremap"
-    with torch.enable_grad():
-        outd = m.drift_net(xa, m.input, t, m.names, m.text_encoder, image_context=m.A_emb)
-        outn = m.noise_net(xa, m.drift_noised_x, t, m.names, m.text_encoder, image_context=m.A_emb)
-    pred_d, dsm = outd if isinstance(outd, tuple) else (outd, [])
-    pred_n, nsm = outn if isinstance(outn, tuple) else (outn, [])
-    iter_time = time.time() - st  # the reference times the forward only (:246,290)
     rec = torch.zeros(10, device=m.device, dtype=torch.float32)  # dl, nl, dsm x4, nsm x4
-    outs_d, grads_d = [pred_d], [mse_loss_and_grad(pred_d, tgt_d, rec[0:1])]
-    outs_n, grads_n = [pred_n], [mse_loss_and_grad(pred_n, m.std_noise, rec[1:2])]
-    if use_dsm:
-        outs_d += list(dsm)
-        grads_d += score_map_losses(dsm, tgt_d, rec, 2)
-    if use_nsm:
-        outs_n += list(nsm)
-        grads_n += score_map_losses(nsm, m.std_noise, rec, 6)
     m.noise_optimizer.zero_grad()
     m.drift_optimizer.zero_grad()
-    # The two nets share no parameters, so their backward passes are two independent graph walks: drift first, and its flat
-    # gradient buffer starts its all-reduce (RCCL's own stream) while the noise net's backward still computes.
     sync = m.grad_sync
+
+    def fwd(net, xb, target, slot_main, slot_sm, use_sm):
+        with torch.enable_grad():
+            out = net(xa, xb, t, m.names, m.text_encoder, image_context=m.A_emb)
+        pred, sm = out if isinstance(out, tuple) else (out, [])
+        outs, grads = [pred], [mse_loss_and_grad(pred, target, rec[slot_main:slot_main + 1])]
+        if use_sm:
+            outs += list(sm)
+            grads += score_map_losses(sm, target, rec, slot_sm)
+        return outs, grads
+
+    # The two nets share no parameters and no activations: forward, losses and backward of each run on a stream of their own
+    # (autograd replays a node's backward on the stream of its forward), so one net's latency-bound token-side launches and kernel
+    # tails overlap with the other's convolutions, as in the sampling loop.  IDIFF_TRAIN_TWO_STREAMS=0: one stream.
+    two = TRAIN_TWO_STREAMS and xa.is_cuda
+    if two:
+        main = torch.cuda.current_stream()
+        if getattr(m, "_train_streams", None) is None:
+            m._train_streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        s1, s2 = m._train_streams
+        s1.wait_stream(main)
+        s2.wait_stream(main)
+        with torch.cuda.stream(s1):
+            outs_d, grads_d = fwd(m.drift_net, m.input, tgt_d, 0, 2, use_dsm)
+        with torch.cuda.stream(s2):
+            outs_n, grads_n = fwd(m.noise_net, m.drift_noised_x, m.std_noise, 1, 6, use_nsm)
+        iter_time = time.time() - st  # the reference times the forward only (:246,290)
+        # drift first: its flat gradient buffer starts its all-reduce (RCCL's own stream) while the noise net's backward computes
+        with torch.cuda.stream(s1):
+            torch.autograd.backward(outs_d, grads_d)
+        if sync is not None:
+            main.wait_stream(s1)
+            sync.start(m.drift_optimizer.flat_grads())
+        with torch.cuda.stream(s2):
+            torch.autograd.backward(outs_n, grads_n)
+        main.wait_stream(s1)
+        main.wait_stream(s2)
+        if sync is not None:
+            sync.start(m.noise_optimizer.flat_grads())
+        return rec, iter_time, use_dsm, use_nsm
+    outs_d, grads_d = fwd(m.drift_net, m.input, tgt_d, 0, 2, use_dsm)
+    outs_n, grads_n = fwd(m.noise_net, m.drift_noised_x, m.std_noise, 1, 6, use_nsm)
+    iter_time = time.time() - st
+    # Two independent graph walks: drift first, and its flat gradient buffer starts its all-reduce while the noise net's backward
+    # still computes.
     torch.autograd.backward(outs_d, grads_d)
     if sync is not None:
         sync.start(m.drift_optimizer.flat_grads())
