@@ -13,6 +13,7 @@
 //                  channel (M) dimension of P.V, partial S tiles are exchanged through LDS; flash-decoding
 //                  style split over keys + combine kernel.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -506,6 +507,147 @@ __global__ __launch_bounds__(256) void smm_xattn_kernel(const float* __restrict_
     }
 }
 
+// Wave-per-key-block form for the narrow (compact) memories, CM = 72 / 136: every wave owns whole 32-key blocks (wave w of a workgroup takes
+// blocks w, w + 4, ...) with ALL CM channels, so S is complete inside the wave -- no partial tiles through LDS, no barrier per block --
+// and P.V runs on ceil(CM / 32) channel blocks instead of 4 x 32 (84 instead of 100 MFMAs per 32 keys at CM = 72).  The four waves keep
+// a running max / sum / partial output each and merge them in LDS at the end (wave order): one partial per workgroup, as before.  profiles/r03: the channel-split
+// form streamed the 72-row memory at 1.85 TB/s (12 launches, 1.3 ms per step).
+template <int CM>
+__global__ __launch_bounds__(256) void smm_xattn_w_kernel(const float* __restrict__ qf, const float* __restrict__ mem, float* __restrict__ ws, int rows,
+                                                          int N, int nsplit, int kps, float scale) {
+    constexpr int CB = (CM + 31) / 32;           // 32-channel blocks of the P.V product
+    constexpr int TILE = CB * 32 * 33;           // per-wave mem slice [CB*32 c][33]; rows >= CM stay zero
+    constexpr int NF4 = (CM * 8 + 63) / 64;      // float4 loads per lane per 32-key block
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    float* tile = smem + wave * TILE;
+    const int b = blockIdx.y, sp = blockIdx.x;
+    const float* memb = mem + (long long)b * CM * N;
+    for (int i = lane; i < TILE; i += 64) tile[i] = 0.f;  // (wave-private; LDS is in order within a wave)
+
+    float qreg[CM / 2];
+#pragma unroll
+    for (int t = 0; t < CM / 2; ++t) qreg[t] = l31 < rows ? qf[((long long)b * rows + l31) * CM + 2 * t + half] : 0.f;
+    floatx16 O[CB];
+#pragma unroll
+    for (int m = 0; m < CB; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[m][r] = 0.f;
+    float mrun = -INFINITY, lrun = 0.f;
+
+    const int nkb = (N + 31) / 32;
+    const int kb_begin = sp * kps + wave;
+    const int kb_end = min(nkb, sp * kps + kps);
+    floatx4 rt[NF4];
+    auto load_tile = [&](int kbi) {
+        const int key0 = kbi * 32;
+#pragma unroll
+        for (int i = 0; i < NF4; ++i) {
+            const int f = lane + i * 64;  // float4 index in [CM][8]
+            const int c = f >> 3, j4 = (f & 7) * 4;
+            floatx4 z = {0.f, 0.f, 0.f, 0.f};
+            if ((CM * 8) % 64 != 0 && f >= CM * 8) {
+            } else if (key0 + j4 + 3 < N)
+                z = *reinterpret_cast<const floatx4*>(memb + (long long)c * N + key0 + j4);
+            else
+                for (int e = 0; e < 4; ++e)
+                    if (key0 + j4 + e < N) z[e] = memb[(long long)c * N + key0 + j4 + e];
+            rt[i] = z;
+        }
+    };
+    auto write_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < NF4; ++i) {
+            const int f = lane + i * 64;
+            const int c = f >> 3, j4 = (f & 7) * 4;
+            if ((CM * 8) % 64 != 0 && f >= CM * 8) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[c * 33 + j4 + e] = rt[i][e];
+        }
+    };
+    if (kb_begin < kb_end) load_tile(kb_begin);
+    for (int kbi = kb_begin; kbi < kb_end; kbi += 4) {
+        write_tile();
+        if (kbi + 4 < kb_end) load_tile(kbi + 4);
+        floatx16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < CM / 2; ++t) S = __builtin_amdgcn_mfma_f32_32x32x2f32(tile[(2 * t + half) * 33 + l31], qreg[t], S, 0, 0, 0);
+        const int key0 = kbi * 32 + 4 * half;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float sv = (key0 + KAPPA(r) < N) ? S[r] * scale : -INFINITY;
+            S[r] = sv;
+            mx = fmaxf(mx, sv);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrun, mx);
+        const float alpha = __expf(mrun - mnew);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __expf(S[r] - mnew);
+            S[r] = p;
+            ps += p;
+        }
+        lrun = lrun * alpha + ps;
+        mrun = mnew;
+#pragma unroll
+        for (int m = 0; m < CB; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[m][r] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int m = 0; m < CB; ++m)
+                O[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(tile[(m * 32 + l31) * 33 + KAPPA(r) + 4 * half], S[r], O[m], 0, 0, 0);
+    }
+    // the four waves' partials meet in LDS (each in its own, now idle, tile area: [c][32 rows], then the m and l rows) and leave as
+    // ONE partial per workgroup, combined in wave order
+    static_assert((CM + 2) * 32 <= TILE, "partial does not fit the tile area");
+    const float l = lrun + __shfl_xor(lrun, 32, 64);
+#pragma unroll
+    for (int m = 0; m < CB; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cl = m * 32 + KAPPA(r) + 4 * half;
+            if (cl < CM) tile[cl * 32 + l31] = O[m][r];
+        }
+    if (half == 0) {
+        tile[CM * 32 + l31] = mrun;
+        tile[(CM + 1) * 32 + l31] = l;
+    }
+    __syncthreads();
+    float* wp = ws + ((long long)b * nsplit + sp) * (CM + 2) * 32;
+    for (int i = tid; i < CM * 32; i += 256) {
+        const int row = i & 31;
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) M = fmaxf(M, smem[w * TILE + CM * 32 + row]);
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float ms = smem[w * TILE + CM * 32 + row];
+            acc += smem[w * TILE + i] * (ms == -INFINITY ? 0.f : __expf(ms - M));
+        }
+        wp[i] = acc;
+    }
+    if (tid < 32) {
+        float M = -INFINITY, L = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) M = fmaxf(M, smem[w * TILE + CM * 32 + tid]);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float ms = smem[w * TILE + CM * 32 + tid];
+            L += smem[w * TILE + (CM + 1) * 32 + tid] * (ms == -INFINITY ? 0.f : __expf(ms - M));
+        }
+        wp[CM * 32 + tid] = M;
+        wp[(CM + 1) * 32 + tid] = L;
+    }
+}
+
 __global__ __launch_bounds__(256) void smm_xattn_combine_kernel(const float* __restrict__ ws, float* __restrict__ o, int rows, int nsplit, int XCM,
                                                                 float* __restrict__ lse) {
     // thread = (channel c, row): the partials are laid out [c][32 rows], so a wave reads two full 128-byte lines per split
@@ -836,14 +978,26 @@ static int smm_xattn_fwd_impl(const float* qf, const float* mem, float* o, float
     hipStream_t st = (hipStream_t)stream;
     const int xcb = (Cm / 4 + 31) / 32;
     const size_t lds = (size_t)(4 * xcb * 32 * 33 + 4 * 16 * 64) * sizeof(float);
+    int ns_eff = ns;  // partials the combine kernel walks
     if (Cm == 256)
         hipLaunchKernelGGL(smm_xattn_kernel<64>, dim3(ns, B), dim3(256), lds, st, qf, mem, ws, rows, N, ns, kps, scale);
     else if (Cm == 136)
         hipLaunchKernelGGL(smm_xattn_kernel<34>, dim3(ns, B), dim3(256), lds, st, qf, mem, ws, rows, N, ns, kps, scale);
-    else
+    else if (kps >= 4) {  // compact 72-row memory: wave-per-key-block form (every wave has at least one block)
+        static const bool wform_off = [] {
+            const char* e = getenv("IDIFF_XATTN_WFORM");
+            return e && e[0] == '0';
+        }();
+        if (!wform_off) {
+            const size_t ldsw = (size_t)4 * 3 * 32 * 33 * sizeof(float);
+            hipLaunchKernelGGL(smm_xattn_w_kernel<72>, dim3(ns, B), dim3(256), ldsw, st, qf, mem, ws, rows, N, ns, kps, scale);
+        } else {
+            hipLaunchKernelGGL(smm_xattn_kernel<18>, dim3(ns, B), dim3(256), lds, st, qf, mem, ws, rows, N, ns, kps, scale);
+        }
+    } else
         hipLaunchKernelGGL(smm_xattn_kernel<18>, dim3(ns, B), dim3(256), lds, st, qf, mem, ws, rows, N, ns, kps, scale);
     IDIFF_CHECK_LAUNCH("smm_xattn_fwd");
-    hipLaunchKernelGGL(smm_xattn_combine_kernel, dim3((32 * Cm + 255) / 256, B), dim3(256), 0, st, ws, o, rows, ns, Cm, lse);
+    hipLaunchKernelGGL(smm_xattn_combine_kernel, dim3((32 * Cm + 255) / 256, B), dim3(256), 0, st, ws, o, rows, ns_eff, Cm, lse);
     IDIFF_CHECK_LAUNCH("smm_xattn_combine");
     return IDIFF_OK;
 }
