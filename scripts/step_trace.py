@@ -48,9 +48,9 @@ def main():
         c[1] += t
     tot = sum(v[1] for v in by.values())
     foreign = {k: v for k, v in by.items() if k.startswith("at::") or k.startswith("__amd_rocclr") or k.startswith("Cijk_") or "rocclr" in k}
-    wino = sum(v[1] for k, v in by.items() if k.startswith("conv_wino_kernel") or k.startswith("conv_wino4_kernel"))
+    wino = sum(v[1] for k, v in by.items() if k.startswith("conv_wino"))
     print(f"steady-state step: {len(step)} launches, {tot / 1e6:.3f} ms of kernel time, {span_ns / 1e6:.3f} ms first-start to last-end")
-    print(f"  conv_wino4_kernel + conv_wino_kernel {wino / 1e6:.3f} ms ({100.0 * wino / tot:.1f} %), everything else {(tot - wino) / 1e6:.3f} ms")
+    print(f"  3x3 Winograd convs (conv_wino4_kernel + conv_wino4h_kernel + conv_wino_kernel) {wino / 1e6:.3f} ms ({100.0 * wino / tot:.1f} %), everything else {(tot - wino) / 1e6:.3f} ms")
     print(f"  launches that are not this library's kernels: {sum(v[0] for v in foreign.values())} {dict((k, v[0]) for k, v in foreign.items())}")
     lines = [("kernel", "launches_per_step", "total_us", "avg_us", "share_pct")]
     for k, (n, t) in sorted(by.items(), key=lambda kv: -kv[1][1]):
