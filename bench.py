@@ -57,8 +57,9 @@ def parse():
                     "is estimated to fit --cpu-budget-s, else 4)")
     ap.add_argument("--cpu-budget-s", type=float, default=140.0, help="time budget of the CPU-baseline leg (warm + timed steps)")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--attn", choices=["f32", "bf16"], default="f32", help="bf16 = REDUCED-PRECISION VARIANT line (self-attention "
-                    "contractions on the bf16 matrix cores; BASELINE config c5): own metric label, PSNR delta vs the fp32 path stated")
+    ap.add_argument("--attn", choices=["f32", "bf16", "f16"], default="f32", help="bf16 / f16 = REDUCED-PRECISION VARIANT line (self-attention "
+                    "contractions on the bf16 / fp16 matrix cores; f16 with operands clamped to +-255 is the reference's own form, BASELINE "
+                    "config c5): own metric label, PSNR delta vs the fp32 path stated")
     ap.add_argument("--grad-wire", choices=["fp32", "bf16"], default="fp32", help="--mode train: wire format of the gradient all-reduce")
     ap.add_argument("--mode", choices=["sample", "train", "irsde"], default="sample",
                     help="sample = headline denoising-steps/s metric (driftSDE: 2 UNet forwards + update per step); train = secondary "
@@ -282,7 +283,7 @@ def attention_variant_delta(args, dev, steps=8):
     from oracle import sde_ref  # PSNR helper only (the checker's formula, trainUM.py:319-323 semantics)
     outs = []
     batch = make_batch(2, args.size, seed=99, mixed=True)
-    for dt in ("f32", "bf16"):
+    for dt in ("f32", args.attn):
         ops.ATTN_DTYPE = dt
         model, sde = pipeline.build(phase="test", device=dev, T=steps, seed=0)
         model.set_eval()
@@ -293,7 +294,7 @@ def attention_variant_delta(args, dev, steps=8):
         outs.append(torch.from_numpy(model.get_visuals()).clone())
     ops.ATTN_DTYPE = "f32"
     d = abs(sde_ref.psnr(outs[0], batch['target']) - sde_ref.psnr(outs[1], batch['target']))
-    return {"variant": "self-attention contractions on bf16 MFMA (fp32 softmax and accumulation); everything else fp32",
+    return {"variant": "self-attention contractions on %s MFMA (fp32 softmax and accumulation); everything else fp32" % args.attn,
             "psnr_delta_db_vs_fp32_path": float("%.3g" % d), "max_abs_diff_vs_fp32_path": float("%.3g" % float((outs[0] - outs[1]).abs().max())),
             "measured_on": "%d-step chain, batch 2, %dx%d, same weights / inputs / noise" % (steps, args.size, args.size)}
 
@@ -450,9 +451,9 @@ def main():
     from instancediff_amd.utils.synthetic import make_batch
 
     variant = None
-    if args.attn == "bf16" and args.mode == "sample":
+    if args.attn != "f32" and args.mode == "sample":
         variant = attention_variant_delta(args, dev)  # measured first, on the fp32 path's own inputs
-        ops.ATTN_DTYPE = "bf16"
+        ops.ATTN_DTYPE = args.attn
     os.environ["IDIFF_GRAD_WIRE"] = args.grad_wire
 
     if args.mode == "train":
@@ -564,11 +565,11 @@ def main():
         value = world * args.steps / el
         label = "denoising steps/sec (%dx%d bs%d)" % (args.size, args.size, args.batch)
         if variant is not None:
-            label += " -- REDUCED-PRECISION VARIANT: bf16 MFMA self-attention"
+            label += " -- REDUCED-PRECISION VARIANT: %s MFMA self-attention" % args.attn
         line = {"metric": label, "value": round(value, 4),
                 "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32" if variant is None else "f32 + bf16 attention", "data": "synthetic", "graph": run.stepper.mode == "graph",
+                "dtype": "f32" if variant is None else "f32 + %s attention" % args.attn, "data": "synthetic", "graph": run.stepper.mode == "graph",
                 "two_streams": bool(sde.two_streams), "variant": variant,
                 "launches_per_step": launches_per_step,
                 "config": {"workload": "%dx%d 1-ch synthetic, %d-step reverse chain, batch %d per GPU, 2 UNet fwd + reverse update per step"

@@ -244,6 +244,9 @@ int idiff_attn_self_fwd(const float* qkv, float* out, float* lse, int B, int C, 
 /* REDUCED-PRECISION VARIANT of idiff_attn_self_fwd (off by default; BASELINE config c5 "fp16 MFMA attention"): Q K^T and P V on
  * the bf16 matrix cores, fp32 softmax and accumulation; head dim 64.  Reported by bench.py as a separate, labelled line. */
 int idiff_attn_self_bf16_fwd(const float* qkv, float* out, int B, int C, int N, int heads, float scale, idiff_stream_t stream);
+/* the same with fp16 operands clamped to +-255 before the cast -- the reference's own half-precision form (flash-attn branch,
+ * models/_modified_BiomedCLIP.py:509-513; BASELINE config c5 "fp16 MFMA attention"); labelled variant, off by default */
+int idiff_attn_self_f16_fwd(const float* qkv, float* out, int B, int C, int N, int heads, float scale, idiff_stream_t stream);
 /* pixels attend to M context tokens: q [B,C,N] channel-major, k,v [B,M,C] token-major, out [B,C,N]; M <= 32 */
 int idiff_attn_ctx_fwd(const float* q, const float* k, const float* v, float* out, int B, int C, int N, int M,
                        int heads, float scale, idiff_stream_t stream);

@@ -74,6 +74,7 @@ SIGNATURES = {
     "idiff_chan_layernorm_fwd": (I, [P, I64, P, P, P, I64, I, I, I, F, P, c_stream]),
     "idiff_attn_self_fwd": (I, [P, P, P, I, I, I, I, F, c_stream]),
     "idiff_attn_self_bf16_fwd": (I, [P, P, I, I, I, I, F, c_stream]),
+    "idiff_attn_self_f16_fwd": (I, [P, P, I, I, I, I, F, c_stream]),
     "idiff_attn_ctx_fwd": (I, [P, P, P, P, I, I, I, I, I, F, c_stream]),
     "idiff_attn_tokens_fwd": (I, [P, P, P, P, I, I, I, I, I, F, I64, I64, c_stream]),
     "idiff_smm_xattn_ws_floats": (I64, [I, I, I, I, I]),

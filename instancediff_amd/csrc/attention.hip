@@ -13,6 +13,7 @@
 //                  channel (M) dimension of P.V, partial S tiles are exchanged through LDS; flash-decoding
 //                  style split over keys + combine kernel.
 #include <math.h>
+#include <type_traits>
 #include <stdlib.h>
 
 #include "common.h"
@@ -157,16 +158,35 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
 // P is taken from the S accumulator (register r of half-wave g holds key KAPPA(r) + 4g), so the k slots of the second product
 // are enumerated in that key order on the V side as well.
 // ---------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// HT = __bf16: the variant above.  HT = _Float16: the reference's own half-precision form (v_mfma_f32_32x32x16_f16, q / k / v clamped to
+// +-255 before the cast, as models/_modified_BiomedCLIP.py:509-513 does for flash-attn) -- BASELINE config c5's "fp16 MFMA attention".
+template <typename HT>
+struct HalfVec {
+    typedef HT x8 __attribute__((ext_vector_type(8)));
+    typedef HT x4 __attribute__((ext_vector_type(4)));
+};
+template <typename HT>
+__device__ __forceinline__ HT to_half(float v) {
+    if constexpr (std::is_same<HT, _Float16>::value) v = fminf(fmaxf(v, -255.f), 255.f);
+    return (HT)v;
+}
+template <typename HT>
+__device__ __forceinline__ floatx16 mfma_half(typename HalfVec<HT>::x8 a, typename HalfVec<HT>::x8 b, floatx16 c) {
+    if constexpr (std::is_same<HT, _Float16>::value) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 
-__global__ __launch_bounds__(256) void attn_self_bf16_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int N, int heads,
+template <typename HT>
+__global__ __launch_bounds__(256) void attn_self_half_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int N, int heads,
                                                              float scale) {
     constexpr int DH = 64, MB = 2;
     constexpr int KROW = DH + 8;   // bf16 per K row (key-major), padded: rows land 4 banks apart
     constexpr int VROW = 32 + 4;   // bf16 per V row (channel-major), padded
     constexpr int KT = 32 * KROW, VT = DH * VROW, BUF = KT + VT;  // bf16 elements per buffer
-    extern __shared__ __attribute__((aligned(16))) __bf16 bsm[];
+    typedef typename HalfVec<HT>::x8 bf16x8;
+    typedef typename HalfVec<HT>::x4 bf16x4;
+    extern __shared__ __attribute__((aligned(16))) unsigned short bsm_raw[];
+    HT* const bsm = reinterpret_cast<HT*>(bsm_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.y / heads, h = blockIdx.y % heads;
     const int q0 = (blockIdx.x * 4 + wave) * 32;
@@ -178,7 +198,7 @@ __global__ __launch_bounds__(256) void attn_self_bf16_kernel(const float* __rest
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) qreg[s][e] = (__bf16)(qi < N ? qb[(long long)(16 * s + 8 * half + e) * N + qi] : 0.f);
+        for (int e = 0; e < 8; ++e) qreg[s][e] = to_half<HT>(qi < N ? qb[(long long)(16 * s + 8 * half + e) * N + qi] : 0.f);
     floatx16 O[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m)
@@ -205,15 +225,15 @@ __global__ __launch_bounds__(256) void attn_self_bf16_kernel(const float* __rest
         }
     };
     auto write_tile = [&](int buf) {
-        __bf16* kt = bsm + buf * BUF;
-        __bf16* vt = kt + KT;
+        HT* kt = bsm + buf * BUF;
+        HT* vt = kt + KT;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int f = tid + i * 256;
             const int d = f >> 3, j4 = (f & 7) * 4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) kt[(j4 + e) * KROW + d] = (__bf16)rk[i][e];  // transposed: key-major rows
-            *reinterpret_cast<bf16x4*>(vt + d * VROW + j4) = bf16x4{(__bf16)rv[i][0], (__bf16)rv[i][1], (__bf16)rv[i][2], (__bf16)rv[i][3]};
+            for (int e = 0; e < 4; ++e) kt[(j4 + e) * KROW + d] = to_half<HT>(rk[i][e]);  // transposed: key-major rows
+            *reinterpret_cast<bf16x4*>(vt + d * VROW + j4) = bf16x4{to_half<HT>(rv[i][0]), to_half<HT>(rv[i][1]), to_half<HT>(rv[i][2]), to_half<HT>(rv[i][3])};
         }
     };
     load_tile(0);
@@ -222,15 +242,15 @@ __global__ __launch_bounds__(256) void attn_self_bf16_kernel(const float* __rest
     for (int kbi = 0; kbi < nkb; ++kbi) {
         const int buf = kbi & 1;
         if (kbi + 1 < nkb) load_tile(kbi + 1);
-        const __bf16* kt = bsm + buf * BUF;
-        const __bf16* vt = kt + KT;
+        const HT* kt = bsm + buf * BUF;
+        const HT* vt = kt + KT;
         floatx16 S;
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {  // A: key l31, channels 16 s + 8 half + e
             const bf16x8 ka = *reinterpret_cast<const bf16x8*>(kt + l31 * KROW + 16 * s + 8 * half);
-            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qreg[s], S, 0, 0, 0);
+            S = mfma_half<HT>(ka, qreg[s], S);
         }
         const int key0 = kbi * 32 + 4 * half;
         float mx = -INFINITY;
@@ -249,7 +269,7 @@ __global__ __launch_bounds__(256) void attn_self_bf16_kernel(const float* __rest
         for (int r = 0; r < 16; ++r) {
             const float p = __expf(S[r] - mnew);
             ps += p;
-            pb[r >> 3][r & 7] = (__bf16)p;
+            pb[r >> 3][r & 7] = (HT)p;
         }
         lrun = lrun * alpha + ps;
         mrun = mnew;
@@ -261,10 +281,10 @@ __global__ __launch_bounds__(256) void attn_self_bf16_kernel(const float* __rest
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int m = 0; m < MB; ++m) {  // A: channel 32 m + l31, the same key order as pb
-                const __bf16* vr = vt + (m * 32 + l31) * VROW + 16 * t + 4 * half;
+                const HT* vr = vt + (m * 32 + l31) * VROW + 16 * t + 4 * half;
                 const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vr), hi = *reinterpret_cast<const bf16x4*>(vr + 8);
                 const bf16x8 va = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                O[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb[t], O[m], 0, 0, 0);
+                O[m] = mfma_half<HT>(va, pb[t], O[m]);
             }
         if (kbi + 1 < nkb) write_tile(buf ^ 1);
         __syncthreads();
@@ -904,8 +924,19 @@ extern "C" int idiff_attn_self_bf16_fwd(const float* qkv, float* out, int B, int
     IDIFF_CHECK_ARG(N % 4 == 0 && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0, "attn_self_bf16: N %% 4 and 16-byte alignment required");
     dim3 grid((N + 127) / 128, B * heads);
     const size_t lds = (size_t)2 * (32 * (64 + 8) + 64 * (32 + 4)) * sizeof(uint16_t);
-    hipLaunchKernelGGL(attn_self_bf16_kernel, grid, dim3(256), lds, (hipStream_t)stream, qkv, out, C, N, heads, scale);
+    hipLaunchKernelGGL(attn_self_half_kernel<__bf16>, grid, dim3(256), lds, (hipStream_t)stream, qkv, out, C, N, heads, scale);
     IDIFF_CHECK_LAUNCH("attn_self_bf16_fwd");
+    return IDIFF_OK;
+}
+
+extern "C" int idiff_attn_self_f16_fwd(const float* qkv, float* out, int B, int C, int N, int heads, float scale, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(qkv && out && B > 0 && C > 0 && N > 0 && heads > 0 && C % heads == 0, "attn_self_f16: bad args");
+    IDIFF_CHECK_ARG(C / heads == 64, "attn_self_f16: head dim must be 64 (got %d)", C / heads);
+    IDIFF_CHECK_ARG(N % 4 == 0 && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0, "attn_self_f16: N %% 4 and 16-byte alignment required");
+    dim3 grid((N + 127) / 128, B * heads);
+    const size_t lds = (size_t)2 * (32 * (64 + 8) + 64 * (32 + 4)) * sizeof(uint16_t);
+    hipLaunchKernelGGL(attn_self_half_kernel<_Float16>, grid, dim3(256), lds, (hipStream_t)stream, qkv, out, C, N, heads, scale);
+    IDIFF_CHECK_LAUNCH("attn_self_f16_fwd");
     return IDIFF_OK;
 }
 

@@ -408,8 +408,9 @@ def chan_layernorm(x, gamma, beta, eps=1e-5, want_mean_rstd=False):
     return (out, mr) if want_mean_rstd else out
 
 
-# IDIFF_ATTN_DTYPE=bf16: the self-attention contractions on the bf16 matrix cores (reduced-precision VARIANT, never the default;
-# bench.py --attn bf16 reports it as its own line with its PSNR delta against the fp32 path)
+# IDIFF_ATTN_DTYPE=bf16 | f16: the self-attention contractions on the bf16 / fp16 matrix cores (reduced-precision VARIANTS, never the
+# default; f16 = the reference's own form, operands clamped to +-255; bench.py --attn bf16|f16 reports them as their own lines with
+# the PSNR delta against the fp32 path)
 ATTN_DTYPE = os.environ.get("IDIFF_ATTN_DTYPE", "f32").lower()
 
 
@@ -420,8 +421,9 @@ def attn_self(qkv, heads, scale, want_lse=False):
     B, C3, H, W = qkv.shape
     Cc, N = C3 // 3, H * W
     out = torch.empty((B, Cc, H, W), device=qkv.device, dtype=torch.float32)
-    if ATTN_DTYPE == "bf16" and not want_lse and Cc // heads == 64 and N % 4 == 0:
-        check(lib.idiff_attn_self_bf16_fwd(_p(qkv), _p(out), B, Cc, N, heads, scale, _stream()), "attn_self_bf16_fwd")
+    if ATTN_DTYPE in ("bf16", "f16") and not want_lse and Cc // heads == 64 and N % 4 == 0:
+        fn = lib.idiff_attn_self_bf16_fwd if ATTN_DTYPE == "bf16" else lib.idiff_attn_self_f16_fwd
+        check(fn(_p(qkv), _p(out), B, Cc, N, heads, scale, _stream()), "attn_self_%s_fwd" % ATTN_DTYPE)
         return out
     lse = torch.empty((B, heads, N), device=qkv.device, dtype=torch.float32) if want_lse else None
     check(lib.idiff_attn_self_fwd(_p(qkv), _p(out), _p(lse), B, Cc, N, heads, scale, _stream()), "attn_self_fwd")

@@ -212,8 +212,18 @@ def test_attn_self_bf16_variant_close_to_fp32_kernel():
         ops.check(lib.idiff_attn_self_bf16_fwd(ops._p(qkv.to(DEV)), ops._p(out), B, C, H * W, heads, scale, ops._stream()), "attn_self_bf16")
         e32 = float((f32.cpu().double() - ref).abs().max() / ref.abs().max())
         e16 = float((out.cpu().double() - ref).abs().max() / ref.abs().max())
-        print(f"attn_self N={H * W}: fp32 kernel {e32:.2e}, bf16 variant {e16:.2e}")
-        assert e32 < 1e-5 and e16 < 2e-2
+        # the fp16 form (the reference's flash-attn branch: operands clamped to +-255, then fp16): 2^-11 relative per operand
+        outh = torch.empty_like(f32)
+        ops.check(lib.idiff_attn_self_f16_fwd(ops._p(qkv.to(DEV)), ops._p(outh), B, C, H * W, heads, scale, ops._stream()), "attn_self_f16")
+        eh = float((outh.cpu().double() - ref).abs().max() / ref.abs().max())
+        print(f"attn_self N={H * W}: fp32 kernel {e32:.2e}, bf16 variant {e16:.2e}, fp16 variant {eh:.2e}")
+        assert e32 < 1e-5 and e16 < 2e-2 and eh < 4e-3
+    # the +-255 clamp of the fp16 form (models/_modified_BiomedCLIP.py:509-513): huge keys do not overflow to inf / NaN
+    big = torch.randn(1, 3 * 256, 8, 8, generator=g) * 0.6
+    big[:, 256:512] *= 1e5                       # keys far beyond the fp16 range
+    outb = torch.empty(1, 256, 8, 8, device=DEV)
+    ops.check(ops._lib.load().idiff_attn_self_f16_fwd(ops._p(big.to(DEV)), ops._p(outb), 1, 256, 64, 4, 0.125, ops._stream()), "attn_self_f16")
+    assert torch.isfinite(outb).all()
 
 
 def test_linear_t_grouped_equals_single_launches():
