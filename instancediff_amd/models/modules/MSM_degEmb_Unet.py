@@ -103,17 +103,40 @@ class TransformerDecoderLayer(nn.Module):  # :520-549
         self.mlp = nn.Sequential(nn.Linear(d_model, d_model * 4), nn.GELU(), nn.Identity(), nn.Linear(d_model * 4, d_model))
 
 
+class TransformerDecoderLayer_scaled(TransformerDecoderLayer):  # :552-590
+    """TransformerDecoderLayer with a learnable per-channel gain on each residual branch (x + gamma_sa * self_attn, x + gamma_ca *
+    cross_attn, x + gamma_mlp * mlp), initialised to 0.1; parameter names and shapes ([1,1,d]) as the reference's.  The gains ride in
+    the residual linears' epilogue (`gscale` of idiff_linear_t_*): no extra launch.  The reference's `if_flash=True` form swaps in
+    Attention_flash (:481-517: +-255 clamp, fp16 flash_attn) -- same parameters; here the attention arithmetic is chosen by
+    ops.ATTN_DTYPE, and fp32 is what `if_flash=False` computes."""
+
+    def __init__(self, d_model, nhead):
+        super().__init__(d_model, nhead)
+        self.gamma_sa = nn.Parameter(torch.ones((1, 1, d_model)) * 1e-1)
+        self.gamma_ca = nn.Parameter(torch.ones((1, 1, d_model)) * 1e-1)
+        self.gamma_mlp = nn.Parameter(torch.ones((1, 1, d_model)) * 1e-1)
+
+
+def branch_gains(layer):
+    """(gamma_sa, gamma_ca, gamma_mlp) as [d] views for a scaled layer, (None, None, None) for a plain one"""
+    if hasattr(layer, "gamma_sa"):
+        return layer.gamma_sa.reshape(-1), layer.gamma_ca.reshape(-1), layer.gamma_mlp.reshape(-1)
+    return None, None, None
+
+
 class ContextDecoder(nn.Module):  # :1194-1244
-    def __init__(self, transformer_width=256, transformer_heads=4, transformer_layers=3, visual_dim=512, text_dim=512, dropout=0.1):
+    layer_cls = TransformerDecoderLayer
+
+    def __init__(self, transformer_width=256, transformer_heads=4, transformer_layers=3, visual_dim=512, text_dim=512, dropout=0.1, outdim=None):
         super().__init__()
         self.width, self.heads = transformer_width, transformer_heads
         self.dropout = float(dropout)  # :1200 (training mode only: unet_autograd._smm; the sampling path never drops)
         self.memory_proj = nn.Sequential(nn.LayerNorm(visual_dim), nn.Linear(visual_dim, transformer_width),
                                          nn.LayerNorm(transformer_width))
         self.text_proj = nn.Sequential(nn.LayerNorm(text_dim), nn.Linear(text_dim, transformer_width))
-        self.decoder = nn.ModuleList([TransformerDecoderLayer(transformer_width, transformer_heads)
+        self.decoder = nn.ModuleList([self.layer_cls(transformer_width, transformer_heads)
                                       for _ in range(transformer_layers)])
-        self.out_proj = nn.Sequential(nn.LayerNorm(transformer_width), nn.Linear(transformer_width, visual_dim))
+        self.out_proj = nn.Sequential(nn.LayerNorm(transformer_width), nn.Linear(transformer_width, visual_dim if outdim is None else outdim))
         self.apply(self._init_weights)
 
     @staticmethod
@@ -125,6 +148,19 @@ class ContextDecoder(nn.Module):  # :1194-1244
         elif isinstance(m, nn.LayerNorm):
             nn.init.constant_(m.bias, 0)
             nn.init.constant_(m.weight, 1.0)
+
+
+class ContextDecoder_Hierachical(ContextDecoder):  # :1247-1308 (if_scale=True, the only form the reference's constructor accepts:
+    # its if_scale=False branch passes if_flash= to TransformerDecoderLayer, which has no such argument)
+    """ContextDecoder built from TransformerDecoderLayer_scaled, with a free output width `outdim` (reference default 512; a
+    ScoreMapModule needs outdim == visual_dim, which is what it passes).  State-dict keys equal the reference class's."""
+    layer_cls = TransformerDecoderLayer_scaled
+
+    def __init__(self, transformer_width=256, transformer_heads=4, transformer_layers=6, visual_dim=512, text_dim=512, dropout=0.1, outdim=512):
+        super().__init__(transformer_width, transformer_heads, transformer_layers, visual_dim, text_dim, dropout, outdim=outdim)
+
+
+DECODER_TYPES = {"ContextDecoder": ContextDecoder, "ContextDecoder_Hierachical": ContextDecoder_Hierachical}
 
 
 def _class_tokens(n_cls, prompt_len, names=ARTIFACT_TYPES):
@@ -149,7 +185,10 @@ class ScoreMapModule(nn.Module):
     feature (ContextDecoder) added back to the text emb; text (x) feature -> score map [B,K,h,w]."""
 
     def __init__(self, visual_dim=64, CLIP_Type="CLIP", token_embed_dim=512, text_dim=512, n_ctx=8, n_cls=5, prompt_len=10,
-                 decoder_layers=3, decoder_width=256, decoder_heads=4, tokenizer=None, class_names=ARTIFACT_TYPES, dropout=0.1):
+                 decoder_layers=3, decoder_width=256, decoder_heads=4, tokenizer=None, class_names=ARTIFACT_TYPES, dropout=0.1,
+                 decoder_type="ContextDecoder"):
+        """decoder_type: "ContextDecoder" (the frozen spec) or "ContextDecoder_Hierachical" (scaled layers,
+        _modified_BiomedCLIP.py:1247-1308) -- the candidate building blocks SURVEY.md section 8 a6 lists for the missing module."""
         super().__init__()
         self.visual_dim, self.n_cls, self.text_dim = visual_dim, n_cls, text_dim
         self.contexts = nn.Parameter(torch.zeros(1, n_ctx, token_embed_dim))
@@ -161,7 +200,10 @@ class ScoreMapModule(nn.Module):
         self.register_buffer("tokens", _class_tokens(n_cls, prompt_len) if tokenizer is None else
                              torch.as_tensor(tokenizer(list(class_names)[:n_cls])).long())
         self.text_to_visual = nn.Linear(text_dim, visual_dim)
-        self.context_decoder = ContextDecoder(decoder_width, decoder_heads, decoder_layers, visual_dim, text_dim, dropout=dropout)
+        if decoder_type not in DECODER_TYPES:
+            raise ValueError(f"decoder_type {decoder_type!r}: expected one of {sorted(DECODER_TYPES)}")
+        self.context_decoder = DECODER_TYPES[decoder_type](decoder_width, decoder_heads, decoder_layers, visual_dim, text_dim, dropout=dropout,
+                                                           **({} if decoder_type == "ContextDecoder" else {"outdim": visual_dim}))
         self.gamma = nn.Parameter(torch.ones(visual_dim) * 1e-4)
         self._text_cache = None
 
@@ -220,7 +262,7 @@ class ScoreMapModule(nn.Module):
         (no text_to_visual residual, no gamma); used to pin this path to outputs of the real reference class."""
         B, C = feat.shape[:2]
         out = self._decoder_tokens(feat, text.contiguous(), cache_prefix=False, plain_out=True)  # caller-owned text: not a stable cache key
-        return out.reshape(B, text.shape[1], C)
+        return out.reshape(B, text.shape[1], -1)  # outdim wide (== C for ContextDecoder)
 
     def _decoder_tokens(self, feat, text, cache_prefix=True, plain_out=False):
         """tv [B*K, C] = text_to_visual(text) + gamma * out_proj(LN(x_L)) with x_L the decoder state after the last
@@ -283,7 +325,8 @@ def decoder_tokens_grouped(smms, feats, texts, cache_prefix=True, plain_out=Fals
                                                              lambda sa=l.self_attn: torch.cat([sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight], 0).detach().t().contiguous()),
                                          ln=(l.norm1.weight, l.norm1.bias, l.norm1.eps)) for x, l in zip(xs, lay)])
         att = ops.attn_tokens_packed_grouped([q.reshape(B, K, 3 * Wd) for q in qkv], heads, lay[0].self_attn.scale)
-        xs = ops.linear_t_grouped([dict(x=a.reshape(R, Wd), wT=wT(l.self_attn.proj), bias=l.self_attn.proj.bias, res=x) for a, l, x in zip(att, lay, xs)])
+        xs = ops.linear_t_grouped([dict(x=a.reshape(R, Wd), wT=wT(l.self_attn.proj), bias=l.self_attn.proj.bias, res=x, gscale=branch_gains(l)[0])
+                                   for a, l, x in zip(att, lay, xs)])
         qc = ops.linear_t_grouped([dict(x=x, wT=wT(l.cross_attn.q_proj), ln=(l.norm2.weight, l.norm2.bias, l.norm2.eps)) for x, l in zip(xs, lay)])
         # cross attention, k/v projections folded onto the (few) queries, per head:
         #   qf[:, h-block] = qc[:, h-block] @ wkf[h row block]   (Wk's row block IS the transposed-weight form [K=dh][N=Cm])
@@ -313,7 +356,7 @@ def decoder_tokens_grouped(smms, feats, texts, cache_prefix=True, plain_out=Fals
         return [text, dec.text_proj[0].weight, dec.text_proj[0].bias, dec.text_proj[1].weight, dec.text_proj[1].bias, l0.norm1.weight, l0.norm1.bias,
                 l0.self_attn.q_proj.weight, l0.self_attn.k_proj.weight, l0.self_attn.v_proj.weight, l0.self_attn.proj.weight, l0.self_attn.proj.bias,
                 l0.norm2.weight, l0.norm2.bias, l0.cross_attn.q_proj.weight, l0.cross_attn.k_proj.weight, mp[1].weight, mp[1].bias, mp[2].weight,
-                m.text_to_visual.weight, m.text_to_visual.bias]
+                m.text_to_visual.weight, m.text_to_visual.bias] + ([l0.gamma_sa] if hasattr(l0, "gamma_sa") else [])
 
     if torch.is_grad_enabled() or not cache_prefix:
         pre = text_prefix(list(range(L)))
@@ -349,10 +392,11 @@ def decoder_tokens_grouped(smms, feats, texts, cache_prefix=True, plain_out=Fals
             groups += [dict(x=o[:, h * Cm:(h + 1) * Cm], wT=wvf[:, h * dh:(h + 1) * dh], bias=None if bvf is None else bvf[h * dh:(h + 1) * dh],
                             out=av[:, h * dh:(h + 1) * dh]) for h in range(heads)]
         _grouped_chunks(groups)
-        xs = ops.linear_t_grouped([dict(x=av, wT=wT(l.cross_attn.proj), bias=l.cross_attn.proj.bias, res=x) for av, l, x in zip(avs, lay, xs)])
+        xs = ops.linear_t_grouped([dict(x=av, wT=wT(l.cross_attn.proj), bias=l.cross_attn.proj.bias, res=x, gscale=branch_gains(l)[1])
+                                   for av, l, x in zip(avs, lay, xs)])
         hm = ops.linear_t_grouped([dict(x=x, wT=wT(l.mlp[0]), bias=l.mlp[0].bias, act_out=ops.ACT_GELU, ln=(l.norm3.weight, l.norm3.bias, l.norm3.eps))
                                    for x, l in zip(xs, lay)])
-        xs = ops.linear_t_grouped([dict(x=h_, wT=wT(l.mlp[3]), bias=l.mlp[3].bias, res=x) for h_, l, x in zip(hm, lay, xs)])
+        xs = ops.linear_t_grouped([dict(x=h_, wT=wT(l.mlp[3]), bias=l.mlp[3].bias, res=x, gscale=branch_gains(l)[2]) for h_, l, x in zip(hm, lay, xs)])
     if plain_out:
         return ops.linear_t_grouped([dict(x=x, wT=wT(s["dec"].out_proj[1]), bias=s["dec"].out_proj[1].bias,
                                           ln=(s["dec"].out_proj[0].weight, s["dec"].out_proj[0].bias, s["dec"].out_proj[0].eps)) for x, s in zip(xs, st)])

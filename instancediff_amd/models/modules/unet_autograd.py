@@ -5,6 +5,7 @@ batched-GEMM + softmax + LayerNorm Functions so that autograd derives their back
 import torch
 
 from ... import ops
+from .MSM_degEmb_Unet import branch_gains
 from ...train_ops import (ActFn, AddFn, AddVecFn, BgemmFn, ChanLayerNormFn, ChanNormalizeFn, ConvFn, GatherChannelFn, LayerNormRowsFn,
                           LinearFn, ResBlockFn, ScaleColsFn, SmmXattnFn, SoftmaxRowsFn, dropout)
 
@@ -103,14 +104,19 @@ def _smm(smm, feat, text_encoder, idx):
     # MLP's inner Dropout and the block's output Dropout, models/_modified_BiomedCLIP.py:448-478,520-549); identity in eval()
     pd, tr = dec.dropout, smm.training
     mem_grad = {}  # the layers' gradients w.r.t. the shared memory are summed inside the fused backward kernel (SmmXattnFn)
+
+    def branch(y, g):  # TransformerDecoderLayer_scaled's per-channel gain on a residual branch (:586-589); plain layers: none
+        return y if g is None else ScaleColsFn.apply(y, g)
+
     for layer in dec.decoder:
         sa, ca = layer.self_attn, layer.cross_attn
+        g_sa, g_ca, g_mlp = branch_gains(layer)
         n1 = LayerNormRowsFn.apply(x, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
         q = LinearFn.apply(n1, sa.q_proj.weight, None).reshape(B, K, Wd)
         k = LinearFn.apply(n1, sa.k_proj.weight, None).reshape(B, K, Wd)
         v = LinearFn.apply(n1, sa.v_proj.weight, None).reshape(B, K, Wd)
         a = _heads_attention(q, k, v, heads, sa.scale).reshape(R, Wd)
-        x = AddFn.apply(x, dropout(LinearFn.apply(a, sa.proj.weight, sa.proj.bias), pd, tr), 1.0)
+        x = AddFn.apply(x, branch(dropout(LinearFn.apply(a, sa.proj.weight, sa.proj.bias), pd, tr), g_sa), 1.0)
         n2 = LayerNormRowsFn.apply(x, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
         qc = LinearFn.apply(n2, ca.q_proj.weight, None)  # [R, Wd]
         # k/v projections folded onto the queries: qf_h = q_h Wk_h ; S = qf mem ; o = P mem^T ; av_h = o_h Wv_h^T.
@@ -128,10 +134,10 @@ def _smm(smm, feat, text_encoder, idx):
         oh = o.reshape(B, heads, K, Wd).permute(1, 0, 2, 3).reshape(heads, R, Wd)        # [heads, R, Wd]
         av = BgemmFn.apply(oh, ca.v_proj.weight.reshape(heads, dh, Wd), False, True)     # [heads, R, dh]
         av = av.permute(1, 0, 2).reshape(R, Wd)
-        x = AddFn.apply(x, dropout(LinearFn.apply(av, ca.proj.weight, ca.proj.bias), pd, tr), 1.0)
+        x = AddFn.apply(x, branch(dropout(LinearFn.apply(av, ca.proj.weight, ca.proj.bias), pd, tr), g_ca), 1.0)
         n3 = LayerNormRowsFn.apply(x, layer.norm3.weight, layer.norm3.bias, layer.norm3.eps)
         hm = dropout(ActFn.apply(LinearFn.apply(n3, layer.mlp[0].weight, layer.mlp[0].bias), ops.ACT_GELU), pd, tr)
-        x = AddFn.apply(x, dropout(LinearFn.apply(hm, layer.mlp[3].weight, layer.mlp[3].bias), pd, tr), 1.0)
+        x = AddFn.apply(x, branch(dropout(LinearFn.apply(hm, layer.mlp[3].weight, layer.mlp[3].bias), pd, tr), g_mlp), 1.0)
     op = dec.out_proj
     diff = LinearFn.apply(LayerNormRowsFn.apply(x, op[0].weight, op[0].bias, op[0].eps), op[1].weight, op[1].bias)  # [R, C]
     t2v = LinearFn.apply(t2d, smm.text_to_visual.weight, smm.text_to_visual.bias)

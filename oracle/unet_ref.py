@@ -95,15 +95,33 @@ class TransformerDecoderLayer(nn.Module):  # :520-549; dropout sites as the refe
         return x
 
 
+class TransformerDecoderLayer_scaled(TransformerDecoderLayer):  # :552-590 with if_flash=False (plain Attention)
+    def __init__(self, d_model, nhead, dropout=0.1):
+        super().__init__(d_model, nhead, dropout)
+        self.gamma_sa = nn.Parameter(torch.ones((1, 1, d_model)) * 1e-1)
+        self.gamma_ca = nn.Parameter(torch.ones((1, 1, d_model)) * 1e-1)
+        self.gamma_mlp = nn.Parameter(torch.ones((1, 1, d_model)) * 1e-1)
+
+    def forward(self, x, mem):  # :584-590
+        q = k = v = self.norm1(x)
+        x = x + self.gamma_sa * self.sa_drop(self.self_attn(q, k, v))
+        q = self.norm2(x)
+        x = x + self.gamma_ca * self.ca_drop(self.cross_attn(q, mem, mem))
+        x = x + self.gamma_mlp * self.dropout(self.mlp(self.norm3(x)))
+        return x
+
+
 class ContextDecoder(nn.Module):  # :1194-1244
-    def __init__(self, transformer_width=256, transformer_heads=4, transformer_layers=3, visual_dim=512, text_dim=512):
+    layer_cls = TransformerDecoderLayer
+
+    def __init__(self, transformer_width=256, transformer_heads=4, transformer_layers=3, visual_dim=512, text_dim=512, outdim=None):
         super().__init__()
         self.memory_proj = nn.Sequential(nn.LayerNorm(visual_dim), nn.Linear(visual_dim, transformer_width),
                                          nn.LayerNorm(transformer_width))
         self.text_proj = nn.Sequential(nn.LayerNorm(text_dim), nn.Linear(text_dim, transformer_width))
-        self.decoder = nn.ModuleList([TransformerDecoderLayer(transformer_width, transformer_heads)
+        self.decoder = nn.ModuleList([self.layer_cls(transformer_width, transformer_heads)
                                       for _ in range(transformer_layers)])
-        self.out_proj = nn.Sequential(nn.LayerNorm(transformer_width), nn.Linear(transformer_width, visual_dim))
+        self.out_proj = nn.Sequential(nn.LayerNorm(transformer_width), nn.Linear(transformer_width, visual_dim if outdim is None else outdim))
 
     def forward(self, text, visual):
         visual = self.memory_proj(visual)
@@ -113,18 +131,28 @@ class ContextDecoder(nn.Module):  # :1194-1244
         return self.out_proj(x)
 
 
+class ContextDecoder_Hierachical(ContextDecoder):  # :1247-1308, if_scale=True / if_flash=False: scaled layers, free output width
+    layer_cls = TransformerDecoderLayer_scaled
+
+    def __init__(self, transformer_width=256, transformer_heads=4, transformer_layers=6, visual_dim=512, text_dim=512, outdim=512):
+        super().__init__(transformer_width, transformer_heads, transformer_layers, visual_dim, text_dim, outdim=outdim)
+
+
 class ScoreMapModule(nn.Module):
     """text emb [B,K,512] (frozen encoder over class prompts + learnable context) -> MHCA stack over the
     conv feature -> text (+) -> text (x) feature -> score map [B,K,h,w]  (figure LDD_Overall2.png)."""
 
     def __init__(self, visual_dim=64, CLIP_Type="CLIP", token_embed_dim=512, text_dim=512, n_ctx=8, n_cls=5,
-                 prompt_len=10, decoder_layers=3, decoder_width=256, decoder_heads=4):
+                 prompt_len=10, decoder_layers=3, decoder_width=256, decoder_heads=4, decoder_type="ContextDecoder"):
         super().__init__()
         self.visual_dim = visual_dim
         self.contexts = nn.Parameter(torch.zeros(1, n_ctx, token_embed_dim))
         self.register_buffer("tokens", torch.zeros(n_cls, prompt_len, dtype=torch.long))
         self.text_to_visual = nn.Linear(text_dim, visual_dim)
-        self.context_decoder = ContextDecoder(decoder_width, decoder_heads, decoder_layers, visual_dim, text_dim)
+        if decoder_type == "ContextDecoder":
+            self.context_decoder = ContextDecoder(decoder_width, decoder_heads, decoder_layers, visual_dim, text_dim)
+        else:
+            self.context_decoder = ContextDecoder_Hierachical(decoder_width, decoder_heads, decoder_layers, visual_dim, text_dim, outdim=visual_dim)
         self.gamma = nn.Parameter(torch.ones(visual_dim) * 1e-4)
 
     def forward(self, feat, text_encoder):

@@ -10,6 +10,9 @@ ATTN_CASES = {"attn_self": (256, 4, 5, 5, 11), "attn_cross": (256, 4, 5, 300, 12
 LAYER_SEED = 77  # TransformerDecoderLayer(256, 4), :520-549
 # tag -> (decoder layers, visual_dim, visual tokens, weight seed)   ContextDecoder, :1194-1244 (reference default: 6 layers)
 DEC_CASES = {"dec_c64": (3, 64, 16 * 16, 167), "dec_c128": (3, 128, 8 * 8, 231), "dec_default6": (6, 256, 6 * 6, 362)}
+SCALED_LAYER_SEED = 78  # TransformerDecoderLayer_scaled(256, 4, if_flash=False), :552-590
+# tag -> (decoder layers, visual_dim, visual tokens, outdim, weight seed)   ContextDecoder_Hierachical(if_scale=True, if_flash=False), :1247-1308
+HIER_CASES = {"hier_c64": (3, 64, 16 * 16, 64, 468), "hier_default6_o512": (6, 128, 8 * 8, 512, 533)}
 
 
 def seeded_state(module, seed, scale=0.08):

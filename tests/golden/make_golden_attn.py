@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Golden vectors for the attention / decoder building blocks the ScoreMapModule is made of, produced by the REAL reference
-classes `Attention`, `TransformerDecoderLayer`, `ContextDecoder` of /root/reference/models/_modified_BiomedCLIP.py
-(:448-478, :520-549, :1194-1244).  Dev container only (needs /root/reference); writes data only: tests/golden/attn_golden.npz.
+classes `Attention`, `TransformerDecoderLayer(_scaled)`, `ContextDecoder(_Hierachical)` of /root/reference/models/_modified_BiomedCLIP.py
+(:448-478, :520-590, :1194-1308).  Dev container only (needs /root/reference); writes data only: tests/golden/attn_golden.npz.
 
 Import recipe.  The file cannot be imported plainly: `timm` is not installed and the module sits in the `models` package whose
 __init__ pulls in the whole (partly missing) model tree.  It is therefore executed by path under a private package name, with
@@ -30,7 +30,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from attn_fixture_util import ATTN_CASES, DEC_CASES, LAYER_SEED, seeded_state  # noqa: E402
+from attn_fixture_util import ATTN_CASES, DEC_CASES, HIER_CASES, LAYER_SEED, SCALED_LAYER_SEED, seeded_state  # noqa: E402
 
 REF = "/root/reference/models/_modified_BiomedCLIP.py"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "attn_golden.npz")
@@ -97,6 +97,22 @@ def main():
         for tag, (layers, vdim, hw, seed) in DEC_CASES.items():
             m = ref.ContextDecoder(transformer_width=256, transformer_heads=4, transformer_layers=layers, visual_dim=vdim, text_dim=512,
                                    dropout=0.0).eval()
+            m.load_state_dict(seeded_state(m, seed))
+            text = torch.randn(2, 5, 512, generator=g)
+            visual = torch.randn(2, hw, vdim, generator=g)
+            out[f"{tag}/text"], out[f"{tag}/visual"] = text.numpy(), visual.numpy()
+            out[f"{tag}/out"] = m(text, visual).numpy()
+        # ---- appended after the cases above (their draws from `g`, hence their arrays, are unchanged) ---------------------------------
+        # TransformerDecoderLayer_scaled (:552-590) and ContextDecoder_Hierachical (:1247-1308), if_flash=False (flash_attn is not
+        # installed; Attention_flash has the same parameters) and if_scale=True (the only form the constructor accepts)
+        m = ref.TransformerDecoderLayer_scaled(256, 4, dropout=0.0, if_flash=False).eval()
+        m.load_state_dict(seeded_state(m, SCALED_LAYER_SEED))
+        x = torch.randn(2, 5, 256, generator=g)
+        mem = torch.randn(2, 144, 256, generator=g)
+        out["slayer/x"], out["slayer/mem"], out["slayer/out"] = x.numpy(), mem.numpy(), m(x, mem).numpy()
+        for tag, (layers, vdim, hw, outdim, seed) in HIER_CASES.items():
+            m = ref.ContextDecoder_Hierachical(transformer_width=256, transformer_heads=4, transformer_layers=layers, visual_dim=vdim, text_dim=512,
+                                               dropout=0.0, outdim=outdim, if_scale=True, if_flash=False).eval()
             m.load_state_dict(seeded_state(m, seed))
             text = torch.randn(2, 5, 512, generator=g)
             visual = torch.randn(2, hw, vdim, generator=g)

@@ -12,7 +12,7 @@ import torch
 from oracle import unet_ref
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
-from attn_fixture_util import ATTN_CASES, DEC_CASES, LAYER_SEED, seeded_state  # noqa: E402
+from attn_fixture_util import ATTN_CASES, DEC_CASES, HIER_CASES, LAYER_SEED, SCALED_LAYER_SEED, seeded_state  # noqa: E402
 
 TOL = 2e-6  # relative to the output's max magnitude
 
@@ -55,4 +55,26 @@ def test_context_decoder_matches_reference(golden_attn, tag):
     with torch.no_grad():
         out = m(torch.from_numpy(golden_attn[f"{tag}/text"]), torch.from_numpy(golden_attn[f"{tag}/visual"]))
     assert out.shape == (2, 5, vdim)
+    assert rel_err(out, golden_attn[f"{tag}/out"]) < TOL
+
+
+def test_scaled_decoder_layer_matches_reference(golden_attn):
+    """TransformerDecoderLayer_scaled(if_flash=False), _modified_BiomedCLIP.py:552-590; gains seeded away from their 0.1 init"""
+    m = unet_ref.TransformerDecoderLayer_scaled(256, 4).eval()
+    m.load_state_dict(seeded_state(m, SCALED_LAYER_SEED))
+    assert tuple(m.gamma_sa.shape) == (1, 1, 256)
+    with torch.no_grad():
+        out = m(torch.from_numpy(golden_attn["slayer/x"]), torch.from_numpy(golden_attn["slayer/mem"]))
+    assert rel_err(out, golden_attn["slayer/out"]) < TOL
+
+
+@pytest.mark.parametrize("tag", list(HIER_CASES))
+def test_hierarchical_context_decoder_matches_reference(golden_attn, tag):
+    """ContextDecoder_Hierachical(if_scale=True, if_flash=False), :1247-1308"""
+    layers, vdim, hw, outdim, seed = HIER_CASES[tag]
+    m = unet_ref.ContextDecoder_Hierachical(256, 4, layers, vdim, 512, outdim=outdim).eval()
+    m.load_state_dict(seeded_state(m, seed))
+    with torch.no_grad():
+        out = m(torch.from_numpy(golden_attn[f"{tag}/text"]), torch.from_numpy(golden_attn[f"{tag}/visual"]))
+    assert out.shape == (2, 5, outdim)
     assert rel_err(out, golden_attn[f"{tag}/out"]) < TOL

@@ -17,13 +17,13 @@ from oracle import sde_ref, unet_ref  # noqa: E402
 DEV = "cuda"
 
 
-def oracle_nets(model):
+def oracle_nets(model, decoder_type="ContextDecoder"):
     opt = pipeline.load_options()
     mo = opt['models']['DriftNoise']
     refs = []
     for key, net in (('dnet_settings', model.drift_net), ('nnet_settings', model.noise_net)):
         s = {k: v for k, v in dict(mo[key]).items() if k not in ("module_name", "class_name")}
-        smm = nn.ModuleList([unet_ref.ScoreMapModule(visual_dim=mo['score_map_ngf'] * m) for m in mo['score_map_ch_mult']])
+        smm = nn.ModuleList([unet_ref.ScoreMapModule(visual_dim=mo['score_map_ngf'] * m, decoder_type=decoder_type) for m in mo['score_map_ch_mult']])
         r = unet_ref.LearnableForwardUNet_MultiScoreMap(CLIP_ScoreMapModule=smm, use_image_context=True, **s).eval()
         r.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()})
         refs.append(r)
@@ -290,3 +290,56 @@ def test_reverse_type_other_than_std_is_refused():
     b = make_batch(1, 32, seed=1)
     with pytest.raises(NotImplementedError):
         sde.reverse_ddpm(b['input'].to(DEV), b['names'], model.text_encoder, reverse_type="scaled", image_context=b['A_emb'].to(DEV))
+
+
+def test_chain_with_the_hierarchical_scaled_decoder_option():
+    """model option score_map_decoder: ContextDecoder_Hierachical (TransformerDecoderLayer_scaled blocks, reference
+    models/_modified_BiomedCLIP.py:552-590,1247-1308) -- a 10-step 64x64 chain against the oracle built with the same option; the
+    decoder made visible (gamma 0.3) and the branch gains moved off their 0.1 init."""
+    T, B, H = 10, 2, 64
+    model, sde = pipeline.build(phase="test", device=torch.device(DEV), T=T, seed=0, score_map_decoder="ContextDecoder_Hierachical")
+    model.set_eval()
+    g = torch.Generator().manual_seed(99)
+    with torch.no_grad():
+        for net in (model.drift_net, model.noise_net):
+            for m in net.CLIP_ScoreMapModule:
+                assert type(m.context_decoder).__name__ == "ContextDecoder_Hierachical"
+                for l in m.context_decoder.decoder:
+                    for name in ("gamma_sa", "gamma_ca", "gamma_mlp"):
+                        getattr(l, name).copy_((0.1 + 0.3 * torch.randn((1, 1, 256), generator=g)).to(DEV))
+    make_scoremap_branch_visible(model)
+    batch = make_batch(B, H, seed=5)
+    x_T = batch['input'] + 0.4 * torch.randn(batch['input'].shape, generator=g)
+    noises = torch.randn((T,) + tuple(batch['input'].shape), generator=g)
+    model.feed_data(batch)
+    model.test(x_T=x_T.to(DEV), noises=noises.to(DEV))
+    out = torch.from_numpy(model.get_visuals())
+    refs = oracle_nets(model, decoder_type="ContextDecoder_Hierachical")
+    assert any("gamma_ca" in k for k in refs[0].state_dict())
+    rsde = sde_ref.DriftSDERef(T, refs[0], refs[1], max_sigma=0.4)
+    with torch.no_grad():
+        ref = rsde.reverse_ddpm(batch['input'], batch['names'], unet_ref.StubTextEncoder(), x_T, noises, image_context=batch['A_emb'])
+        # the gains matter: the plain-decoder oracle with the shared weights gives a visibly different chain
+        plain = oracle_nets_drop_gains(model)
+        other = sde_ref.DriftSDERef(T, plain[0], plain[1], max_sigma=0.4).reverse_ddpm(
+            batch['input'], batch['names'], unet_ref.StubTextEncoder(), x_T, noises, image_context=batch['A_emb'])
+    err = float((out - ref).abs().max())
+    worst = max(abs(sde_ref.psnr(out[b], batch['target'][b]) - sde_ref.psnr(ref[b], batch['target'][b])) for b in range(B))
+    print(f"hierarchical decoder chain: max|hip-oracle| {err:.3e}, worst |dPSNR| {worst:.2e} dB; plain-decoder oracle differs by "
+          f"{float((other - ref).abs().max()):.3e}")
+    assert worst < 1e-3 and err < 5e-4
+    assert float((other - ref).abs().max()) > 20 * max(err, 1e-7)
+
+
+def oracle_nets_drop_gains(model):
+    """plain-ContextDecoder oracle nets loaded with the product's weights minus the branch gains (control for the test above)"""
+    opt = pipeline.load_options()
+    mo = opt['models']['DriftNoise']
+    refs = []
+    for key, net in (('dnet_settings', model.drift_net), ('nnet_settings', model.noise_net)):
+        s = {k: v for k, v in dict(mo[key]).items() if k not in ("module_name", "class_name")}
+        smm = nn.ModuleList([unet_ref.ScoreMapModule(visual_dim=mo['score_map_ngf'] * m) for m in mo['score_map_ch_mult']])
+        r = unet_ref.LearnableForwardUNet_MultiScoreMap(CLIP_ScoreMapModule=smm, use_image_context=True, **s).eval()
+        r.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items() if ".gamma_sa" not in k and ".gamma_ca" not in k and ".gamma_mlp" not in k})
+        refs.append(r)
+    return refs

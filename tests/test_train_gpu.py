@@ -508,3 +508,46 @@ def test_fused_scoremap_cross_attention_forward_backward_vs_fp64(B, R, N):
         e = float((got.detach().cpu().double() - ref.detach()).abs().max() / ref.detach().abs().max())
         print(f"fused cross-attention B={B} R={R} N={N}: {name} rel err {e:.2e}")
         assert e < tol, (name, e)
+
+
+@pytest.mark.parametrize("C,H", [(64, 16), (256, 8)])
+def test_scaled_decoder_scoremap_module_gradients_vs_fp64_oracle(C, H):
+    """ScoreMapModule over ContextDecoder_Hierachical / TransformerDecoderLayer_scaled (models/_modified_BiomedCLIP.py:552-590,
+    1247-1308): training-mode forward (dropout 0) and every parameter gradient, the branch gains gamma_sa/ca/mlp included, against
+    the fp64 oracle module with the same weights."""
+    from instancediff_amd.models.modules.MSM_degEmb_Unet import ScoreMapModule
+    from instancediff_amd.models.modules.unet_autograd import _smm
+    B, K = 2, 5
+    g = _g(31)
+    smm = ScoreMapModule(visual_dim=C, decoder_layers=2, decoder_type="ContextDecoder_Hierachical", dropout=0.0).to(DEV).train()
+    with torch.no_grad():
+        smm.gamma.fill_(0.3)
+        for l in smm.context_decoder.decoder:
+            for name in ("gamma_sa", "gamma_ca", "gamma_mlp"):
+                getattr(l, name).copy_((0.1 + 0.2 * torch.randn((1, 1, 256), generator=g)).to(DEV))
+    ref = unet_ref.ScoreMapModule(visual_dim=C, decoder_layers=2, decoder_type="ContextDecoder_Hierachical")
+    ref.load_state_dict({k: v.detach().cpu() for k, v in smm.state_dict().items()})
+    ref = ref.double()
+    from instancediff_amd.models.text_encoder import StubTextEncoder
+    te = StubTextEncoder().to(DEV)
+    feat = torch.randn(B, C, H, H, generator=g)
+    wgt = torch.randn(B, K, H, H, generator=g)
+    idx = torch.tensor([1, 3], dtype=torch.int32, device=DEV)
+    fr = feat.double().requires_grad_(True)
+    out_r = ref(fr, unet_ref.StubTextEncoder().double())
+    (out_r * wgt.double()).sum().backward()
+    fd = feat.to(DEV).requires_grad_(True)
+    score, _ = _smm(smm, fd, te, idx)
+    (score * wgt.to(DEV)).sum().backward()
+    assert _rel(score, out_r.float()) < 2e-5
+    assert _rel(fd.grad, fr.grad.float()) < 5e-4
+    rg = dict(ref.named_parameters())
+    seen = 0
+    for k, p in smm.named_parameters():
+        r = rg[k].grad
+        assert p.grad is not None, k
+        scale = float(r.abs().max())
+        e = float((p.grad.cpu().double().reshape(r.shape) - r).abs().max()) / max(scale, 1e-12)
+        assert e < 1e-3, (k, e)
+        seen += "gamma_" in k
+    assert seen == 6
