@@ -105,6 +105,10 @@ typedef struct {
                                request: profiling, parity tests of a kernel at small sizes; a request for the F(4x4,3x3) kernel
                                waives its 16-items-per-sample threshold, nothing else); -(1 + IDIFF_CONV_ALGO_x) = prefer that
                                kernel where the shape tiles for it, the library's own choice elsewhere */
+    const void* wx3;        /* ks == 1, normal mode: the weights split three ways into bf16 planes (idiff_pack_conv1x1_x3) or NULL.
+                               With it, 1x1 layers whose pixels tile by 256 (Cout % 64 == 0, C0 % 8 == 0, Cin % 8 == 0, Cin >= 32, no prologue, no
+                               statistics) run on the bf16 matrix cores with six products per fp32 product (IDIFF_CONV_ALGO_X3:
+                               fp32-class result, csrc/conv1x1_x3.hip); NULL keeps them on the f32 matrix cores */
 } idiff_conv_desc;
 
 int idiff_conv2d_num_tiles(int Hout, int Wout);
@@ -115,7 +119,13 @@ int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream);
 #define IDIFF_CONV_ALGO_STREAM1X1 2 /* weight gradient only: streaming 1x1 product */
 #define IDIFF_CONV_ALGO_WINOGRAD4 3 /* F(4x4,3x3),  conv_wino4.hip  */
 #define IDIFF_CONV_ALGO_WINOGRAD4H 4 /* F(4x4,3x3), half-patch items, two workgroups per CU: conv_wino4h.hip */
+#define IDIFF_CONV_ALGO_X3 5 /* 1x1, fp32 operands as three bf16 planes, six bf16 MFMAs per product: conv1x1_x3.hip */
 int idiff_conv2d_last_algo(void);
+/* w [Cout][Cin] (the ks == 1 weight, torch layout) -> the three-plane bf16 image idiff_conv_desc.wx3 points to:
+ * [chunk of 32 ci][block of 64 co][plane][octet of 8 ci][co][8 bf16], zero beyond Cin / Cout; x = plane0 + plane1 + plane2 exactly.
+ * `image` holds idiff_conv1x1_x3_image_bytes(Cout, Cin) bytes, 16-byte aligned. */
+long long idiff_conv1x1_x3_image_bytes(int Cout, int Cin);
+int idiff_pack_conv1x1_x3(const float* w, void* image, int Cout, int Cin, idiff_stream_t stream);
 /* w [Cout][Cin][ks][ks] (torch layout) -> wpk [ks*ks][Cin][Cout] */
 int idiff_pack_conv_weight(const float* w, float* wpk, int Cout, int Cin, int ks, idiff_stream_t stream);
 /* same, but spatially flipped and in/out swapped: wpk_T [ks*ks][Cout][Cin] for the data-gradient conv */

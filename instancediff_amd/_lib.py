@@ -34,6 +34,7 @@ class ConvDesc(C.Structure):
         ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p), ("gn_film", C.c_void_p), ("gn_film_ld", C.c_int64), ("gn_eps", C.c_float),
         ("gn_groups", C.c_int32), ("gn_out_a", C.c_void_p), ("gn_out_b", C.c_void_p), ("gn_mean_rstd", C.c_void_p), ("gn_ticket", C.c_void_p),
         ("algo_request", C.c_int32),
+        ("wx3", C.c_void_p),
     ]
 
 
@@ -59,6 +60,8 @@ SIGNATURES = {
     "idiff_pack_conv_weight_T": (I, [P, P, I, I, I, c_stream]),
     "idiff_pack_conv_weight_wino": (I, [P, P, I, I, I, c_stream]),
     "idiff_pack_conv_weight_wino4": (I, [P, P, I, I, I, c_stream]),
+    "idiff_conv1x1_x3_image_bytes": (C.c_longlong, [I, I]),
+    "idiff_pack_conv1x1_x3": (I, [P, P, I, I, c_stream]),
     "idiff_gn_finalize": (I, [P, I, I, I, I, I, P, P, P, I64, F, P, P, P, c_stream]),
     "idiff_affine_silu_add": (I, [P, I64, P, P, P, I64, P, P, I64, I, I, I, c_stream]),
     "idiff_linear_fwd": (I, [P, I64, P, I64, P, P, I64, P, P, I64, I, I, I, I, I, c_stream]),

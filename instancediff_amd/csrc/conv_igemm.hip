@@ -692,8 +692,24 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
     const bool hard = d->algo_request > 0;
     const int req = (hard ? d->algo_request : -d->algo_request) - 1;  // -1: the library picks
     IDIFF_CHECK_ARG(req == -1 || req == IDIFF_CONV_ALGO_DIRECT || req == IDIFF_CONV_ALGO_WINOGRAD || req == IDIFF_CONV_ALGO_WINOGRAD4 ||
-                        req == IDIFF_CONV_ALGO_WINOGRAD4H,
+                        req == IDIFF_CONV_ALGO_WINOGRAD4H || req == IDIFF_CONV_ALGO_X3,
                     "conv2d: bad algo_request %d", d->algo_request);
+    // Flattened 1x1 layers with a split weight image: the bf16x3 kernel (conv1x1_x3.hip) -- fp32-class result at 2.67x the matrix
+    // throughput; decided on the layer's shape only.  IDIFF_X3=0 (A/B runs) keeps them on the f32 matrix cores.
+    {
+        static const bool x3_on = [] {
+            const char* e = getenv("IDIFF_X3");
+            return !e || atoi(e) != 0;
+        }();
+        const bool reqx3 = req == IDIFF_CONV_ALGO_X3;
+        const bool can = twl == 8 && d->wx3 != nullptr && idiff_detail::conv1x1_x3_eligible(a);
+        IDIFF_CHECK_ARG(!(hard && reqx3) || can, "conv2d: algo_request bf16x3 but the layer is not a flattened 1x1 with a split weight image");
+        if (can && (reqx3 || (req == -1 && x3_on))) {
+            IDIFF_CHECK_ARG((reinterpret_cast<uintptr_t>(d->wx3) & 15) == 0, "conv2d: wx3 must be 16-byte aligned");
+            g_last_algo = IDIFF_CONV_ALGO_X3;
+            return idiff_detail::launch_conv1x1_x3(a, d->wx3, st);
+        }
+    }
     // Which F(4x4,3x3) kernel (both read the same weight image): decided on the layer's PER-SAMPLE shape only.
     //   >= 16 items of 16x32 pixels x 64 channels per sample: the 16x32 kernel -- except two-source (virtual concat) layers, whose long
     //      K favours the half-patch kernel (weights straight into the A operand: -4..8 % measured on the up-path layers at c2);

@@ -243,10 +243,16 @@ class ScoreMapModule(nn.Module):
             if c is not None and c[0] == key and c[2]() is text_encoder:
                 return c[1]
             with torch.no_grad():
-                text = text_encoder(self.tokens, self.contexts).float().expand(B, -1, -1).contiguous()
+                text = self._encode(text_encoder).expand(B, -1, -1).contiguous()
             self._text_cache = (key, text, weakref.ref(text_encoder))
             return text
-        return text_encoder(self.tokens, self.contexts).float().expand(B, -1, -1).contiguous()
+        return self._encode(text_encoder).expand(B, -1, -1).contiguous()
+
+    def _encode(self, text_encoder):
+        """one context set through the frozen encoder -> [1, K, text_dim]; CLIPTextContextEncoder returns [B, K, D]
+        (_modified_BiomedCLIP.py:883), HFContextTextEncoder the flat [B*K, D] (:979-991)"""
+        t = text_encoder(self.tokens, self.contexts).float()
+        return t.reshape(1, self.n_cls, -1) if t.dim() == 2 else t
 
     def forward(self, feat, text_encoder, idx=None):
         """feat [B,C,h,w] -> (score [B,K,h,w], sel [B,1,h,w] or None)."""

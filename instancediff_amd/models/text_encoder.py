@@ -120,6 +120,114 @@ class CLIPTextContextEncoder(nn.Module):
         return x.reshape(B, K, self.embed_dim)
 
 
+def _ns(**mods):
+    """a bare container whose children carry the given names (for HuggingFace-shaped parameter paths)"""
+    m = nn.Module()
+    for k, v in mods.items():
+        m.add_module(k, v)
+    return m
+
+
+class HFContextTextEncoder(nn.Module):
+    """The frozen BiomedCLIP context text encoder of the reference (models/_modified_BiomedCLIP.py:885-1015; selected by
+    CLIP_Type "BiomedCLIP", models/drift_noise_model.py:71-77): PubMedBERT = BERT-base (12 post-LN layers x 768, 12 heads, GELU MLP
+    3072, vocab 30522, 512 absolute positions, LayerNorm eps 1e-12; the hard-coded config dict :909-915) + CLS last-hidden-state
+    pooler + bias-free MLP projection 768 -> 640 -> 512 (:938-944).
+
+    `forward(x [K, N1] token ids, context [B, N2, 768]) -> [B*K, 512]` as the reference returns it (row b*K + k): the context
+    tokens are spliced in after the [CLS] embedding of every class prompt (`token_embedding`, :950-958), positions 0..N1+N2-1 and
+    token type 0 added, LayerNorm; attention mask = 1 on [CLS] / the context / non-pad prompt tokens (:966-969; the reference
+    builds it for exactly 5 prompts and B*K == 5, here K and B are free and the mask repeats over B).  The transformer is restated
+    here as plain torch (transformers' BertModel.forward(inputs_embeds=, attention_mask=) in eval mode: the reference's
+    modified_BertModel.forward :1081-1191 is a copy of it that ignores its `context` argument) -- no dependency on the
+    `transformers` package in the product.  Parameter paths equal the reference module's state dict (`transformer.embeddings.*`,
+    `transformer.encoder.layer.<i>.attention.self.query.*`, ..., `proj.0.weight`, `proj.2.weight`), so `init_weights` loads the
+    `text.*` entries of a BiomedCLIP checkpoint (open_clip_pytorch_model.bin) exactly as :946-953 does.  Frozen, forward argument
+    of the nets: host-side torch module evaluated once per context set."""
+    ignores_token_ids = False
+
+    def __init__(self, output_dim=512, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072, vocab_size=30522,
+                 max_position_embeddings=512, type_vocab_size=2, pad_token_id=0, layer_norm_eps=1e-12, output_tokens=False):
+        super().__init__()
+        H = hidden_size
+        self.output_dim, self.output_tokens, self.pad_token_id = output_dim, output_tokens, pad_token_id
+        self.heads, self.vocab_size, self.context_length = num_attention_heads, vocab_size, max_position_embeddings
+
+        def ln():
+            return nn.LayerNorm(H, eps=layer_norm_eps)
+
+        def layer():
+            return _ns(attention=_ns(self=_ns(query=nn.Linear(H, H), key=nn.Linear(H, H), value=nn.Linear(H, H)),
+                                     output=_ns(dense=nn.Linear(H, H), LayerNorm=ln())),
+                       intermediate=_ns(dense=nn.Linear(H, intermediate_size)),
+                       output=_ns(dense=nn.Linear(intermediate_size, H), LayerNorm=ln()))
+        self.transformer = _ns(
+            embeddings=_ns(word_embeddings=nn.Embedding(vocab_size, H, padding_idx=pad_token_id), position_embeddings=nn.Embedding(max_position_embeddings, H),
+                           token_type_embeddings=nn.Embedding(type_vocab_size, H), LayerNorm=ln()),
+            encoder=_ns(layer=nn.ModuleList([layer() for _ in range(num_hidden_layers)])))
+        hid = (H + output_dim) // 2
+        self.proj = nn.Sequential(nn.Linear(H, hid, bias=False), nn.GELU(), nn.Linear(hid, output_dim, bias=False))
+        for m in self.transformer.modules():  # BertPreTrainedModel._init_weights (initializer_range 0.02)
+            if isinstance(m, (nn.Linear, nn.Embedding)):
+                nn.init.normal_(m.weight, std=0.02)
+                if isinstance(m, nn.Linear):
+                    nn.init.zeros_(m.bias)
+        with torch.no_grad():
+            self.transformer.embeddings.word_embeddings.weight[pad_token_id].zero_()
+
+    def init_weights(self, pretrain_path):
+        """load the `text.`-prefixed entries of a BiomedCLIP checkpoint (:946-953; strict=False and the report, as the reference).
+        HF buffers some transformers versions store (`embeddings.position_ids`, `embeddings.token_type_ids`) are constants here."""
+        state_dict = torch.load(pretrain_path, map_location="cpu", weights_only=True)
+        sd = {k[5:]: v for k, v in state_dict.items() if k.startswith("text.")}
+        for k in ("transformer.embeddings.position_ids", "transformer.embeddings.token_type_ids"):
+            sd.pop(k, None)
+        if not sd:
+            raise ValueError(f"{pretrain_path!r} holds no `text.*` entries: not a BiomedCLIP checkpoint")
+        missing, unexpected = self.load_state_dict(sd, strict=False)
+        if len(missing) == len(self.state_dict()):
+            raise ValueError(f"none of the text tower's parameters were found in {pretrain_path!r}")
+        print(f"{missing}, {unexpected}are misaligned params in text encoder")
+
+    def token_embedding(self, input_ids, context):  # :950-958
+        emb = self.transformer.embeddings.word_embeddings(input_ids)
+        K, N1, C = emb.shape
+        B, N2, _ = context.shape
+        emb = emb.reshape(1, K, N1, C).expand(B, K, N1, C)
+        ctx = context.reshape(B, 1, N2, C).expand(B, K, N2, C)
+        return torch.cat([emb[:, :, 0:1], ctx, emb[:, :, 1:]], dim=2).reshape(B * K, N1 + N2, C)
+
+    def forward(self, x, context):
+        K, N1 = x.shape
+        B, N2, C = context.shape
+        L = N1 + N2
+        if L > self.context_length:
+            raise ValueError(f"prompt length {N1} + context length {N2} exceeds the {self.context_length} positions")
+        keep = torch.ones((K, L), dtype=torch.bool, device=x.device)  # :966-969
+        tok = x != self.pad_token_id
+        keep[:, 0:1] = tok[:, 0:1]
+        keep[:, N2 + 1:] = tok[:, 1:]
+        keep = keep.reshape(1, K, L).expand(B, K, L).reshape(B * K, 1, 1, L)
+        emb = self.transformer.embeddings
+        h = self.token_embedding(x, context).to(emb.LayerNorm.weight.dtype)
+        bias = torch.zeros((B * K, 1, 1, L), dtype=h.dtype, device=h.device).masked_fill(~keep, torch.finfo(h.dtype).min)
+        h = emb.LayerNorm(h + emb.token_type_embeddings.weight[0] + emb.position_embeddings.weight[:L])
+        S, nh = B * K, self.heads
+        dh = h.shape[-1] // nh
+        for l in self.transformer.encoder.layer:
+            sa = getattr(l.attention, "self")
+            q, k, v = [f(h).reshape(S, L, nh, dh).transpose(1, 2) for f in (sa.query, sa.key, sa.value)]  # [S, heads, L, dh]
+            att = (q @ k.transpose(-1, -2)) * dh ** -0.5 + bias
+            a = (att.softmax(dim=-1) @ v).transpose(1, 2).reshape(S, L, nh * dh)
+            h = l.attention.output.LayerNorm(l.attention.output.dense(a) + h)
+            m = torch.nn.functional.gelu(l.intermediate.dense(h))
+            h = l.output.LayerNorm(l.output.dense(m) + h)
+        projected = self.proj(h[:, 0])  # ClsLastHiddenStatePooler (BiomedCLIP/hf_model.py:83-93): position 0
+        if self.output_tokens:
+            return projected, h
+        return projected
+
+
 def build_text_encoder(pretrain_path=None, CLIP_Type="CLIP"):
     """Returns (frozen encoder, token_embed_dim) for `CLIP_Type` (models/drift_noise_model.py:70-90).
 
@@ -128,8 +236,9 @@ def build_text_encoder(pretrain_path=None, CLIP_Type="CLIP"):
         `StubTextEncoder`, explicitly requested;
       * CLIP_Type "CLIP" builds `CLIPTextContextEncoder` and loads the text tower of the configured OpenAI CLIP archive;
         a configured path that does not exist raises FileNotFoundError (the reference would crash in torch.jit.load,
-        _modified_BiomedCLIP.py:831).  "BiomedCLIP" (HF PubMedBERT) is not implemented: pass an instance via
-        CLIPDriftModel(text_encoder=...)."""
+        _modified_BiomedCLIP.py:831);
+      * CLIP_Type "BiomedCLIP" builds `HFContextTextEncoder` (PubMedBERT-shaped, token_embed_dim 768) and loads the `text.*`
+        entries of the configured BiomedCLIP checkpoint (models/drift_noise_model.py:71-77)."""
     if str(CLIP_Type).lower() == "stub":
         enc = StubTextEncoder()
         for p in enc.parameters():
@@ -143,8 +252,12 @@ def build_text_encoder(pretrain_path=None, CLIP_Type="CLIP"):
         raise FileNotFoundError(f"text_encoder_pretrain_path={pretrain_path!r} does not exist: refusing to run CLIP_Type={CLIP_Type!r} "
                                 "with random text embeddings (set CLIP_Type: stub to ask for the seeded stand-in explicitly)")
     if str(CLIP_Type) == "BiomedCLIP":
-        raise NotImplementedError("the BiomedCLIP (HF PubMedBERT) context encoder (_modified_BiomedCLIP.py:885-1015) is not implemented; "
-                                  "pass an encoder instance via CLIPDriftModel(text_encoder=...)")
+        enc = HFContextTextEncoder()  # max seq len = 512
+        enc.init_weights(pretrain_path=str(pretrain_path))
+        for p in enc.parameters():
+            p.requires_grad_(False)
+        enc.eval()
+        return enc, 768
     enc = CLIPTextContextEncoder(context_length=42, embed_dim=512, transformer_width=512, transformer_heads=8, transformer_layers=12,
                                  pretrained=str(pretrain_path))  # models/drift_noise_model.py:79-86
     enc.init_weights()

@@ -61,13 +61,15 @@ def _c(t, name="tensor", dtype=torch.float32):
 
 # IDIFF_WINOGRAD=0 keeps every 3x3 conv on the direct implicit-GEMM kernel (A/B runs, parity bisection)
 WINOGRAD = bool(int(os.environ.get("IDIFF_WINOGRAD", "1")))
+# IDIFF_X3=0: no three-plane bf16 images of 1x1 weights are built, so every 1x1 conv stays on the f32 matrix cores
+X3 = bool(int(os.environ.get("IDIFF_X3", "1")))
 # IDIFF_WINOGRAD4=0 keeps the forward 3x3 convs off the F(4x4,3x3) kernel (they run F(2x2,3x3) or direct instead)
 WINOGRAD4 = WINOGRAD and bool(int(os.environ.get("IDIFF_WINOGRAD4", "1")))
 # IDIFF_WINOGRAD4_DGRAD=0 keeps the data-gradient convs of the backward pass on F(2x2,3x3)
 WINOGRAD4_DGRAD = bool(int(os.environ.get("IDIFF_WINOGRAD4_DGRAD", "1")))
 
 
-CONV_ALGO_DIRECT, CONV_ALGO_WINOGRAD, CONV_ALGO_STREAM1X1, CONV_ALGO_WINOGRAD4, CONV_ALGO_WINOGRAD4H = 0, 1, 2, 3, 4
+CONV_ALGO_DIRECT, CONV_ALGO_WINOGRAD, CONV_ALGO_STREAM1X1, CONV_ALGO_WINOGRAD4, CONV_ALGO_WINOGRAD4H, CONV_ALGO_X3 = 0, 1, 2, 3, 4, 5
 _ALGO_REQUEST = threading.local()
 
 
@@ -103,6 +105,11 @@ def pack_conv_weight(w, transpose=False):
             wino4 = torch.empty((36 * kconv * ((cconv + 63) // 64) * 64,), device=w.device, dtype=torch.float32)
             check(lib.idiff_pack_conv_weight_wino4(_p(w), _p(wino4), co, ci, 1 if transpose else 0, _stream()), "pack_conv_weight_wino4")
             out.wino4 = wino4
+    if k == 1 and not transpose and X3 and co % 64 == 0 and ci >= 32:
+        # three-plane bf16 image of a 1x1 weight (idiff_conv_desc.wx3): flattened 1x1 layers then run on the bf16 matrix cores
+        x3 = torch.empty((lib.idiff_conv1x1_x3_image_bytes(co, ci) // 2,), device=w.device, dtype=torch.int16)
+        check(lib.idiff_pack_conv1x1_x3(_p(w), x3.data_ptr(), co, ci, _stream()), "pack_conv1x1_x3")
+        out.x3 = x3
     return out
 
 
@@ -138,6 +145,9 @@ def conv2d(src0, wpk, bias, ks, Cout, src1=None, mode=CONV_NORMAL, pro=None, out
         wino4 = getattr(wpk, "wino4", None)
         if wino4 is not None:
             d.wwino4 = wino4.data_ptr()
+    x3 = getattr(wpk, "x3", None)
+    if x3 is not None and ks == 1 and mode == CONV_NORMAL:
+        d.wx3 = x3.data_ptr()
     if bias is not None:
         d.bias = _c(bias, "bias").data_ptr()
     if pro is not None:

@@ -158,6 +158,8 @@ class ScoreMapModule(nn.Module):
     def forward(self, feat, text_encoder):
         B, C, H, W = feat.shape
         text = text_encoder(self.tokens, self.contexts.expand(B, -1, -1))  # [B,K,text_dim]
+        if text.dim() == 2:  # HFContextTextEncoder returns the flat [B*K, text_dim] (_modified_BiomedCLIP.py:979-991)
+            text = text.reshape(B, -1, text.shape[-1])
         vis = feat.reshape(B, C, H * W).permute(0, 2, 1)
         diff = self.context_decoder(text, vis)  # [B,K,C]
         tv = self.text_to_visual(text) + self.gamma * diff

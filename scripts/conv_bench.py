@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--algos", type=str, default="", help="comma list of conv algorithm ids to request for the 3x3 layers, timed interleaved "
                     "(3 = F(4x4,3x3) 16x32 items, 4 = half-patch form, 1 = F(2x2,3x3)); empty = the library's choice")
+    ap.add_argument("--algos1", type=str, default="", help="the same for the 1x1 layers (0 = f32 matrix cores, 5 = bf16x3 split operands)")
     args = ap.parse_args()
     dev = "cuda"
     B = args.batch
@@ -35,6 +36,15 @@ def main():
         ("L2up 416->256 3x3 +stats", 256, 160, 256, 64, 3, 0, True, False),
         ("up 128->64 3x3 upsample", 128, 0, 64, 128, 3, 1, False, False),
         ("res 1x1 144->64", 64, 80, 64, 256, 1, 0, False, False),
+        ("res 1x1 128->64", 64, 64, 64, 256, 1, 0, False, False),
+        ("res 1x1 208->128", 128, 80, 128, 128, 1, 0, False, False),
+        ("res 1x1 192->128", 128, 64, 128, 128, 1, 0, False, False),
+        ("res 1x1 416->256", 256, 160, 256, 64, 1, 0, False, False),
+        ("res 1x1 384->256", 256, 128, 256, 64, 1, 0, False, False),
+        ("res 1x1 576->256", 256, 320, 256, 32, 1, 0, False, False),
+        ("res 1x1 512->256", 256, 256, 256, 32, 1, 0, False, False),
+        ("qkv 1x1 256->768", 256, 0, 768, 32, 1, 0, False, False),
+        ("proj 1x1 256->256", 256, 0, 256, 32, 1, 0, False, False),
         ("mem 1x1 64->256", 64, 0, 256, 256, 1, 0, False, False),
         ("down 1x1 unshuffle 64->64", 64, 0, 64, 256, 1, 2, False, False),
         ("final 3x3 64->5", 64, 0, 5, 256, 3, 0, False, False),
@@ -56,6 +66,9 @@ def main():
         kw = dict(src0=x0, wpk=w, bias=b, ks=ks, Cout=Co, src1=x1, mode=mode, pro=p, out=out, want_stats=stats)
         if args.algos and ks == 3:
             for al in args.algos.split(","):
+                cases.append((f"{name} [algo {al}]", dict(kw, algo=int(al)), fl))
+        elif args.algos1 and ks == 1 and mode == 0:
+            for al in args.algos1.split(","):
                 cases.append((f"{name} [algo {al}]", dict(kw, algo=int(al)), fl))
         else:
             cases.append((name, kw, fl))

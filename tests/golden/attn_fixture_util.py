@@ -35,3 +35,8 @@ TEXT_CASES = {
     "text_ref_shape": (dict(context_length=42, vocab_size=49408, transformer_width=512, transformer_heads=8, transformer_layers=12, embed_dim=512),
                        8, 5, 1, 902),  # models/drift_noise_model.py:79-86
 }
+
+# tag -> (class prompts K (the reference's mask is built for exactly 5, :966), prompt length N1, context tokens N2, weight seed)
+# HFContextTextEncoder, _modified_BiomedCLIP.py:885-1015 (PubMedBERT shape is hard-coded there: one size only)
+HFTEXT_CASES = {"hftext_n8": (5, 12, 8, 1201), "hftext_n32": (5, 10, 32, 1202)}
+HFTEXT_SCALE = 0.03  # std of the seeded matrices (768-wide layers)

@@ -247,7 +247,7 @@ def test_text_encoder_selection_is_loud(tmp_path):
     present.write_bytes(b"not a checkpoint")
     with pytest.raises(Exception, match="(?i)zip|archive|jit|pytorch|constants|file"):  # a real archive is parsed by torch.jit.load, as the reference does
         build_text_encoder(str(present), "CLIP")
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(Exception, match="(?i)pickle|zip|archive|load|invalid|weights"):  # HFContextTextEncoder.init_weights parses it with torch.load
         build_text_encoder(str(present), "BiomedCLIP")
     opt = pipeline.load_options()
     assert opt["models"]["DriftNoise"]["CLIP_Type"] == "stub"  # the shipped synthetic configuration asks for the stub by name
