@@ -74,6 +74,10 @@ __device__ __forceinline__ floatx4 mma(const uintx4& a, const uintx4& b, const f
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// UNSH: pixel-unshuffle(2) gather (IDIFF_CONV_UNSHUFFLE2, single source): virtual channel 4c + 2dy + dx of output pixel (oy, ox) is input
+// pixel (2oy + dy, 2ox + dx) of real channel c.  An octet = two real channels; a thread's four output pixels are eight consecutive
+// input pixels of two rows: 2 channels x 2 rows x 2 halves = the same eight 16-byte loads, re-indexed in registers.
+template <bool UNSH>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv1x1_x3_kernel(const ConvArgs a, const unsigned short* __restrict__ wx3) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char* const Bs = smem_raw;
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int tile = (logical / a.ncob) % a.ntiles;
     const int b = logical / (a.ncob * a.ntiles);
     const int co0 = cob * BM;
-    const long long HW = (long long)a.Hout * a.Wout;  // flattened by the caller: Hout == 1
+    const long long HW = (long long)a.Hout * a.Wout;  // output plane (normal mode: flattened by the caller, Hout == 1)
     const long long pix0 = (long long)tile * 256;
 
     {
@@ -113,17 +117,32 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // with zero records: no memory traffic, the registers read 0.0.  An octet lies in one source (C0v % 8 == 0) and is whole or
     // beyond Cin (Cin % 8 == 0).
     constexpr int RSRC_FLAGS = 0x00020000;
-    const float* const s0 = a.src0 + (long long)b * a.bs0 + pix0;
+    const float* const s0 = a.src0 + (long long)b * a.bs0 + (UNSH ? 0 : pix0);
     const float* const s1 = a.src1 ? a.src1 + (long long)b * a.bs1 + pix0 : s0;
-    const int chstride_b = (int)(HW * 4);  // bytes between channels (8 of them < 2^31: checked by the launcher)
+    const long long HWin = (long long)a.Hin * a.Win;
+    const int chstride_b = (int)((UNSH ? HWin : HW) * 4);  // bytes between (real) channels (8 of them < 2^31: checked by the launcher)
+    int xoff = q * 16;                                      // the lane's byte offset inside a channel plane
+    if (UNSH) {
+        const int p = (int)pix0 + 4 * q;
+        const int oy = p / a.Wout, ox = p - oy * a.Wout;
+        xoff = (2 * oy * a.Win + 2 * ox) * 4;
+    }
     auto load_x = [&](floatx4 (&xr)[8], int cc) {
         const int ch0 = cc * CKB + kg * 8;  // uniform
         const bool valid = ch0 < a.Cin;     // also false for a chunk past the last one
-        const bool second = ch0 >= a.C0v;
-        const float* const p = (second ? s1 : s0) + (long long)(valid ? (second ? ch0 - a.C0v : ch0) : 0) * HW;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(scalar_ptr(p), 0, __builtin_amdgcn_readfirstlane(valid ? 0x7fffffff : 0), RSRC_FLAGS);
+        if (UNSH) {
+            const float* const p = s0 + (long long)(valid ? (ch0 >> 2) : 0) * HWin;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(scalar_ptr(p), 0, __builtin_amdgcn_readfirstlane(valid ? 0x7fffffff : 0), RSRC_FLAGS);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) xr[c] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rs, q * 16, c * chstride_b, 0));
+            for (int c = 0; c < 8; ++c)  // c = (channel cl, row dy, half): the row's eight pixels as two 16-byte pieces
+                xr[c] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rs, xoff, (c >> 2) * chstride_b + ((c >> 1) & 1) * a.Win * 4 + (c & 1) * 16, 0));
+        } else {
+            const bool second = ch0 >= a.C0v;
+            const float* const p = (second ? s1 : s0) + (long long)(valid ? (second ? ch0 - a.C0v : ch0) : 0) * HW;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(scalar_ptr(p), 0, __builtin_amdgcn_readfirstlane(valid ? 0x7fffffff : 0), RSRC_FLAGS);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) xr[c] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rs, xoff, c * chstride_b, 0));
+        }
     };
     auto load_w = [&](int cc) {
         const bool valid = cc < nchunks;
@@ -138,7 +157,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         for (int i = 0; i < 4; ++i) {
             float v[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) v[c] = xr[c][i];
+            for (int c = 0; c < 8; ++c) {
+                if (UNSH) {  // octet element c = 4 cl + 2 dy + dx  <-  row piece (cl, dy), pixel 2 i + dx of its eight
+                    const int px = 2 * i + (c & 1);
+                    v[c] = xr[(c >> 1) * 2 + (px >> 2)][px & 3];
+                } else {
+                    v[c] = xr[c][i];
+                }
+            }
             uintx4 p1, p2, p3;
             split3(v, p1, p2, p3);
             *reinterpret_cast<uintx4*>(bw + i * B_ISTR) = p1;
@@ -295,21 +321,28 @@ __global__ void pack_x3_kernel(const float* __restrict__ w, uintx4* __restrict__
 
 namespace idiff_detail {
 
-// a: flattened 1x1 geometry (Hout == 1, Wout = pixels per sample, ntiles = Wout / 256, ncob = Cout / 64)
-bool conv1x1_x3_eligible(const ConvArgs& a) {
-    return a.Hout == 1 && a.Wout % 256 == 0 && a.Wout <= (1 << 25) && a.Cout % BM == 0 && a.C0v % 8 == 0 && a.Cin % 8 == 0 && !a.pro_a && !a.stats &&
-           a.Cin >= CKB;
+// normal mode: `a` holds the flattened 1x1 geometry (Hout == 1, Wout = pixels per sample); unshuffle mode: the real geometry.
+// Either way ntiles = output pixels per sample / 256 and ncob = Cout / 64 (set by the caller for this kernel).
+bool conv1x1_x3_eligible(const ConvArgs& a, int mode) {
+    const long long hw = (long long)a.Hout * a.Wout;
+    if (hw % 256 || hw > (1 << 25) || a.Cout % BM || a.Cin % 8 || a.Cin < CKB || a.pro_a || a.stats) return false;
+    if (mode == IDIFF_CONV_UNSHUFFLE2)
+        return !a.src1 && a.Wout % 4 == 0 && a.Win == 2 * a.Wout && (long long)a.Hin * a.Win <= (1 << 25) && a.bs0 % 4 == 0 &&
+               (reinterpret_cast<uintptr_t>(a.src0) & 15) == 0;
+    return mode == IDIFF_CONV_NORMAL && a.Hout == 1 && a.C0v % 8 == 0;
 }
 
-int launch_conv1x1_x3(const ConvArgs& a, const void* wx3, hipStream_t st) {
+int launch_conv1x1_x3(const ConvArgs& a, int mode, const void* wx3, hipStream_t st) {
     const size_t lds = B_BYTES + A_BYTES + 4 * BM * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "conv2d(1x1 x3): hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv1x1_x3_kernel, dim3(a.total_wg), dim3(NT), lds, st, a, static_cast<const unsigned short*>(wx3));
+    if (mode == IDIFF_CONV_UNSHUFFLE2) hipLaunchKernelGGL(conv1x1_x3_kernel<true>, dim3(a.total_wg), dim3(NT), lds, st, a, static_cast<const unsigned short*>(wx3));
+    else hipLaunchKernelGGL(conv1x1_x3_kernel<false>, dim3(a.total_wg), dim3(NT), lds, st, a, static_cast<const unsigned short*>(wx3));
     IDIFF_CHECK_LAUNCH("conv2d_fwd(1x1 x3)");
     return IDIFF_OK;
 }

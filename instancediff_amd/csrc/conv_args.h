@@ -67,7 +67,8 @@ int launch_conv_wino4h(const ConvArgs& a, int mode, hipStream_t st);
 // conv1x1_x3.hip: 1x1 conv on the bf16 matrix cores, fp32 operands split three ways (six MFMAs per product: fp32-class result).
 // `a` must describe the flattened 1x1 geometry (Hout == 1, 256-pixel tiles, 64-channel blocks); eligible: Wout % 256 == 0,
 // Cout % 64 == 0, C0v % 8 == 0, Cin % 8 == 0, Cin >= 32, no prologue, no GroupNorm partials.  wx3 = image of idiff_pack_conv1x1_x3.
-bool conv1x1_x3_eligible(const ConvArgs& a);
-int launch_conv1x1_x3(const ConvArgs& a, const void* wx3, hipStream_t st);
+// Unshuffle mode (pixel-unshuffle downsample): the real geometry, single source, Wout % 4 == 0, output pixels per sample % 256 == 0.
+bool conv1x1_x3_eligible(const ConvArgs& a, int mode);
+int launch_conv1x1_x3(const ConvArgs& a, int mode, const void* wx3, hipStream_t st);
 
 }  // namespace idiff_detail

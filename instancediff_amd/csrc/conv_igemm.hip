@@ -702,12 +702,24 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
             return !e || atoi(e) != 0;
         }();
         const bool reqx3 = req == IDIFF_CONV_ALGO_X3;
-        const bool can = twl == 8 && d->wx3 != nullptr && idiff_detail::conv1x1_x3_eligible(a);
-        IDIFF_CHECK_ARG(!(hard && reqx3) || can, "conv2d: algo_request bf16x3 but the layer is not a flattened 1x1 with a split weight image");
+        bool can = false;
+        ConvArgs ax = a;
+        if (d->ks == 1 && d->wx3 != nullptr && (reinterpret_cast<uintptr_t>(d->wx3) & 15) == 0) {
+            if (d->mode == IDIFF_CONV_NORMAL) {
+                can = twl == 8 && idiff_detail::conv1x1_x3_eligible(ax, d->mode);
+            } else if (d->mode == IDIFF_CONV_UNSHUFFLE2) {  // its own tiling: 256 consecutive output pixels x 64 channels
+                ax.ncob = a.Cout / 64;
+                ax.ntiles = (int)(((long long)a.Hout * a.Wout) / 256);
+                ax.tiles_x = ax.ntiles;
+                const long long tot = (long long)a.B * ax.ntiles * ax.ncob;
+                ax.total_wg = (unsigned)tot;
+                can = tot > 0 && tot < (1ll << 31) && idiff_detail::conv1x1_x3_eligible(ax, d->mode);
+            }
+        }
+        IDIFF_CHECK_ARG(!(hard && reqx3) || can, "conv2d: algo_request bf16x3 but the layer is not a 1x1 that tiles by 256 pixels with a split weight image");
         if (can && (reqx3 || (req == -1 && x3_on))) {
-            IDIFF_CHECK_ARG((reinterpret_cast<uintptr_t>(d->wx3) & 15) == 0, "conv2d: wx3 must be 16-byte aligned");
             g_last_algo = IDIFF_CONV_ALGO_X3;
-            return idiff_detail::launch_conv1x1_x3(a, d->wx3, st);
+            return idiff_detail::launch_conv1x1_x3(ax, d->mode, d->wx3, st);
         }
     }
     // Which F(4x4,3x3) kernel (both read the same weight image): decided on the layer's PER-SAMPLE shape only.

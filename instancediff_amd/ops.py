@@ -105,10 +105,13 @@ def pack_conv_weight(w, transpose=False):
             wino4 = torch.empty((36 * kconv * ((cconv + 63) // 64) * 64,), device=w.device, dtype=torch.float32)
             check(lib.idiff_pack_conv_weight_wino4(_p(w), _p(wino4), co, ci, 1 if transpose else 0, _stream()), "pack_conv_weight_wino4")
             out.wino4 = wino4
-    if k == 1 and not transpose and X3 and co % 64 == 0 and ci >= 32:
-        # three-plane bf16 image of a 1x1 weight (idiff_conv_desc.wx3): flattened 1x1 layers then run on the bf16 matrix cores
-        x3 = torch.empty((lib.idiff_conv1x1_x3_image_bytes(co, ci) // 2,), device=w.device, dtype=torch.int16)
-        check(lib.idiff_pack_conv1x1_x3(_p(w), x3.data_ptr(), co, ci, _stream()), "pack_conv1x1_x3")
+    cconv1, kconv1 = (ci, co) if transpose else (co, ci)  # the conv's (Cout, Cin)
+    if k == 1 and X3 and cconv1 % 64 == 0 and kconv1 >= 32 and kconv1 % 8 == 0:
+        # three-plane bf16 image of a 1x1 weight (idiff_conv_desc.wx3): flattened 1x1 layers then run on the bf16 matrix cores; the
+        # data-gradient pack is the image of the transposed matrix
+        wm = w.reshape(co, ci).t().contiguous() if transpose else w
+        x3 = torch.empty((lib.idiff_conv1x1_x3_image_bytes(cconv1, kconv1) // 2,), device=w.device, dtype=torch.int16)
+        check(lib.idiff_pack_conv1x1_x3(_p(wm), x3.data_ptr(), cconv1, kconv1, _stream()), "pack_conv1x1_x3")
         out.x3 = x3
     return out
 
@@ -146,7 +149,7 @@ def conv2d(src0, wpk, bias, ks, Cout, src1=None, mode=CONV_NORMAL, pro=None, out
         if wino4 is not None:
             d.wwino4 = wino4.data_ptr()
     x3 = getattr(wpk, "x3", None)
-    if x3 is not None and ks == 1 and mode == CONV_NORMAL:
+    if x3 is not None and ks == 1 and mode in (CONV_NORMAL, CONV_UNSHUFFLE2):
         d.wx3 = x3.data_ptr()
     if bias is not None:
         d.bias = _c(bias, "bias").data_ptr()

@@ -47,6 +47,8 @@ def main():
         ("proj 1x1 256->256", 256, 0, 256, 32, 1, 0, False, False),
         ("mem 1x1 64->256", 64, 0, 256, 256, 1, 0, False, False),
         ("down 1x1 unshuffle 64->64", 64, 0, 64, 256, 1, 2, False, False),
+        ("down 1x1 unshuffle 128->256 @64", 128, 0, 256, 64, 1, 2, False, False),
+        ("down 1x1 unshuffle 64->128 @128", 64, 0, 128, 128, 1, 2, False, False),
         ("final 3x3 64->5", 64, 0, 5, 256, 3, 0, False, False),
         ("init 7x7 2->64", 1, 1, 64, 256, 7, 0, False, False),
     ]
@@ -67,7 +69,7 @@ def main():
         if args.algos and ks == 3:
             for al in args.algos.split(","):
                 cases.append((f"{name} [algo {al}]", dict(kw, algo=int(al)), fl))
-        elif args.algos1 and ks == 1 and mode == 0:
+        elif args.algos1 and ks == 1 and mode in (0, 2):
             for al in args.algos1.split(","):
                 cases.append((f"{name} [algo {al}]", dict(kw, algo=int(al)), fl))
         else:

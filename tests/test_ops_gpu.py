@@ -743,3 +743,29 @@ def test_conv1x1_bf16x3_extreme_magnitudes_and_policy():
     assert ops._lib.load().idiff_conv2d_last_algo() == ops.CONV_ALGO_DIRECT
     with pytest.raises(Exception, match="bf16x3"):
         ops.conv2d(xs.to(DEV), wpk, None, 1, Cout, algo=ops.CONV_ALGO_X3)
+
+
+@pytest.mark.parametrize("B,C0,Cout,H,W,variant", [
+    (2, 64, 64, 32, 64, "plain"),    # the level-0 downsample (256 virtual channels -> 64), 2 output rows of 32 per... tile = 8 rows
+    (1, 128, 256, 64, 64, "res"),    # 512 -> 256, four channel blocks
+    (3, 16, 64, 16, 128, "plain"),   # 64 virtual channels: two chunks; wide rows (a 256-pixel tile = four output rows of 64)
+])
+def test_conv1x1_bf16x3_pixel_unshuffle(B, C0, Cout, H, W, variant):
+    """IDIFF_CONV_UNSHUFFLE2 on the bf16x3 kernel: the gather re-indexes eight 16-byte row pieces in registers"""
+    g = _g(13)
+    x = torch.randn(B, C0, H, W, generator=g) * 2.0
+    w = torch.randn(Cout, 4 * C0, 1, 1, generator=g) / math.sqrt(4 * C0)
+    bias = torch.randn(Cout, generator=g)
+    ref = F.conv2d(F.pixel_unshuffle(x.double(), 2), w.double(), bias.double())
+    kw = {}
+    if variant == "res":
+        r = torch.randn(B, Cout, H // 2, W // 2, generator=g)
+        ref = ref + r.double()
+        kw["res"] = r.to(DEV)
+    wpk = ops.pack_conv_weight(w.to(DEV))
+    out = ops.conv2d(x.to(DEV), wpk, bias.to(DEV), 1, Cout, mode=ops.CONV_UNSHUFFLE2, **kw)
+    assert ops._lib.load().idiff_conv2d_last_algo() == ops.CONV_ALGO_X3
+    _close(out, ref, 2e-6, "unshuffle conv1x1 bf16x3 vs fp64")
+    out32 = ops.conv2d(x.to(DEV), wpk, bias.to(DEV), 1, Cout, mode=ops.CONV_UNSHUFFLE2, algo=ops.CONV_ALGO_DIRECT, **kw)
+    assert ops._lib.load().idiff_conv2d_last_algo() == ops.CONV_ALGO_DIRECT
+    _close(out, out32, 2e-6, "unshuffle conv1x1 bf16x3 vs the f32 kernel")
