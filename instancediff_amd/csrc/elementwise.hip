@@ -318,6 +318,13 @@ __global__ __launch_bounds__(256) void scoremap4_kernel(const float* __restrict_
             if (k < K) dot[k] += f * tvn[k * C + c];
     };
     int c = 0;
+    for (; c + 8 <= C; c += 8) {  // eight 16-byte loads in flight per thread (16 waves per CU: 128 KB; four covered an HBM miss only just)
+        floatx4 f[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = *reinterpret_cast<const floatx4*>(fb + (long long)(c + i) * HW);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) step(f[i], c + i);
+    }
     for (; c + 4 <= C; c += 4) {
         const floatx4 f0 = *reinterpret_cast<const floatx4*>(fb + (long long)c * HW);
         const floatx4 f1 = *reinterpret_cast<const floatx4*>(fb + (long long)(c + 1) * HW);
