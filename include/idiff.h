@@ -109,6 +109,8 @@ typedef struct {
                                With it, 1x1 layers whose pixels tile by 256 (Cout % 64 == 0, C0 % 8 == 0, Cin % 8 == 0, Cin >= 32, no prologue, no
                                statistics) run on the bf16 matrix cores with six products per fp32 product (IDIFF_CONV_ALGO_X3:
                                fp32-class result, csrc/conv1x1_x3.hip); NULL keeps them on the f32 matrix cores */
+    const void* wwino4x;    /* ks == 3: F(4x4,3x3)-domain weights as three bf16 planes (idiff_pack_conv_weight_wino4x) or NULL; read only
+                               when algo_request names IDIFF_CONV_ALGO_WINOGRAD4X (experimental kernel, csrc/conv_wino4x.hip) */
 } idiff_conv_desc;
 
 int idiff_conv2d_num_tiles(int Hout, int Wout);
@@ -120,10 +122,15 @@ int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream);
 #define IDIFF_CONV_ALGO_WINOGRAD4 3 /* F(4x4,3x3),  conv_wino4.hip  */
 #define IDIFF_CONV_ALGO_WINOGRAD4H 4 /* F(4x4,3x3), half-patch items, two workgroups per CU: conv_wino4h.hip */
 #define IDIFF_CONV_ALGO_X3 5 /* 1x1, fp32 operands as three bf16 planes, six bf16 MFMAs per product: conv1x1_x3.hip */
+#define IDIFF_CONV_ALGO_WINOGRAD4X 6 /* F(4x4,3x3) with three-plane bf16 operands (experimental, by request only): conv_wino4x.hip */
 int idiff_conv2d_last_algo(void);
 /* w [Cout][Cin] (the ks == 1 weight, torch layout) -> the three-plane bf16 image idiff_conv_desc.wx3 points to:
  * [chunk of 32 ci][block of 64 co][plane][octet of 8 ci][co][8 bf16], zero beyond Cin / Cout; x = plane0 + plane1 + plane2 exactly.
  * `image` holds idiff_conv1x1_x3_image_bytes(Cout, Cin) bytes, 16-byte aligned. */
+/* the same split for the F(4x4,3x3)-domain weights U = G g G^T (shapes as idiff_pack_conv_weight_wino4): image of
+ * idiff_conv_wino4x_image_bytes(conv Cout, conv Cin) bytes, [chunk of 16 ci][block of 64 co][position][plane][octet][co][8 bf16] */
+long long idiff_conv_wino4x_image_bytes(int Cout, int Cin);
+int idiff_pack_conv_weight_wino4x(const float* w, void* image, int Cout, int Cin, int transpose, idiff_stream_t stream);
 long long idiff_conv1x1_x3_image_bytes(int Cout, int Cin);
 int idiff_pack_conv1x1_x3(const float* w, void* image, int Cout, int Cin, idiff_stream_t stream);
 /* w [Cout][Cin][ks][ks] (torch layout) -> wpk [ks*ks][Cin][Cout] */

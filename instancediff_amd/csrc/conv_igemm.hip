@@ -692,7 +692,7 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
     const bool hard = d->algo_request > 0;
     const int req = (hard ? d->algo_request : -d->algo_request) - 1;  // -1: the library picks
     IDIFF_CHECK_ARG(req == -1 || req == IDIFF_CONV_ALGO_DIRECT || req == IDIFF_CONV_ALGO_WINOGRAD || req == IDIFF_CONV_ALGO_WINOGRAD4 ||
-                        req == IDIFF_CONV_ALGO_WINOGRAD4H || req == IDIFF_CONV_ALGO_X3,
+                        req == IDIFF_CONV_ALGO_WINOGRAD4H || req == IDIFF_CONV_ALGO_X3 || req == IDIFF_CONV_ALGO_WINOGRAD4X,
                     "conv2d: bad algo_request %d", d->algo_request);
     // Flattened 1x1 layers with a split weight image: the bf16x3 kernel (conv1x1_x3.hip) -- fp32-class result at 2.67x the matrix
     // throughput; decided on the layer's shape only.  IDIFF_X3=0 (A/B runs) keeps them on the f32 matrix cores.
@@ -720,6 +720,16 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
         if (can && (reqx3 || (req == -1 && x3_on))) {
             g_last_algo = IDIFF_CONV_ALGO_X3;
             return idiff_detail::launch_conv1x1_x3(ax, d->mode, d->wx3, st);
+        }
+    }
+    if (req == IDIFF_CONV_ALGO_WINOGRAD4X) {  // experimental split-operand F(4x4,3x3): never the library's own choice
+        ConvArgs ax = a;
+        ax.wwino4 = static_cast<const float*>(d->wwino4x);  // same shape rules as the f32 F(4x4,3x3) kernels
+        const bool can = d->wwino4x != nullptr && idiff_detail::conv_wino4_items(ax, d->ks, d->mode, true) > 0;
+        IDIFF_CHECK_ARG(!hard || can, "conv2d: algo_request F(4x4,3x3) bf16x3 but the shape does not tile for it (or no wwino4x image)");
+        if (can) {
+            g_last_algo = IDIFF_CONV_ALGO_WINOGRAD4X;
+            return finalize_after(idiff_detail::launch_conv_wino4x(a, d->mode, d->wwino4x, st));
         }
     }
     // Which F(4x4,3x3) kernel (both read the same weight image): decided on the layer's PER-SAMPLE shape only.

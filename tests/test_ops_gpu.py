@@ -491,7 +491,28 @@ def force_wino4(request):
     (17, 40, 0, 64, 64, 96, "plain"),
 ])
 def test_conv_winograd4_matches_direct_and_fp64(force_wino4, B, C0, C1, Cout, H, W, variant):
-    lib = force_wino4
+    _check_wino4_case(force_wino4, B, C0, C1, Cout, H, W, variant)
+
+
+W4X_CASES = [
+    (2, 64, 0, 64, 32, 32, "plain"), (1, 8, 0, 128, 16, 64, "plain"), (2, 64, 0, 64, 16, 96, "prologue"), (1, 24, 40, 192, 32, 32, "concat"),
+    (2, 32, 0, 64, 16, 16, "upsample"), (1, 128, 0, 256, 64, 64, "epilogue"), (2, 32, 0, 80, 16, 32, "plain"), (1, 64, 0, 144, 16, 32, "epilogue"),
+    (2, 32, 0, 64, 28, 56, "plain"), (1, 64, 0, 64, 8, 112, "prologue"), (1, 24, 16, 64, 20, 40, "concat"), (2, 32, 0, 64, 28, 28, "epilogue"),
+    (21, 8, 0, 64, 64, 64, "epilogue"), (17, 40, 0, 64, 64, 96, "plain"),
+]
+
+
+@pytest.mark.parametrize("B,C0,C1,Cout,H,W,variant", W4X_CASES)
+def test_conv_winograd4x_split_operand_kernel_matches_direct_and_fp64(B, C0, C1, Cout, H, W, variant):
+    """csrc/conv_wino4x.hip (experimental, by request only): F(4x4,3x3) on the bf16 matrix cores, operands split three ways, 16
+    channels x two planes per matrix instruction -- the same cases and tolerances as the f32 F(4x4,3x3) kernels"""
+    with ops.request_conv3x3_algo(ops.CONV_ALGO_WINOGRAD4X):
+        lib = ops._lib.load()
+        lib.expected_algo = ops.CONV_ALGO_WINOGRAD4X
+        _check_wino4_case(lib, B, C0, C1, Cout, H, W, variant)
+
+
+def _check_wino4_case(lib, B, C0, C1, Cout, H, W, variant):
     g = _g(21)
     Cin = C0 + C1
     x0 = torch.randn(B, C0, H, W, generator=g)
@@ -520,7 +541,11 @@ def test_conv_winograd4_matches_direct_and_fp64(force_wino4, B, C0, C1, Cout, H,
         ref = raw + res.double() + vec.double()[:, :, None, None] + silu64(aa.double()[:, :, None, None] * aux.double() + ab.double()[:, :, None, None])
         kw.update(res=res.to(DEV), vec=vec.to(DEV), aux=(aux.to(DEV), aa.to(DEV), ab.to(DEV)))
     wd = w.to(DEV)
-    out_w, st_w = ops.conv2d(x0.to(DEV), _pack(wd, True, wino4=True), b.to(DEV), 3, Cout, want_stats=True, **kw)
+
+    def pk():
+        p = _pack(wd, True, wino4=True)
+        return ops.attach_wino4x(p, wd) if lib.expected_algo == ops.CONV_ALGO_WINOGRAD4X else p
+    out_w, st_w = ops.conv2d(x0.to(DEV), pk(), b.to(DEV), 3, Cout, want_stats=True, **kw)
     assert lib.idiff_conv2d_last_algo() == lib.expected_algo, "the requested F(4x4,3x3) kernel did not run"
     out_d, st_d = ops.conv2d(x0.to(DEV), _pack(wd, False), b.to(DEV), 3, Cout, want_stats=True, algo=ops.CONV_ALGO_DIRECT, **kw)
     assert lib.idiff_conv2d_last_algo() == 0
@@ -530,7 +555,7 @@ def test_conv_winograd4_matches_direct_and_fp64(force_wino4, B, C0, C1, Cout, H,
     _close(st_w.sum(1)[..., 1], (raw ** 2).sum(dim=(2, 3)), 4e-5, "winograd4 stats sumsq")
     _close(st_w, st_d.cpu(), 1e-4, "per-patch stats layout")
     # without statistics, and the launch is repeatable bit for bit
-    out_2 = ops.conv2d(x0.to(DEV), _pack(wd, True, wino4=True), b.to(DEV), 3, Cout, **kw)
+    out_2 = ops.conv2d(x0.to(DEV), pk(), b.to(DEV), 3, Cout, **kw)
     assert torch.equal(out_2, out_w)
 
 
