@@ -156,34 +156,47 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
     };
     typedef const __attribute__((address_space(4))) floatx4* cfloatx4p;
-    // one staging pass: 4 channels (sub) -> R[slot]; beyond Cin: zeros (their weights are zero too, but LDS must hold finite values)
-    auto stage_sub = [&](int sub, int slot, int b) {
-        float x[NL];
-        const bool live = sub < nsub;
-        const int cbase = sub * CK;
+    // staging in passes of 4 channels (sub -> R[slot]); beyond Cin: zeros (their weights are zero too, but LDS must hold finite
+    // values).  The next chunk's 24 raw elements travel in registers during the last multiply phase of the current one.
+    float rawr[SUBS][NL];
+    auto load_chunk = [&](int cc) {
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const int goff = live ? gtab[i * NT + tid] : -1;
-            if (SPEC == 3 && cbase >= a.C0v) x[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, goff, (cbase - a.C0v) * HWin * 4, 0));
-            else x[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs0, goff, cbase * HWin * 4, 0));
-        }
-        floatx4 pa = {0.f, 0.f, 0.f, 0.f}, pb = pa;
-        if (SPEC == 2 && live) {
-            const long long o = (long long)b * a.C0r + cbase;
-            pa = *(cfloatx4p)(a.pro_a + o);
-            pb = *(cfloatx4p)(a.pro_b + o);
-        }
+        for (int s = 0; s < SUBS; ++s) {
+            const int sub = cc * SUBS + s;
+            const bool live = sub < nsub;
+            const int cbase = sub * CK;
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            float v = x[i];
-            if (SPEC == 2) {  // channel of element tid + i*512: ((i*512 + wave*64) / 768), wave-uniform
-                const int ch = (i * NT + wave * 64) / PSP;
-                const float fa = ch == 0 ? pa.x : ch == 1 ? pa.y : ch == 2 ? pa.z : pa.w;
-                const float fb = ch == 0 ? pb.x : ch == 1 ? pb.y : ch == 2 ? pb.z : pb.w;
-                v = silu_fast(fa * v + fb);
-                if (((omask >> i) & 1u) || !live) v = 0.f;  // padding is zero AFTER the activation
+            for (int i = 0; i < NL; ++i) {
+                const int goff = gtab[i * NT + tid] | (live ? 0 : -1);  // branch-free: a dead pass reads through offset -1 (0.0, no access)
+                if (SPEC == 3 && cbase >= a.C0v) rawr[s][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, goff, (cbase - a.C0v) * HWin * 4, 0));
+                else rawr[s][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs0, goff, cbase * HWin * 4, 0));
             }
-            Rb[slot * R_SUB + tid + i * NT] = v;
+        }
+    };
+    auto write_chunk = [&](int cc, int b) {
+#pragma unroll
+        for (int s = 0; s < SUBS; ++s) {
+            const int sub = cc * SUBS + s;
+            const bool live = sub < nsub;
+            const int cbase = sub * CK;
+            floatx4 pa = {0.f, 0.f, 0.f, 0.f}, pb = pa;
+            if (SPEC == 2 && live) {
+                const long long o = (long long)b * a.C0r + cbase;
+                pa = *(cfloatx4p)(a.pro_a + o);
+                pb = *(cfloatx4p)(a.pro_b + o);
+            }
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                float v = rawr[s][i];
+                if (SPEC == 2) {  // channel of element tid + i*512: ((i*512 + wave*64) / 768), wave-uniform
+                    const int ch = (i * NT + wave * 64) / PSP;
+                    const float fa = ch == 0 ? pa.x : ch == 1 ? pa.y : ch == 2 ? pa.z : pa.w;
+                    const float fb = ch == 0 ? pb.x : ch == 1 ? pb.y : ch == 2 ? pb.z : pb.w;
+                    v = silu_fast(fa * v + fb);
+                    if (((omask >> i) & 1u) || !live) v = 0.f;  // padding is zero AFTER the activation
+                }
+                Rb[s * R_SUB + tid + i * NT] = v;
+            }
         }
     };
 
@@ -194,35 +207,44 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const float* const trb = Rb + (cp >> 1) * R_SUB + (2 * (cp & 1)) * PSP + (4 * tty) * RS + 4 * ttx;
     unsigned char* const vwr = Vb + vh * VROW + (cp >> 2) * 512 + tile * 16 + (cp & 3) * 4;
     auto transform_row = [&](int u) {
-        // B^T row u: w[c] = sum_r BT[u][r] d[r][c]
-        const float bt0 = u == 0 ? 4.f : 0.f;
-        const float bt1 = u == 1 ? -4.f : u == 2 ? 4.f : u == 3 ? -2.f : u == 4 ? 2.f : u == 5 ? 4.f : 0.f;
-        const float bt2 = u == 0 ? -5.f : (u == 1 || u == 2) ? -4.f : (u == 3 || u == 4) ? -1.f : 0.f;
-        const float bt3 = u == 1 ? 1.f : u == 2 ? -1.f : u == 3 ? 2.f : u == 4 ? -2.f : u == 5 ? -5.f : 0.f;
-        const float bt4 = u == 5 ? 0.f : 1.f;
-        const float bt5 = u == 5 ? 1.f : 0.f;
-        unsigned s[2][6][3];
+        // B^T row u touches at most four patch rows: w[c] = sum_k co[k] d[row[k]][c]   (uniform rows and coefficients, no branch)
+        //   u = 0: 4 d0 - 5 d2 + d4        u = 1, 2: (d4 - 4 d2) +- (d3 - 4 d1)        u = 3, 4: (d4 - d2) +- 2 (d3 - d1)        u = 5: 4 d1 - 5 d3 + d5
+        const int r0 = u == 0 ? 0 : 1, r1 = u == 0 ? 2 : (u == 5 ? 3 : 2), r2 = u == 0 ? 4 : (u == 5 ? 5 : 3), r3 = 4;
+        const float c0 = u == 0 ? 4.f : u == 1 ? -4.f : u == 2 ? 4.f : u == 3 ? -2.f : u == 4 ? 2.f : 4.f;
+        const float c1 = (u == 0 || u == 5) ? -5.f : (u <= 2 ? -4.f : -1.f);
+        const float c2 = (u == 0 || u == 5) ? 1.f : (u == 1 ? 1.f : u == 2 ? -1.f : u == 3 ? 2.f : -2.f);
+        const float c3 = (u == 0 || u == 5) ? 0.f : 1.f;
+        unsigned s0[6][3];
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
             const float* p = trb + ch * PSP;
-            float w[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                const float co = r == 0 ? bt0 : r == 1 ? bt1 : r == 2 ? bt2 : r == 3 ? bt3 : r == 4 ? bt4 : bt5;
+            float w[6];
+            auto row = [&](int r, float co, bool first) {
                 const floatx4 lo = *reinterpret_cast<const floatx4*>(p + r * RS);
                 const floatx2 hi = *reinterpret_cast<const floatx2*>(p + r * RS + 4);
-                w[0] = __builtin_fmaf(co, lo.x, w[0]), w[1] = __builtin_fmaf(co, lo.y, w[1]), w[2] = __builtin_fmaf(co, lo.z, w[2]);
-                w[3] = __builtin_fmaf(co, lo.w, w[3]), w[4] = __builtin_fmaf(co, hi.x, w[4]), w[5] = __builtin_fmaf(co, hi.y, w[5]);
-            }
+                if (first) {
+                    w[0] = co * lo.x, w[1] = co * lo.y, w[2] = co * lo.z, w[3] = co * lo.w, w[4] = co * hi.x, w[5] = co * hi.y;
+                } else {
+                    w[0] = __builtin_fmaf(co, lo.x, w[0]), w[1] = __builtin_fmaf(co, lo.y, w[1]), w[2] = __builtin_fmaf(co, lo.z, w[2]);
+                    w[3] = __builtin_fmaf(co, lo.w, w[3]), w[4] = __builtin_fmaf(co, hi.x, w[4]), w[5] = __builtin_fmaf(co, hi.y, w[5]);
+                }
+            };
+            row(r0, c0, true), row(r1, c1, false), row(r2, c2, false), row(r3, c3, false);
             float o[6];
             bt6(w, o);
 #pragma unroll
-            for (int v = 0; v < 6; ++v) split3(o[v], s[ch][v][0], s[ch][v][1], s[ch][v][2]);
+            for (int v = 0; v < 6; ++v) {
+                if (ch == 0) {
+                    split3(o[v], s0[v][0], s0[v][1], s0[v][2]);
+                } else {
+                    unsigned s1[3];
+                    split3(o[v], s1[0], s1[1], s1[2]);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<unsigned*>(vwr + ((v * 3 + pl) * 2) * 512) = pack_hi(s1[pl], s0[v][pl]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int v = 0; v < 6; ++v)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<unsigned*>(vwr + ((v * 3 + pl) * 2) * 512) = pack_hi(s[1][v][pl], s[0][v][pl]);
     };
 
     const int G = gridDim.x;
@@ -257,40 +279,64 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         floatx4 acc[18][2];  // [u * 3 + vl][tile block]
 #pragma unroll
         for (int p = 0; p < 18; ++p) acc[p][0] = acc[p][1] = floatx4{0.f, 0.f, 0.f, 0.f};
-        const __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(scalar_ptr(wimg)), 0, 0x7fffffff, RSRC_FLAGS);
-
+        load_chunk(0);
         for (int cc = 0; cc < nchunks; ++cc) {
             __syncthreads();  // the previous chunk's transforms have read R
-#pragma unroll
-            for (int s = 0; s < SUBS; ++s) stage_sub(cc * SUBS + s, s, b);
+#ifdef W4X_NO_PREFETCH
+            load_chunk(cc);
+#endif
+            write_chunk(cc, b);
             __syncthreads();
             const int ubase = (cc * a.ncob + it_cob) * UBLK;  // < 2^31: checked by the launcher
 #pragma unroll
             for (int up = 0; up < 3; ++up) {
                 transform_row(2 * up + vh);
+                __builtin_amdgcn_sched_barrier(0);
+                // A operands: the first row's three positions are requested behind the transform (its registers are free again) and
+                // travel across the barrier; the second row's behind the first row's MFMAs
+                uintx4 av[3][2];
+                auto load_a = [&](int rr) {
+                    // (the resource is rebuilt here from the kernel argument: kept across the item it is spilled to vector registers
+                    // and every load becomes a waterfall loop)
+                    const __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(scalar_ptr(wimg)), 0, 0x7fffffff, RSRC_FLAGS);
+#pragma unroll
+                    for (int vl = 0; vl < 3; ++vl) {
+                        const int pofs = __builtin_amdgcn_readfirstlane(ubase + ((2 * up + rr) * 6 + 3 * vh + vl) * UPOS);  // uniform
+                        av[vl][0] = __builtin_bit_cast(uintx4, __builtin_amdgcn_raw_buffer_load_b128(rsu, a_off0, pofs, 0));
+                        av[vl][1] = __builtin_bit_cast(uintx4, __builtin_amdgcn_raw_buffer_load_b128(rsu, a_off1, pofs, 0));
+                    }
+                };
+                load_a(0);
                 __syncthreads();
+                // the next chunk's pixels: behind the A operands in the in-order vmcnt queue; unconditional -- a chunk past the last one
+                // reads through offset -1 (no memory access, 0.0): a uniform branch around loads would turn every wait into vmcnt(0)
+#ifndef W4X_NO_PREFETCH
+                if (up == 2) load_chunk(cc + 1);
+#endif
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr) {
                     const int u = 2 * up + rr;
+                    uintx4 ac[3][2];
+#pragma unroll
+                    for (int vl = 0; vl < 3; ++vl) ac[vl][0] = av[vl][0], ac[vl][1] = av[vl][1];
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (rr == 0) load_a(1);
 #pragma unroll
                     for (int vl = 0; vl < 3; ++vl) {
-                        const int v = 3 * vh + vl;  // uniform
-                        const int pofs = ubase + (u * 6 + v) * UPOS;
-                        const uintx4 a1 = __builtin_bit_cast(uintx4, __builtin_amdgcn_raw_buffer_load_b128(rsu, a_off0, pofs, 0));
-                        const uintx4 a3 = __builtin_bit_cast(uintx4, __builtin_amdgcn_raw_buffer_load_b128(rsu, a_off1, pofs, 0));
-                        const unsigned char* const vb = Vb + rr * VROW + v * (3 * 2 * 512);
+                        const unsigned char* const vb = Vb + rr * VROW + (3 * vh + vl) * (3 * 2 * 512);
 #pragma unroll
                         for (int tb = 0; tb < 2; ++tb) {
                             const uintx4 b1 = *reinterpret_cast<const uintx4*>(vb + b_off1 + tb * 256);
                             const uintx4 b2 = *reinterpret_cast<const uintx4*>(vb + b_off2 + tb * 256);
                             const uintx4 b3 = *reinterpret_cast<const uintx4*>(vb + b_off3 + tb * 256);
                             floatx4 c = acc[u * 3 + vl][tb];
-                            c = mma(a3, b3, c);
-                            c = mma(a1, b2, c);
-                            c = mma(a1, b1, c);
+                            c = mma(ac[vl][1], b3, c);
+                            c = mma(ac[vl][0], b2, c);
+                            c = mma(ac[vl][0], b1, c);
                             acc[u * 3 + vl][tb] = c;
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 __syncthreads();  // the V rows are free again
             }
