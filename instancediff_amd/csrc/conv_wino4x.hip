@@ -102,14 +102,32 @@ __device__ __forceinline__ floatx4 mma(const uintx4& a, const uintx4& b, const f
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+#ifdef W4X_TRACE  // per-phase cycle counts of wave 0 (s_memtime), summed over the items, printed by the launcher (debug builds)
+#define TR_PARAM , long long* trace
+#define TR_INIT long long tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_t = __builtin_readcyclecounter();
+#define TR_MARK(k)                                         \
+    {                                                      \
+        const long long t_ = __builtin_readcyclecounter(); \
+        tr_acc[k] += t_ - tr_t;                            \
+        tr_t = t_;                                         \
+    }
+#define TR_FINI \
+    if (tid == 0) for (int q_ = 0; q_ < 8; ++q_) atomicAdd((unsigned long long*)trace + q_, (unsigned long long)tr_acc[q_]);
+#else
+#define TR_PARAM
+#define TR_INIT
+#define TR_MARK(k)
+#define TR_FINI
+#endif
+
 // SPEC: 1 = single source, no prologue; 2 = single source + GN/FiLM/SiLU prologue; 3 = two sources (virtual concat)
 template <int MODE, int SPEC, bool RAG>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino4x_kernel(const ConvArgs a, const Geo4x g, const unsigned char* __restrict__ wimg) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino4x_kernel(const ConvArgs a, const Geo4x g, const unsigned char* __restrict__ wimg TR_PARAM) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const econst = smem;                                        // [4][64]
     float* const Rb = smem + 256;                                      // [SUBS][R_SUB]; the epilogue's exchange area afterwards
-    unsigned char* const Vb = reinterpret_cast<unsigned char*>(Rb + R_FLOATS);  // [2 rows][VROW]
-    int* const gtab = reinterpret_cast<int*>(Vb + 2 * VROW);           // [NL][NT]
+    unsigned char* const Vb = reinterpret_cast<unsigned char*>(Rb + R_FLOATS);  // [2 pair buffers][2 rows][VROW]
+    int* const gtab = reinterpret_cast<int*>(Vb + 4 * VROW);           // [NL][NT]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -200,51 +218,54 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
     };
 
-    // ---- transform role: thread = (tile, channel pair) of one Winograd row per pass; waves 0-3 the even row, waves 4-7 the odd ----
-    const int tl = tid & 255;
-    const int tile = tl & 31, cp = tl >> 5;  // cp 0..7: channels 2cp, 2cp + 1 of the chunk
+    // ---- transform role: thread = (tile, ONE channel of the chunk), BOTH Winograd rows of a pair: the two rows share their patch rows
+    // (five at most), each read once and folded into the two B^T-along-the-rows sums with compile-time coefficients.  Eleven slices,
+    // dealt out between the MFMA units of the previous row pair (every slice's LDS read is consumed one slice later); the outputs
+    // are split and stored as single bf16 (the two channels of a dword come from lanes 32 apart).
+    const int tile = tid & 31, tch = tid >> 5;  // channel tch (0..15) of the chunk
     const int tty = tile >> 3, ttx = tile & 7;
-    const float* const trb = Rb + (cp >> 1) * R_SUB + (2 * (cp & 1)) * PSP + (4 * tty) * RS + 4 * ttx;
-    unsigned char* const vwr = Vb + vh * VROW + (cp >> 2) * 512 + tile * 16 + (cp & 3) * 4;
-    auto transform_row = [&](int u) {
-        // B^T row u touches at most four patch rows: w[c] = sum_k co[k] d[row[k]][c]   (uniform rows and coefficients, no branch)
-        //   u = 0: 4 d0 - 5 d2 + d4        u = 1, 2: (d4 - 4 d2) +- (d3 - 4 d1)        u = 3, 4: (d4 - d2) +- 2 (d3 - d1)        u = 5: 4 d1 - 5 d3 + d5
-        const int r0 = u == 0 ? 0 : 1, r1 = u == 0 ? 2 : (u == 5 ? 3 : 2), r2 = u == 0 ? 4 : (u == 5 ? 5 : 3), r3 = 4;
-        const float c0 = u == 0 ? 4.f : u == 1 ? -4.f : u == 2 ? 4.f : u == 3 ? -2.f : u == 4 ? 2.f : 4.f;
-        const float c1 = (u == 0 || u == 5) ? -5.f : (u <= 2 ? -4.f : -1.f);
-        const float c2 = (u == 0 || u == 5) ? 1.f : (u == 1 ? 1.f : u == 2 ? -1.f : u == 3 ? 2.f : -2.f);
-        const float c3 = (u == 0 || u == 5) ? 0.f : 1.f;
-        unsigned s0[6][3];
+    const float* const trb = Rb + (tch >> 2) * R_SUB + (tch & 3) * PSP + (4 * tty) * RS + 4 * ttx;
+    unsigned char* const vwr0 = Vb + (tch >> 3) * 512 + tile * 16 + (tch & 7) * 2;  // + (2 * pair buffer + row) * VROW + ((v * 3 + plane) * 2) * 512
+    float t_rw[6], t_wa[6], t_wb[6], t_o[6];
+    auto t_slice = [&](int k, auto up_tag, int pbw) {
+        constexpr int UP = decltype(up_tag)::value;
+        // rows of B^T (F(4x4,3x3)): 0: 4 d0 - 5 d2 + d4   1: -4 d1 - 4 d2 + d3 + d4   2: 4 d1 - 4 d2 - d3 + d4   3: -2 d1 - d2 + 2 d3 + d4
+        //                           4: 2 d1 - d2 - 2 d3 + d4   5: 4 d1 - 5 d3 + d5
+        constexpr float BT[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0}, {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+        constexpr int R0 = UP == 0 ? 0 : 1;  // first of the five patch rows the pair touches (pair 1 touches four: the fifth has zero weights)
+        auto rd = [&](int r) {
+            const float* p = trb + r * RS;
+            const floatx4 lo = *reinterpret_cast<const floatx4*>(p);
+            const floatx2 hi = *reinterpret_cast<const floatx2*>(p + 4);
+            t_rw[0] = lo.x, t_rw[1] = lo.y, t_rw[2] = lo.z, t_rw[3] = lo.w, t_rw[4] = hi.x, t_rw[5] = hi.y;
+        };
+        auto fold = [&](int r, bool first) {
+            const float ca = BT[2 * UP][r], cb = BT[2 * UP + 1][r];
 #pragma unroll
-        for (int ch = 0; ch < 2; ++ch) {
-            const float* p = trb + ch * PSP;
-            float w[6];
-            auto row = [&](int r, float co, bool first) {
-                const floatx4 lo = *reinterpret_cast<const floatx4*>(p + r * RS);
-                const floatx2 hi = *reinterpret_cast<const floatx2*>(p + r * RS + 4);
-                if (first) {
-                    w[0] = co * lo.x, w[1] = co * lo.y, w[2] = co * lo.z, w[3] = co * lo.w, w[4] = co * hi.x, w[5] = co * hi.y;
-                } else {
-                    w[0] = __builtin_fmaf(co, lo.x, w[0]), w[1] = __builtin_fmaf(co, lo.y, w[1]), w[2] = __builtin_fmaf(co, lo.z, w[2]);
-                    w[3] = __builtin_fmaf(co, lo.w, w[3]), w[4] = __builtin_fmaf(co, hi.x, w[4]), w[5] = __builtin_fmaf(co, hi.y, w[5]);
-                }
-            };
-            row(r0, c0, true), row(r1, c1, false), row(r2, c2, false), row(r3, c3, false);
-            float o[6];
-            bt6(w, o);
-#pragma unroll
-            for (int v = 0; v < 6; ++v) {
-                if (ch == 0) {
-                    split3(o[v], s0[v][0], s0[v][1], s0[v][2]);
-                } else {
-                    unsigned s1[3];
-                    split3(o[v], s1[0], s1[1], s1[2]);
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<unsigned*>(vwr + ((v * 3 + pl) * 2) * 512) = pack_hi(s1[pl], s0[v][pl]);
-                }
+            for (int c = 0; c < 6; ++c) {
+                t_wa[c] = first ? ca * t_rw[c] : (ca != 0.f ? __builtin_fmaf(ca, t_rw[c], t_wa[c]) : t_wa[c]);
+                t_wb[c] = first ? cb * t_rw[c] : (cb != 0.f ? __builtin_fmaf(cb, t_rw[c], t_wb[c]) : t_wb[c]);
             }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        };
+        auto emit = [&](int rr, int v) {
+            unsigned s1, s2, s3;
+            split3(t_o[v], s1, s2, s3);
+            unsigned char* const q = vwr0 + (2 * pbw + rr) * VROW + ((v * 3) * 2) * 512;
+            *reinterpret_cast<unsigned short*>(q) = (unsigned short)(s1 >> 16);
+            *reinterpret_cast<unsigned short*>(q + 2 * 512) = (unsigned short)(s2 >> 16);
+            *reinterpret_cast<unsigned short*>(q + 4 * 512) = (unsigned short)(s3 >> 16);
+        };
+        if (k == 0) rd(R0);
+        if (k == 1) fold(R0, true), rd(R0 + 1);
+        if (k == 2) fold(R0 + 1, false), rd(R0 + 2);
+        if (k == 3) fold(R0 + 2, false), rd(R0 + 3);
+        if (k == 4) fold(R0 + 3, false), rd(R0 + 4);
+        if (k == 5) fold(R0 + 4, false), bt6(t_wa, t_o);
+        if (k == 6) emit(0, 0), emit(0, 1), emit(0, 2);
+        if (k == 7) emit(0, 3), emit(0, 4), emit(0, 5);
+        if (k == 8) bt6(t_wb, t_o);
+        if (k == 9) emit(1, 0), emit(1, 1), emit(1, 2);
+        if (k == 10) emit(1, 3), emit(1, 4), emit(1, 5);
     };
 
     const int G = gridDim.x;
@@ -260,7 +281,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int b_off2 = ((1 * 2 + oct) * 32 + n16) * 16;                           // [v2 | v2]
     const int b_off3 = (((second ? 0 : 2) * 2 + oct) * 32 + n16) * 16;            // [v3 | v1]
 
+    TR_INIT
     for (int item = first; item < last; item += G) {
+        TR_MARK(7)
         decode(item);
         __syncthreads();  // every wave is done with the previous item's LDS (exchange area, gather table)
         setup_item();
@@ -279,69 +302,76 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         floatx4 acc[18][2];  // [u * 3 + vl][tile block]
 #pragma unroll
         for (int p = 0; p < 18; ++p) acc[p][0] = acc[p][1] = floatx4{0.f, 0.f, 0.f, 0.f};
+        // ---- main loop.  Per chunk of 16 channels (R staged):  T(pair 0) alone | M(pair 0) with T(pair 1) dealt out between its twelve
+        // units | M(pair 1) with T(pair 2) | M(pair 2) with the next chunk's pixels in flight | stage R.  A unit = one position x one
+        // tile block = three MFMAs; its B operands are requested one unit ahead, the A operands three positions ahead (rolling
+        // window of three positions: L2 latency), V pair buffers alternate P, P^1, P.
+        auto a_pofs = [&](int cc, int up, int j) {  // byte offset of position j (0..5) of row pair up of chunk cc in the weight image
+            const int ccl = cc < nchunks ? cc : nchunks - 1;  // past the end: a harmless re-read
+            return __builtin_amdgcn_readfirstlane((ccl * a.ncob + it_cob) * UBLK + ((2 * up + j / 3) * 6 + 3 * vh + j % 3) * UPOS);
+        };
+        uintx4 aw[3][2];
+        auto load_aw = [&](int slot, int pofs) {
+            const __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(scalar_ptr(wimg)), 0, 0x7fffffff, RSRC_FLAGS);
+            aw[slot][0] = __builtin_bit_cast(uintx4, __builtin_amdgcn_raw_buffer_load_b128(rsu, a_off0, pofs, 0));
+            aw[slot][1] = __builtin_bit_cast(uintx4, __builtin_amdgcn_raw_buffer_load_b128(rsu, a_off1, pofs, 0));
+        };
+        uintx4 bq[2][3];
+        auto load_b = [&](int set, int pbr, int n) {  // unit n = 2 j + tb of the pair buffer pbr
+            const int j = n >> 1, tb = n & 1;
+            const unsigned char* const vb = Vb + (2 * pbr + j / 3) * VROW + (3 * vh + j % 3) * (3 * 2 * 512) + tb * 256;
+            bq[set][0] = *reinterpret_cast<const uintx4*>(vb + b_off1);
+            bq[set][1] = *reinterpret_cast<const uintx4*>(vb + b_off2);
+            bq[set][2] = *reinterpret_cast<const uintx4*>(vb + b_off3);
+        };
+        // TK: 0 = transform the next pair (up + 1) into the other pair buffer; 1 = nothing; 2 = request the next chunk's pixels first
+        auto mphase = [&](int cc, auto up_tag, auto pbr_tag, auto tk_tag) {
+            constexpr int up = decltype(up_tag)::value, PBR = decltype(pbr_tag)::value, TK = decltype(tk_tag)::value;
+            load_b(0, PBR, 0);
+            if (TK == 2) load_chunk(cc + 1);  // (offset -1 past the last chunk: no access) -- behind the window's A loads, in order
+#pragma unroll
+            for (int n = 0; n < 12; ++n) {
+                const int j = n >> 1, tb = n & 1, u = 2 * up + j / 3, vl = j % 3;
+                if (n + 1 < 12) load_b((n + 1) & 1, PBR, n + 1);
+                floatx4 c = acc[u * 3 + vl][tb];
+                c = mma(aw[j % 3][1], bq[n & 1][2], c);
+                c = mma(aw[j % 3][0], bq[n & 1][1], c);
+                c = mma(aw[j % 3][0], bq[n & 1][0], c);
+                acc[u * 3 + vl][tb] = c;
+                if (tb == 1) {  // the position is done: its window slot takes the position three ahead
+                    if (j + 3 < 6) load_aw(j % 3, a_pofs(cc, up, j + 3));
+                    else if (up < 2) load_aw(j % 3, a_pofs(cc, up + 1, j - 3));
+                    else load_aw(j % 3, a_pofs(cc + 1, 0, j - 3));
+                }
+                if (TK == 0 && n < 11) t_slice(n, std::integral_constant<int, (up + 1) % 3>{}, PBR ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
         load_chunk(0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) load_aw(j, a_pofs(0, 0, j));
+        TR_MARK(0)
         for (int cc = 0; cc < nchunks; ++cc) {
-            __syncthreads();  // the previous chunk's transforms have read R
-#ifdef W4X_NO_PREFETCH
-            load_chunk(cc);
-#endif
+            __syncthreads();  // the previous chunk's transforms have read R, its last multiply phase the pair buffer P
             write_chunk(cc, b);
             __syncthreads();
-            const int ubase = (cc * a.ncob + it_cob) * UBLK;  // < 2^31: checked by the launcher
+            TR_MARK(1)
 #pragma unroll
-            for (int up = 0; up < 3; ++up) {
-                transform_row(2 * up + vh);
-                __builtin_amdgcn_sched_barrier(0);
-                // A operands: the first row's three positions are requested behind the transform (its registers are free again) and
-                // travel across the barrier; the second row's behind the first row's MFMAs
-                uintx4 av[3][2];
-                auto load_a = [&](int rr) {
-                    // (the resource is rebuilt here from the kernel argument: kept across the item it is spilled to vector registers
-                    // and every load becomes a waterfall loop)
-                    const __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(scalar_ptr(wimg)), 0, 0x7fffffff, RSRC_FLAGS);
-#pragma unroll
-                    for (int vl = 0; vl < 3; ++vl) {
-                        const int pofs = __builtin_amdgcn_readfirstlane(ubase + ((2 * up + rr) * 6 + 3 * vh + vl) * UPOS);  // uniform
-                        av[vl][0] = __builtin_bit_cast(uintx4, __builtin_amdgcn_raw_buffer_load_b128(rsu, a_off0, pofs, 0));
-                        av[vl][1] = __builtin_bit_cast(uintx4, __builtin_amdgcn_raw_buffer_load_b128(rsu, a_off1, pofs, 0));
-                    }
-                };
-                load_a(0);
-                __syncthreads();
-                // the next chunk's pixels: behind the A operands in the in-order vmcnt queue; unconditional -- a chunk past the last one
-                // reads through offset -1 (no memory access, 0.0): a uniform branch around loads would turn every wait into vmcnt(0)
-#ifndef W4X_NO_PREFETCH
-                if (up == 2) load_chunk(cc + 1);
-#endif
-#pragma unroll
-                for (int rr = 0; rr < 2; ++rr) {
-                    const int u = 2 * up + rr;
-                    uintx4 ac[3][2];
-#pragma unroll
-                    for (int vl = 0; vl < 3; ++vl) ac[vl][0] = av[vl][0], ac[vl][1] = av[vl][1];
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (rr == 0) load_a(1);
-#pragma unroll
-                    for (int vl = 0; vl < 3; ++vl) {
-                        const unsigned char* const vb = Vb + rr * VROW + (3 * vh + vl) * (3 * 2 * 512);
-#pragma unroll
-                        for (int tb = 0; tb < 2; ++tb) {
-                            const uintx4 b1 = *reinterpret_cast<const uintx4*>(vb + b_off1 + tb * 256);
-                            const uintx4 b2 = *reinterpret_cast<const uintx4*>(vb + b_off2 + tb * 256);
-                            const uintx4 b3 = *reinterpret_cast<const uintx4*>(vb + b_off3 + tb * 256);
-                            floatx4 c = acc[u * 3 + vl][tb];
-                            c = mma(ac[vl][1], b3, c);
-                            c = mma(ac[vl][0], b2, c);
-                            c = mma(ac[vl][0], b1, c);
-                            acc[u * 3 + vl][tb] = c;
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                __syncthreads();  // the V rows are free again
-            }
+            for (int k = 0; k < 11; ++k) t_slice(k, I0{}, 0);
+            TR_MARK(2)
+            __syncthreads();
+            TR_MARK(3)
+            mphase(cc, I0{}, I0{}, I0{});
+            __syncthreads();
+            mphase(cc, I1{}, I1{}, I0{});
+            __syncthreads();
+            mphase(cc, I2{}, I0{}, I2{});
+            TR_MARK(4)
         }
-
+        TR_MARK(5)
         // ---- epilogue.  C layout: lane holds tile n16 of tile block tb and channels 4 kgl + r of the wave's 16-channel block.
         // Phase 1: A^T along u for the wave's three columns, both tile blocks: t[tb][vl][r][dy]
         // Phase X: the wave finishes tile block tb = vh; the other block's t goes to the partner wave (cq, 1 - vh) through LDS, in two
@@ -450,12 +480,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 }
             }
         }
+        TR_MARK(6)
     }
+    TR_FINI
 }
 
 template <int MODE, int SPEC, bool RAG>
 int launch_rag(const ConvArgs& a, const void* wimg, hipStream_t st) {
-    const size_t lds = 256 * sizeof(float) + (size_t)R_FLOATS * sizeof(float) + 2 * VROW + (size_t)NL * NT * sizeof(int);
+    const size_t lds = 256 * sizeof(float) + (size_t)R_FLOATS * sizeof(float) + 4 * VROW + (size_t)NL * NT * sizeof(int);
     static bool attr_set = false;
     auto kern = conv_wino4x_kernel<MODE, SPEC, RAG>;
     if (!attr_set) {
@@ -477,7 +509,19 @@ int launch_rag(const ConvArgs& a, const void* wimg, hipStream_t st) {
     g.total = (int)total;
     const int per = (g.total + num_cu - 1) / num_cu;
     const int grid = (g.total + per - 1) / per;
+#ifdef W4X_TRACE
+    static long long* tr = nullptr;
+    if (!tr) (void)hipMalloc(&tr, 8 * sizeof(long long));
+    (void)hipMemsetAsync(tr, 0, 8 * sizeof(long long), st);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, a, g, static_cast<const unsigned char*>(wimg), tr);
+    long long h[8];
+    (void)hipMemcpyAsync(h, tr, sizeof(h), hipMemcpyDeviceToHost, st);
+    (void)hipStreamSynchronize(st);
+    fprintf(stderr, "[wino4x trace] Cin=%d Cout=%d H=%d items=%d | setup+load0 %lld  stage+bars %lld  transform %lld  bar(T) %lld  multiply %lld  bar(M) %lld  epilogue %lld  item-top %lld (cycles/item, wave 0)\n",
+            a.Cin, a.Cout, a.Hout, g.total, h[0] / g.total, h[1] / g.total, h[2] / g.total, h[3] / g.total, h[4] / g.total, h[5] / g.total, h[6] / g.total, h[7] / g.total);
+#else
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, a, g, static_cast<const unsigned char*>(wimg));
+#endif
     IDIFF_CHECK_LAUNCH("conv2d_fwd(winograd4x)");
     return IDIFF_OK;
 }
