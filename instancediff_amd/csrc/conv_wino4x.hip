@@ -1,22 +1,33 @@
 // Winograd F(4x4,3x3) convolution on the bf16 matrix cores with fp32 operands split three ways (gfx950, v_mfma_f32_16x16x32_bf16).
-// EXPERIMENTAL (round 3): correct and complete behind idiff_conv_desc.algo_request = 1 + IDIFF_CONV_ALGO_WINOGRAD4X, not chosen by the
-// library itself -- this first form is phase-serialised (stage | transform | multiply) and does not beat conv_wino4.hip yet; it fixes
-// the data layouts and the arithmetic of the pipelined kernel planned in DESIGN.md section 8.1.
+// EXPERIMENTAL (round 3): complete (every gather / prologue / epilogue form of conv_wino4.hip, partial patches) and parity-green behind
+// idiff_conv_desc.algo_request = 1 + IDIFF_CONV_ALGO_WINOGRAD4X; never the library's own choice -- it does not beat conv_wino4.hip
+// yet (64->64 at 256^2: 376 us against 295; 416->256 at 64^2: 420 against 347; profiles/r03/x_wino4x_experiments.txt) and its
+// prologue instantiation still spills.  What it fixes for the next round: the arithmetic, the data layouts, the pipeline shape, and
+// the measurement that says where the time goes (the weight stream, below).
 //
 //   Arithmetic.  U = G g G^T and V = B^T d B are formed in fp32 exactly as in conv_wino4.hip; each is then written as the exact sum
 //   of three bf16 values (conv1x1_x3.hip) and a Winograd-domain product is the six bf16 products of order >= 2^-16, accumulated in
-//   fp32: the error class of the f32 kernel.  The 32-deep contraction of the matrix instruction holds 16 input channels x TWO
-//   planes: [u1|u2].[v1|v1] + [u1|u2].[v2|v2] + [u1|u3].[v3|v1] = u1v1 + u2v1 + u1v2 + u2v2 + u1v3 + u3v1 -- three instructions per 16
-//   channels, a chunk of 16 channels (R, the activated patch, stays at 48 KB).
+//   fp32: the error class of the f32 kernel (same test cases, same tolerances).  The 32-deep contraction of the matrix instruction
+//   holds 16 input channels x TWO planes: [u1|u2].[v1|v1] + [u1|u2].[v2|v2] + [u1|u3].[v3|v1] = u1v1 + u2v1 + u1v2 + u2v2 + u1v3 + u3v1
+//   -- three instructions per 16 channels, so a chunk is 16 channels and R, the activated patch, stays at 48 KB.
 //
 //   Work.  Persistent 512-thread workgroups, item = 16x32 pixels (32 tiles) x 64 output channels, as conv_wino4.hip (same gather,
-//   same fused prologue / epilogue contract, same GroupNorm-partials grid).  Per chunk: the 16 channels are staged into R; then per
-//   PAIR of Winograd rows (u, u+1): waves 0-3 / 4-7 transform row u / u+1 of B^T d B for (tile, channel pair) = one task per thread,
-//   split the six outputs and write them as bf16 pairs into the row's V image [v][plane][octet][tile][8 bf16]; barrier; every wave
-//   multiplies: wave (cq, vh) owns 16 output channels x all 32 tiles x the 18 positions (u, 3 vh + 0..2) = 144 accumulators; A
-//   (weights, pre-split image of idiff_pack_conv_weight_wino4x) comes straight from L2, B from the V image.
+//   same fused prologue / epilogue contract, same GroupNorm-partials grid).  V lives in LDS one PAIR of Winograd rows at a time
+//   ([row][v][plane][octet][tile][8 bf16], 37 KB, two pair buffers): all 36 positions of a chunk would be 110 KB.  Per chunk:
+//   stage R | transform pair 0 | multiply pair 0 with the transform of pair 1 dealt out between its twelve units (one unit = one
+//   position x one tile block = three MFMAs; B one unit ahead) | multiply pair 1 with the transform of pair 2 | multiply pair 2 with
+//   the next chunk's pixels in flight.  Transform task = (tile, one channel), both rows of the pair from the five patch rows they
+//   share, outputs split and stored as single bf16.  MFMA role: wave (cq, vh) owns 16 output channels x all 32 tiles x the 18
+//   positions (u, 3 vh + 0..2) = 144 accumulators; A (weights, pre-split image of idiff_pack_conv_weight_wino4x) comes straight from
+//   L2 through a rolling window of three positions.
 //   Epilogue: A^T along u in-lane (a wave holds all six u of its columns), the two waves of a channel block swap the halves they
 //   do not finish (16 tiles each, through LDS), A^T along v over all six columns, then conv_wino4.hip's epilogue unchanged.
+//
+//   Where the time goes (W4X_TRACE build, wave 0, 64 -> 64 at 256^2, four chunks, cycles per item): setup + first loads 21.8 k |
+//   staging + barriers 13.6 k | transform of pair 0 (alone) 8.2 k + 3.8 k | the three multiply phases 47.6 k (4 k each, for 576 cycles
+//   of MFMA and ~520 of transform) | epilogue 10.8 k.  A multiply phase moves 96 KB of weights into the CU: 24 B/clk, near what the
+//   vector L1 delivered in the prototype (35 B/clk; 64 is its peak) -- every weight byte is used by 32 tiles only and is 1.5x as
+//   large as in fp32, at 2.7x the matrix rate.  The next form needs 64 tiles per weight fetch or weights streamed through LDS.
 #include <stdlib.h>
 
 #include <type_traits>
