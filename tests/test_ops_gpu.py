@@ -1,6 +1,7 @@
 """Op-level parity: every C-ABI kernel vs a plain PyTorch CPU (fp64 where cheap) reference of the same op.
 Runs on the GPU box only (-m gpu)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -502,6 +503,24 @@ W4X_CASES = [
 ]
 
 
+W4X_CHILD = os.environ.get("IDIFF_TEST_WINO4X") == "1"
+
+
+def test_conv_winograd4x_cases_in_a_process_of_their_own():
+    """The experimental split-operand F(4x4,3x3) kernel is exercised in a child process: a process that has run it aborts (SIGABRT from
+    the runtime, no message) when it later runs the opt-in fused-GroupNorm-tail launches of conv_wino4*.hip unless kernels are
+    serialised (AMD_SERIALIZE_KERNEL=3) -- open issue; neither path is a default.  The child runs the
+    parametrised cases below (IDIFF_TEST_WINO4X=1) and must report them all passed."""
+    import subprocess
+    import sys
+    env = dict(os.environ, IDIFF_TEST_WINO4X="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "winograd4x_split_operand", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    tail = (r.stdout + r.stderr)[-1500:]
+    assert r.returncode == 0 and f"{len(W4X_CASES)} passed" in r.stdout, tail
+
+
+@pytest.mark.skipif(not W4X_CHILD, reason="run by test_conv_winograd4x_cases_in_a_process_of_their_own (IDIFF_TEST_WINO4X=1)")
 @pytest.mark.parametrize("B,C0,C1,Cout,H,W,variant", W4X_CASES)
 def test_conv_winograd4x_split_operand_kernel_matches_direct_and_fp64(B, C0, C1, Cout, H, W, variant):
     """csrc/conv_wino4x.hip (experimental, by request only): F(4x4,3x3) on the bf16 matrix cores, operands split three ways, 16
