@@ -99,7 +99,10 @@ typedef struct {
                                kernel leaves them zero again; NULL: the separate finalize launch.  Measured at c2 (two nets on two
                                streams, HIP graph): the fused tail saves 76 launches per step and COSTS 0.45 ms of 26.0 -- every
                                workgroup has to drain its output stores before it may signal, and holds its CU meanwhile -- so the
-                               host code leaves it off unless IDIFF_GN_FUSED=1 (profiles/r03/x_gn_fused_finalize.txt) */
+                               host code leaves it off unless IDIFF_GN_FUSED=1 (profiles/r03/x_gn_fused_finalize.txt).  EXPERIMENTAL:
+                               the library itself honours a ticket only in a process started with IDIFF_GN_FUSED=1 (a cold process
+                               has shown an intermittent GPU memory fault in the fused tail, not root-caused); otherwise the ticket
+                               is ignored and the finalize is the library-enqueued launch -- same bits */
     int32_t algo_request;   /* 0 = the library picks (by the layer's per-sample shape only, never by the batch); 1 + IDIFF_CONV_ALGO_x =
                                run exactly that kernel or fail with IDIFF_E_ARG if the shape does not tile for it (a per-call
                                request: profiling, parity tests of a kernel at small sizes; a request for the F(4x4,3x3) kernel

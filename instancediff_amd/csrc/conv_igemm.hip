@@ -750,7 +750,15 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
         else if (req4) half = false;
         else if (items16 >= 16) half = w4h_mode == 2 || (w4h_mode == 1 && a.src1 != nullptr);
         else half = w4h_mode >= 1 && items8 >= 16;
-        const bool fuse = want_gn && d->gn_ticket != nullptr;  // the caller's choice: a ticket buffer asks for the fused tail
+        // The fused tail is experimental AND opt-in twice: the caller passes a ticket buffer and the process sets IDIFF_GN_FUSED=1.
+        // It is slower than the separate finalize launch (+0.45 ms/step) and a cold process has shown an intermittent GPU memory
+        // fault in it (scripts/abort_repro.py): without the environment switch a ticket is ignored and the
+        // finalize is the library-enqueued launch -- same bits.
+        static const bool gn_fused_on = [] {
+            const char* e = getenv("IDIFF_GN_FUSED");
+            return e && atoi(e) != 0;
+        }();
+        const bool fuse = want_gn && d->gn_ticket != nullptr && gn_fused_on;
         static const unsigned gn_nfin = [] {  // IDIFF_GN_FINALIZERS: workgroups kept for the finalize (default 32)
             const char* e = getenv("IDIFF_GN_FINALIZERS");
             const int v = e ? atoi(e) : 32;

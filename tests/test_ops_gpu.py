@@ -688,9 +688,12 @@ def test_conv_winograd4_bits_do_not_depend_on_the_batch(force_wino4):
     (2, 16, 0, 32, 16, 16, 8, True, False, None),     # direct kernel: likewise
 ])
 def test_conv_groupnorm_finalize_fused_equals_separate_launch(B, C0, C1, Cout, H, W, G, film, pro, algo):
-    """idiff_conv_desc.gn_*: the GroupNorm(+FiLM) finalize as the tail of the conv launch (last-arriving workgroups reduce the partials,
-    gn_tail.h) gives the SAME BITS as idiff_gn_finalize on the conv's statistics, launch after launch (the arrival counters clean
-    themselves), with and without a ticket (= fused / library-enqueued finalize)."""
+    """idiff_conv_desc.gn_*: the GroupNorm(+FiLM) finalize riding on the conv call gives the SAME BITS as idiff_gn_finalize on the conv's
+    statistics, launch after launch, with and without a ticket.  With IDIFF_GN_FUSED=1 in the environment a ticket selects the
+    experimental fused tail (last-arriving workgroups reduce the partials, gn_tail.h; the arrival counters clean themselves);
+    without it -- the default, and what the round's test tier runs -- the library ignores the ticket (an intermittent GPU memory
+    fault of the fused tail in a cold process is an open issue: scripts/abort_repro.py) and enqueues the
+    finalize launch: the assertions are the same either way."""
     lib = ops._lib.load()
     g = _g(500 + B + Cout)
     x0 = torch.randn(B, C0, H, W, generator=g).to(DEV)
