@@ -96,13 +96,9 @@ typedef struct {
     float* gn_out_b;
     float* gn_mean_rstd;    /* optional [B, groups, 2] */
     uint32_t* gn_ticket;    /* 4 zero-initialised words owned by the LAYER (not shared with a conv that may run concurrently); the
-                               kernel leaves them zero again; NULL: the separate finalize launch.  Measured at c2 (two nets on two
-                               streams, HIP graph): the fused tail saves 76 launches per step and COSTS 0.45 ms of 26.0 -- every
-                               workgroup has to drain its output stores before it may signal, and holds its CU meanwhile -- so the
-                               host code leaves it off unless IDIFF_GN_FUSED=1 (profiles/r03/x_gn_fused_finalize.txt).  EXPERIMENTAL:
-                               the library itself honours a ticket only in a process started with IDIFF_GN_FUSED=1 (a cold process
-                               has shown an intermittent GPU memory fault in the fused tail, not root-caused); otherwise the ticket
-                               is ignored and the finalize is the library-enqueued launch -- same bits */
+                               kernel leaves them zero again.  Non-NULL selects the finalize as the TAIL of the F(4x4,3x3) conv launch
+                               (gn_tail.h: the last-arriving workgroups reduce the partials; same bits as the separate launch);
+                               NULL, and kernels without the tail: the finalize launch enqueued behind the conv by this call */
     int32_t algo_request;   /* 0 = the library picks (by the layer's per-sample shape only, never by the batch); 1 + IDIFF_CONV_ALGO_x =
                                run exactly that kernel or fail with IDIFF_E_ARG if the shape does not tile for it (a per-call
                                request: profiling, parity tests of a kernel at small sizes; a request for the F(4x4,3x3) kernel
@@ -112,8 +108,6 @@ typedef struct {
                                With it, 1x1 layers whose pixels tile by 256 (Cout % 64 == 0, C0 % 8 == 0, Cin % 8 == 0, Cin >= 32, no prologue, no
                                statistics) run on the bf16 matrix cores with six products per fp32 product (IDIFF_CONV_ALGO_X3:
                                fp32-class result, csrc/conv1x1_x3.hip); NULL keeps them on the f32 matrix cores */
-    const void* wwino4x;    /* ks == 3: F(4x4,3x3)-domain weights as three bf16 planes (idiff_pack_conv_weight_wino4x) or NULL; read only
-                               when algo_request names IDIFF_CONV_ALGO_WINOGRAD4X (experimental kernel, csrc/conv_wino4x.hip) */
 } idiff_conv_desc;
 
 int idiff_conv2d_num_tiles(int Hout, int Wout);
@@ -125,15 +119,10 @@ int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream);
 #define IDIFF_CONV_ALGO_WINOGRAD4 3 /* F(4x4,3x3),  conv_wino4.hip  */
 #define IDIFF_CONV_ALGO_WINOGRAD4H 4 /* F(4x4,3x3), half-patch items, two workgroups per CU: conv_wino4h.hip */
 #define IDIFF_CONV_ALGO_X3 5 /* 1x1, fp32 operands as three bf16 planes, six bf16 MFMAs per product: conv1x1_x3.hip */
-#define IDIFF_CONV_ALGO_WINOGRAD4X 6 /* F(4x4,3x3) with three-plane bf16 operands (experimental, by request only): conv_wino4x.hip */
 int idiff_conv2d_last_algo(void);
 /* w [Cout][Cin] (the ks == 1 weight, torch layout) -> the three-plane bf16 image idiff_conv_desc.wx3 points to:
  * [chunk of 32 ci][block of 64 co][plane][octet of 8 ci][co][8 bf16], zero beyond Cin / Cout; x = plane0 + plane1 + plane2 exactly.
  * `image` holds idiff_conv1x1_x3_image_bytes(Cout, Cin) bytes, 16-byte aligned. */
-/* the same split for the F(4x4,3x3)-domain weights U = G g G^T (shapes as idiff_pack_conv_weight_wino4): image of
- * idiff_conv_wino4x_image_bytes(conv Cout, conv Cin) bytes, [chunk of 16 ci][block of 64 co][position][plane][octet][co][8 bf16] */
-long long idiff_conv_wino4x_image_bytes(int Cout, int Cin);
-int idiff_pack_conv_weight_wino4x(const float* w, void* image, int Cout, int Cin, int transpose, idiff_stream_t stream);
 long long idiff_conv1x1_x3_image_bytes(int Cout, int Cin);
 int idiff_pack_conv1x1_x3(const float* w, void* image, int Cout, int Cin, idiff_stream_t stream);
 /* w [Cout][Cin][ks][ks] (torch layout) -> wpk [ks*ks][Cin][Cout] */

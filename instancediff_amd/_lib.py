@@ -35,7 +35,6 @@ class ConvDesc(C.Structure):
         ("gn_groups", C.c_int32), ("gn_out_a", C.c_void_p), ("gn_out_b", C.c_void_p), ("gn_mean_rstd", C.c_void_p), ("gn_ticket", C.c_void_p),
         ("algo_request", C.c_int32),
         ("wx3", C.c_void_p),
-        ("wwino4x", C.c_void_p),
     ]
 
 
@@ -61,8 +60,6 @@ SIGNATURES = {
     "idiff_pack_conv_weight_T": (I, [P, P, I, I, I, c_stream]),
     "idiff_pack_conv_weight_wino": (I, [P, P, I, I, I, c_stream]),
     "idiff_pack_conv_weight_wino4": (I, [P, P, I, I, I, c_stream]),
-    "idiff_conv_wino4x_image_bytes": (C.c_longlong, [I, I]),
-    "idiff_pack_conv_weight_wino4x": (I, [P, P, I, I, I, c_stream]),
     "idiff_conv1x1_x3_image_bytes": (C.c_longlong, [I, I]),
     "idiff_pack_conv1x1_x3": (I, [P, P, I, I, c_stream]),
     "idiff_gn_finalize": (I, [P, I, I, I, I, I, P, P, P, I64, F, P, P, P, c_stream]),

@@ -29,6 +29,26 @@ extern std::atomic<unsigned long long> g_idiff_launches;  // kernel launches enq
         if (e__ != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "%s: %s", name, hipGetErrorString(e__)); \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: cache what has been set per (call site, device), safe for
+// concurrent host threads (one cache object per kernel instantiation: a function-local static of the launcher).
+struct idiff_dyn_lds_cache {
+    std::atomic<size_t> set[64];
+};
+inline hipError_t idiff_ensure_dyn_lds(idiff_dyn_lds_cache& c, const void* fn, size_t bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const bool cached = dev >= 0 && dev < 64;
+    if (cached && c.set[dev].load(std::memory_order_acquire) >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    if (cached) {
+        size_t prev = c.set[dev].load(std::memory_order_relaxed);
+        while (prev < bytes && !c.set[dev].compare_exchange_weak(prev, bytes, std::memory_order_release)) {}
+    }
+    return hipSuccess;
+}
+
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 

@@ -334,12 +334,11 @@ bool conv1x1_x3_eligible(const ConvArgs& a, int mode) {
 
 int launch_conv1x1_x3(const ConvArgs& a, int mode, const void* wx3, hipStream_t st) {
     const size_t lds = B_BYTES + A_BYTES + 4 * BM * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static idiff_dyn_lds_cache lds_cache[2];
+    {
+        hipError_t e = idiff_ensure_dyn_lds(lds_cache[0], reinterpret_cast<const void*>(conv1x1_x3_kernel<false>), lds);
+        if (e == hipSuccess) e = idiff_ensure_dyn_lds(lds_cache[1], reinterpret_cast<const void*>(conv1x1_x3_kernel<true>), lds);
         if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "conv2d(1x1 x3): hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
     }
     if (mode == IDIFF_CONV_UNSHUFFLE2) hipLaunchKernelGGL(conv1x1_x3_kernel<true>, dim3(a.total_wg), dim3(NT), lds, st, a, static_cast<const unsigned short*>(wx3));
     else hipLaunchKernelGGL(conv1x1_x3_kernel<false>, dim3(a.total_wg), dim3(NT), lds, st, a, static_cast<const unsigned short*>(wx3));

@@ -64,10 +64,6 @@ int launch_conv_wino4(const ConvArgs& a, int mode, hipStream_t st);
 // conv_wino4h.hip: two 256-thread workgroups per CU, items of 8x32 pixels x 64 channels, weights read straight into the A operand
 int launch_conv_wino4h(const ConvArgs& a, int mode, hipStream_t st);
 
-// conv_wino4x.hip (experimental, by request): F(4x4,3x3) with three-plane bf16 operands; shapes as conv_wino4_items, image of
-// idiff_pack_conv_weight_wino4x
-int launch_conv_wino4x(const ConvArgs& a, int mode, const void* wimg, hipStream_t st);
-
 // conv1x1_x3.hip: 1x1 conv on the bf16 matrix cores, fp32 operands split three ways (six MFMAs per product: fp32-class result).
 // `a` must describe the flattened 1x1 geometry (Hout == 1, 256-pixel tiles, 64-channel blocks); eligible: Wout % 256 == 0,
 // Cout % 64 == 0, C0v % 8 == 0, Cin % 8 == 0, Cin >= 32, no prologue, no GroupNorm partials.  wx3 = image of idiff_pack_conv1x1_x3.

@@ -520,12 +520,11 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     if (KS == 1 && TWL == 8 && MODE == IDIFF_CONV_NORMAL && (size_t)32 * 260 > taboff) taboff = (size_t)32 * 260;  // = TABOFF of the kernel
     const size_t lds = (taboff + (a.pro_a ? 2 * (size_t)a.C0r : 0) + 4 * BM) * sizeof(float);
     if (lds > 160 * 1024) IDIFF_FAIL(IDIFF_E_UNSUPPORTED, "conv2d: LDS budget exceeded (%zu bytes)", lds);
-    static size_t attr_set = 0;
+    static idiff_dyn_lds_cache lds_cache;
     auto kern = conv_igemm_kernel<KS, CK, TWL, MODE, VECW, MB, SPEC>;
-    if (lds > attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = idiff_ensure_dyn_lds(lds_cache, reinterpret_cast<const void*>(kern), lds);
         if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "conv2d: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = lds;
     }
     hipLaunchKernelGGL(kern, dim3(a.total_wg), dim3(256), lds, st, a);
     IDIFF_CHECK_LAUNCH("conv2d_fwd");
@@ -692,7 +691,7 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
     const bool hard = d->algo_request > 0;
     const int req = (hard ? d->algo_request : -d->algo_request) - 1;  // -1: the library picks
     IDIFF_CHECK_ARG(req == -1 || req == IDIFF_CONV_ALGO_DIRECT || req == IDIFF_CONV_ALGO_WINOGRAD || req == IDIFF_CONV_ALGO_WINOGRAD4 ||
-                        req == IDIFF_CONV_ALGO_WINOGRAD4H || req == IDIFF_CONV_ALGO_X3 || req == IDIFF_CONV_ALGO_WINOGRAD4X,
+                        req == IDIFF_CONV_ALGO_WINOGRAD4H || req == IDIFF_CONV_ALGO_X3,
                     "conv2d: bad algo_request %d", d->algo_request);
     // Flattened 1x1 layers with a split weight image: the bf16x3 kernel (conv1x1_x3.hip) -- fp32-class result at 2.67x the matrix
     // throughput; decided on the layer's shape only.  IDIFF_X3=0 (A/B runs) keeps them on the f32 matrix cores.
@@ -722,16 +721,6 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
             return idiff_detail::launch_conv1x1_x3(ax, d->mode, d->wx3, st);
         }
     }
-    if (req == IDIFF_CONV_ALGO_WINOGRAD4X) {  // experimental split-operand F(4x4,3x3): never the library's own choice
-        ConvArgs ax = a;
-        ax.wwino4 = static_cast<const float*>(d->wwino4x);  // same shape rules as the f32 F(4x4,3x3) kernels
-        const bool can = d->wwino4x != nullptr && idiff_detail::conv_wino4_items(ax, d->ks, d->mode, true) > 0;
-        IDIFF_CHECK_ARG(!hard || can, "conv2d: algo_request F(4x4,3x3) bf16x3 but the shape does not tile for it (or no wwino4x image)");
-        if (can) {
-            g_last_algo = IDIFF_CONV_ALGO_WINOGRAD4X;
-            return finalize_after(idiff_detail::launch_conv_wino4x(a, d->mode, d->wwino4x, st));
-        }
-    }
     // Which F(4x4,3x3) kernel (both read the same weight image): decided on the layer's PER-SAMPLE shape only.
     //   >= 16 items of 16x32 pixels x 64 channels per sample: the 16x32 kernel -- except two-source (virtual concat) layers, whose long
     //      K favours the half-patch kernel (weights straight into the A operand: -4..8 % measured on the up-path layers at c2);
@@ -750,15 +739,8 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
         else if (req4) half = false;
         else if (items16 >= 16) half = w4h_mode == 2 || (w4h_mode == 1 && a.src1 != nullptr);
         else half = w4h_mode >= 1 && items8 >= 16;
-        // The fused tail is experimental AND opt-in twice: the caller passes a ticket buffer and the process sets IDIFF_GN_FUSED=1.
-        // It is slower than the separate finalize launch (+0.45 ms/step) and a cold process has shown an intermittent GPU memory
-        // fault in it (scripts/abort_repro.py): without the environment switch a ticket is ignored and the
-        // finalize is the library-enqueued launch -- same bits.
-        static const bool gn_fused_on = [] {
-            const char* e = getenv("IDIFF_GN_FUSED");
-            return e && atoi(e) != 0;
-        }();
-        const bool fuse = want_gn && d->gn_ticket != nullptr && gn_fused_on;
+        // The GroupNorm finalize as the tail of the conv launch (gn_tail.h) is opt-in per call: the caller passes a ticket buffer.
+        const bool fuse = want_gn && d->gn_ticket != nullptr;
         static const unsigned gn_nfin = [] {  // IDIFF_GN_FINALIZERS: workgroups kept for the finalize (default 32)
             const char* e = getenv("IDIFF_GN_FINALIZERS");
             const int v = e ? atoi(e) : 32;

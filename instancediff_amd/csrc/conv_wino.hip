@@ -500,12 +500,11 @@ template <int MODE, int SPEC, bool RAG>
 int launch_rag(const ConvArgs& a, hipStream_t st) {
     const size_t lds = ((size_t)2 * R_FLOATS + 2 * V_FLOATS + 2 * U_FLOATS + 256 + (SPEC == 2 ? 4 * (size_t)a.C0r : 0)) * sizeof(float);
     if (lds > 160 * 1024) IDIFF_FAIL(IDIFF_E_UNSUPPORTED, "conv2d(winograd): LDS budget exceeded (%zu bytes)", lds);
-    static size_t attr_set = 0;
+    static idiff_dyn_lds_cache lds_cache;
     auto kern = conv_wino_kernel<MODE, SPEC, RAG>;
-    if (lds > attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = idiff_ensure_dyn_lds(lds_cache, reinterpret_cast<const void*>(kern), lds);
         if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "conv2d(winograd): hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = lds;
     }
     static int num_cu = 0;
     if (num_cu == 0) {

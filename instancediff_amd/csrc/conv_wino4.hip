@@ -355,7 +355,10 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
     const int G = gridDim.x;
     const int first = (int)xcd_remap(blockIdx.x, G);
     const int last = g.total;
-    if (first >= last) return;
+    if (first >= last) {  // no item for this workgroup (the launchers size the grid so that it cannot happen): it still arrives
+        if (a.gn.ticket) idiff_detail::gn_arrive_and_finalize(a, Rb);
+        return;
+    }
     float pre_e = 0.f;
     auto fetch_consts = [&]() {
         if (tid < 256) {
@@ -603,12 +606,11 @@ template <int MODE, int SPEC, bool RAG>
 int launch_rag(const ConvArgs& a, hipStream_t st) {
     const size_t lds = ((size_t)2 * R_FLOATS + 2 * V_FLOATS + 2 * U_FLOATS + 256 + NL * NT) * sizeof(float);
     if (lds > 160 * 1024) IDIFF_FAIL(IDIFF_E_UNSUPPORTED, "conv2d(winograd4): LDS budget exceeded (%zu bytes)", lds);
-    static size_t attr_set = 0;
+    static idiff_dyn_lds_cache lds_cache;
     auto kern = conv_wino4_kernel<MODE, SPEC, RAG>;
-    if (lds > attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = idiff_ensure_dyn_lds(lds_cache, reinterpret_cast<const void*>(kern), lds);
         if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "conv2d(winograd4): hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = lds;
     }
     static int num_cu = 0;
     if (num_cu == 0) {

@@ -320,12 +320,11 @@ template <int MODE, bool PRO>
 int launch(const WwArgs& a, hipStream_t st) {
     const size_t lds = ((size_t)R_FLOATS + 4 * OP_FLOATS + (PRO ? 2 * (size_t)a.C0r : 0)) * sizeof(float);
     if (lds > 160 * 1024) IDIFF_FAIL(IDIFF_E_UNSUPPORTED, "conv2d_wgrad(winograd): LDS budget exceeded (%zu bytes)", lds);
-    static size_t attr_set = 0;
+    static idiff_dyn_lds_cache lds_cache;
     auto kern = wino_wgrad_kernel<MODE, PRO>;
-    if (lds > attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = idiff_ensure_dyn_lds(lds_cache, reinterpret_cast<const void*>(kern), lds);
         if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "conv2d_wgrad(winograd): hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = lds;
     }
     hipLaunchKernelGGL(kern, dim3(a.ncob * a.ncib * a.nsplit), dim3(NT), lds, st, a);
     IDIFF_CHECK_LAUNCH("conv2d_wgrad(winograd)");

@@ -33,9 +33,17 @@ __device__ __forceinline__ void gn_finalize_pair(const ConvArgs& a, int b, int g
     // makes are all in flight at once (agent-scope atomic loads would be issued one round trip at a time)
     const float* sp = a.stats + (long long)b * a.ntiles * C * 2 + (long long)g * cpg * 2;
     const unsigned long long spv = reinterpret_cast<unsigned long long>(sp);
-    const float* sps = reinterpret_cast<const float*>(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(spv >> 32)) << 32) |
-                                                      __builtin_amdgcn_readfirstlane((unsigned)spv));
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sps), 0, 0x7fffffff, 0x00020000);
+    // __builtin_amdgcn_readfirstlane returns a (signed) int: both halves go through `unsigned` before they are widened.  The r03 form
+    // OR-ed the int-typed low half into the 64-bit value directly, which SIGN-extends it -- every partials row whose address has bit
+    // 31 set got 0xffff as the upper 16 bits of its base (s_bfe_i64 / s_or_b64 / s_and_b32 0xffff in the ISA): the intermittent
+    // "Memory access fault by GPU" of the fused tail.
+    const unsigned sp_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)spv);
+    const unsigned sp_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(spv >> 32));
+    const float* sps = reinterpret_cast<const float*>(((unsigned long long)sp_hi << 32) | (unsigned long long)sp_lo);
+    // true extent of what this pair reads: rows 0 .. ntiles-1 of C channels, cpg channels from the group's first (an offset beyond it
+    // fails the range check and reads zero instead of faulting)
+    const int extent = (((a.ntiles - 1) * C) + cpg) * 8;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sps), 0, extent, 0x00020000);
     constexpr int AUX_SC1 = 1 << 4;
     double s = 0.0, q = 0.0;
     const int cl = tid % cpg, tph = tid / cpg, tstep = 256 / cpg;
@@ -81,13 +89,14 @@ __device__ __forceinline__ void gn_finalize_pair(const ConvArgs& a, int b, int g
     __syncthreads();  // wsum is reused by the next pair
 }
 
-// called by every thread of every workgroup once, after the workgroup's last item; scratch: >= 64 bytes of LDS no longer in use
-__device__ __forceinline__ void gn_arrive_and_finalize(const ConvArgs& a, void* scratch) {
+// called by every thread of every workgroup once, after the workgroup's last item (also by a workgroup that had no item);
+// scratch: 80 bytes of LDS no longer in use (two control words, padding, eight doubles), 8-byte aligned
+__device__ __forceinline__ void gn_arrive_and_finalize(const ConvArgs& a, float* scratch) {
     const GnTail& t = a.gn;
     const int tid = threadIdx.x;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial stores have left the CU
     __syncthreads();
-    volatile unsigned* sh = reinterpret_cast<volatile unsigned*>(scratch);
+    unsigned* sh = reinterpret_cast<unsigned*>(scratch);  // plain LDS accesses, ordered by the barriers (volatile made them flat_*)
     if (tid == 0) sh[0] = __hip_atomic_fetch_add(t.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const unsigned mine = sh[0], G = gridDim.x;
@@ -104,7 +113,7 @@ __device__ __forceinline__ void gn_arrive_and_finalize(const ConvArgs& a, void* 
     }
     __syncthreads();
     if (sh[1]) {  // uniform
-        double* wsum = reinterpret_cast<double*>(reinterpret_cast<char*>(scratch) + 16);
+        double* wsum = reinterpret_cast<double*>(scratch + 4);
         for (unsigned p = mine - (G - nfin); p < npairs; p += nfin) gn_finalize_pair(a, (int)(p / (unsigned)t.groups), (int)(p % (unsigned)t.groups), wsum);
     } else if (tid == 0) {
         __hip_atomic_store(t.ticket + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // timeout flag (checked by tests)

@@ -61,9 +61,6 @@ def _c(t, name="tensor", dtype=torch.float32):
 
 # IDIFF_WINOGRAD=0 keeps every 3x3 conv on the direct implicit-GEMM kernel (A/B runs, parity bisection)
 WINOGRAD = bool(int(os.environ.get("IDIFF_WINOGRAD", "1")))
-# IDIFF_WINO4X=1: build the split F(4x4,3x3) weight images too (216 bytes per weight) -- only read by explicit requests for the
-# experimental kernel (CONV_ALGO_WINOGRAD4X)
-WINO4X = bool(int(os.environ.get("IDIFF_WINO4X", "0")))
 # IDIFF_X3=0: no three-plane bf16 images of 1x1 weights are built, so every 1x1 conv stays on the f32 matrix cores
 X3 = bool(int(os.environ.get("IDIFF_X3", "1")))
 # IDIFF_WINOGRAD4=0 keeps the forward 3x3 convs off the F(4x4,3x3) kernel (they run F(2x2,3x3) or direct instead)
@@ -72,7 +69,7 @@ WINOGRAD4 = WINOGRAD and bool(int(os.environ.get("IDIFF_WINOGRAD4", "1")))
 WINOGRAD4_DGRAD = bool(int(os.environ.get("IDIFF_WINOGRAD4_DGRAD", "1")))
 
 
-CONV_ALGO_DIRECT, CONV_ALGO_WINOGRAD, CONV_ALGO_STREAM1X1, CONV_ALGO_WINOGRAD4, CONV_ALGO_WINOGRAD4H, CONV_ALGO_X3, CONV_ALGO_WINOGRAD4X = 0, 1, 2, 3, 4, 5, 6
+CONV_ALGO_DIRECT, CONV_ALGO_WINOGRAD, CONV_ALGO_STREAM1X1, CONV_ALGO_WINOGRAD4, CONV_ALGO_WINOGRAD4H, CONV_ALGO_X3 = 0, 1, 2, 3, 4, 5
 _ALGO_REQUEST = threading.local()
 
 
@@ -108,8 +105,6 @@ def pack_conv_weight(w, transpose=False):
             wino4 = torch.empty((36 * kconv * ((cconv + 63) // 64) * 64,), device=w.device, dtype=torch.float32)
             check(lib.idiff_pack_conv_weight_wino4(_p(w), _p(wino4), co, ci, 1 if transpose else 0, _stream()), "pack_conv_weight_wino4")
             out.wino4 = wino4
-            if WINO4X and not transpose:
-                attach_wino4x(out, w)
     cconv1, kconv1 = (ci, co) if transpose else (co, ci)  # the conv's (Cout, Cin)
     if k == 1 and X3 and cconv1 % 64 == 0 and kconv1 >= 32 and kconv1 % 8 == 0:
         # three-plane bf16 image of a 1x1 weight (idiff_conv_desc.wx3): flattened 1x1 layers then run on the bf16 matrix cores; the
@@ -119,22 +114,6 @@ def pack_conv_weight(w, transpose=False):
         check(lib.idiff_pack_conv1x1_x3(_p(wm), x3.data_ptr(), cconv1, kconv1, _stream()), "pack_conv1x1_x3")
         out.x3 = x3
     return out
-
-
-def attach_wino4x(wpk, w):
-    """builds the three-plane bf16 image of the F(4x4,3x3)-domain weights (idiff_pack_conv_weight_wino4x) and hangs it on the packed
-    weight: conv2d(..., algo=CONV_ALGO_WINOGRAD4X) then runs the experimental split-operand kernel (csrc/conv_wino4x.hip)"""
-    lib = _lib.load()
-    co, ci, k, _ = w.shape
-    assert k == 3
-    img = torch.empty((lib.idiff_conv_wino4x_image_bytes(co, ci) // 2,), device=w.device, dtype=torch.int16)
-    check(lib.idiff_pack_conv_weight_wino4x(_p(_c(w, "weight")), img.data_ptr(), co, ci, 0, _stream()), "pack_conv_weight_wino4x")
-    wpk.wino4x = img
-    return wpk
-
-
-def conv_num_tiles(Hout, Wout):
-    return _lib.load().idiff_conv2d_num_tiles(Hout, Wout)
 
 
 def conv2d(src0, wpk, bias, ks, Cout, src1=None, mode=CONV_NORMAL, pro=None, out=None, res=None, vec=None, aux=None,
@@ -165,9 +144,6 @@ def conv2d(src0, wpk, bias, ks, Cout, src1=None, mode=CONV_NORMAL, pro=None, out
         wino4 = getattr(wpk, "wino4", None)
         if wino4 is not None:
             d.wwino4 = wino4.data_ptr()
-        w4x = getattr(wpk, "wino4x", None)
-        if w4x is not None:
-            d.wwino4x = w4x.data_ptr()
     x3 = getattr(wpk, "x3", None)
     if x3 is not None and ks == 1 and mode in (CONV_NORMAL, CONV_UNSHUFFLE2):
         d.wx3 = x3.data_ptr()
@@ -198,13 +174,19 @@ def conv2d(src0, wpk, bias, ks, Cout, src1=None, mode=CONV_NORMAL, pro=None, out
         d.aux, d.aux_bstride = t.data_ptr(), _bs(t, "aux")
         d.aux_a, d.aux_b = _c(a, "aux_a").data_ptr(), _c(b, "aux_b").data_ptr()
     stats = None
+    bufs = gn.get("bufs") if gn is not None else None  # caller-placed (stats, out_a, out_b[, mean_rstd]): the guard-band tests
     if want_stats or gn is not None:
         nt = lib.idiff_conv2d_num_tiles(Hout, Wout)
-        stats = torch.empty((B, nt, Cout, 2), device=src0.device, dtype=torch.float32)
+        stats = bufs[0] if bufs is not None else torch.empty((B, nt, Cout, 2), device=src0.device, dtype=torch.float32)
+        assert tuple(stats.shape) == (B, nt, Cout, 2) and stats.is_contiguous() and stats.dtype == torch.float32
         d.stats = stats.data_ptr()
     gn_out = None
     if gn is not None:
-        ga, gb = torch.empty((B, Cout), device=src0.device, dtype=torch.float32), torch.empty((B, Cout), device=src0.device, dtype=torch.float32)
+        if bufs is not None:
+            ga, gb = bufs[1], bufs[2]
+            assert tuple(ga.shape) == (B, Cout) == tuple(gb.shape) and ga.is_contiguous() and gb.is_contiguous()
+        else:
+            ga, gb = torch.empty((B, Cout), device=src0.device, dtype=torch.float32), torch.empty((B, Cout), device=src0.device, dtype=torch.float32)
         d.gn_groups, d.gn_eps = int(gn["groups"]), float(gn.get("eps", 1e-5))
         d.gn_gamma, d.gn_beta = _c(gn["gamma"], "gn gamma").data_ptr(), _c(gn["beta"], "gn beta").data_ptr()
         film = gn.get("film")
@@ -215,7 +197,8 @@ def conv2d(src0, wpk, bias, ks, Cout, src1=None, mode=CONV_NORMAL, pro=None, out
         d.gn_out_a, d.gn_out_b = ga.data_ptr(), gb.data_ptr()
         gn_out = (ga, gb)
         if gn.get("want_mean_rstd"):
-            mr = torch.empty((B, d.gn_groups, 2), device=src0.device, dtype=torch.float32)
+            mr = bufs[3] if bufs is not None else torch.empty((B, d.gn_groups, 2), device=src0.device, dtype=torch.float32)
+            assert tuple(mr.shape) == (B, d.gn_groups, 2) and mr.is_contiguous()
             d.gn_mean_rstd = mr.data_ptr()
             gn_out = (ga, gb, mr)
         tk = gn.get("ticket")

@@ -242,14 +242,16 @@ class SmmXattnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, qf, mem, scale, shared=None):
-        """shared: a dict common to the calls that attend to the SAME `mem` (the decoder layers of one ScoreMapModule), with
-        shared["uses"] = their number.  Their memory gradients are then summed inside the backward kernel, in backward order, into
+        """shared: a dict common to the calls that attend to the SAME `mem` (the decoder layers of one ScoreMapModule), created per
+        forward pass; it counts the calls ("pending").  Their memory gradients are then summed inside the backward kernel, in backward order, into
         one buffer that the last of them to run hands to autograd (the others return None): no [B,256,N] adds between them."""
         lib = _lib.load()
         qf, mem = qf.contiguous(), mem.contiguous()
         _c(qf), _c(mem)
         ctx.shared = shared
         if shared is not None:
+            if shared.get("pending", 0) == 0 and shared.get("buf") is not None:
+                raise RuntimeError("SmmXattnFn: a shared memory-gradient buffer is still held from an unfinished backward")
             shared["pending"] = shared.get("pending", 0) + 1
         B, R, Cm = qf.shape
         N = mem.shape[2]
@@ -279,6 +281,12 @@ class SmmXattnFn(torch.autograd.Function):
             dmem = sh["buf"] if acc else torch.empty_like(mem)
             sh["buf"] = dmem
             sh["pending"] -= 1
+            # single use: one backward per forward (a second backward over a retained graph would hand the summed buffer out
+            # again, or never) -- enforced, not assumed
+            if sh["pending"] < 0:
+                sh["pending"], sh["buf"] = 0, None
+                raise RuntimeError("SmmXattnFn: more backward than forward calls on a shared memory gradient (retain_graph / double "
+                                   "backward is not supported by the shared-gradient form; pass shared=None)")
         ws = torch.empty((lib.idiff_smm_xattn_ws_floats(B, R, 1, 256, N),), device=qf.device, dtype=torch.float32)
         check(lib.idiff_smm_xattn_bwd(_p(qf), _p(mem), _p(o), _p(lse), _p(d_o), _p(dqf), _p(dmem), acc, _p(ws), B, R, N, ctx.scale, _stream()),
               "smm_xattn_bwd")

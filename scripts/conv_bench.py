@@ -61,8 +61,6 @@ def main():
         cin = (C0 * 4 if mode == 2 else C0) + C1
         wraw = torch.randn(Co, cin, ks, ks, device=dev) / (cin * ks * ks) ** 0.5
         w = ops.pack_conv_weight(wraw)
-        if ks == 3 and "6" in args.algos.split(",") and Co % 16 == 0 and cin % 8 == 0:
-            ops.attach_wino4x(w, wraw)  # split F(4x4,3x3) image for the experimental kernel (algo 6)
         b = torch.randn(Co, device=dev)
         p = (torch.rand(B, C0, device=dev) + 0.5, torch.randn(B, C0, device=dev) * 0.1) if pro else None
         Ho = H * 2 if mode == 1 else (H // 2 if mode == 2 else H)

@@ -1,3 +1,8 @@
+// ARCHIVED PROTOTYPE (moved out of instancediff_amd/csrc in round 4: not compiled into libidiff_hip.so, not declared in include/idiff.h,
+// not tested).  It was wired behind idiff_conv_desc.algo_request = 1 + 6 with a `wwino4x` weight-image field and
+// idiff_pack_conv_weight_wino4x / idiff_conv_wino4x_image_bytes entry points (git history: commit 95dbc1d .. f02b7f7); it lost to the
+// f32 kernels on every layer measured and DESIGN.md section 8.1 bounds it at ~1.0-1.3x.  Kept for its measured notes only.
+//
 // Winograd F(4x4,3x3) convolution on the bf16 matrix cores with fp32 operands split three ways (gfx950, v_mfma_f32_16x16x32_bf16).
 // EXPERIMENTAL (round 3): complete (every gather / prologue / epilogue form of conv_wino4.hip, partial patches) and parity-green behind
 // idiff_conv_desc.algo_request = 1 + IDIFF_CONV_ALGO_WINOGRAD4X; never the library's own choice -- it does not beat conv_wino4.hip

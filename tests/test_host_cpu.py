@@ -355,6 +355,18 @@ def test_reference_era_state_file_resumes_through_the_model_entry_point(tmp_path
     with pytest.raises(RuntimeError):
         model.load_training_state(str(evil))
     assert model.load_training_state(str(evil), trusted=True)["iter"] == 9
+    # a legacy-format (non-zip) file that is ONE pickle whose __reduce__ names a foreign callable: torch's legacy loader reads its
+    # header with pickle_module.load(f), which must be the allow-listing unpickler too -- the callable is never called
+    marker = tmp_path / "called"
+
+    class Boom:
+        def __reduce__(self):
+            return (os.mkdir, (str(marker),))
+    legacy = tmp_path / "7.state"
+    legacy.write_bytes(pickle.dumps(Boom(), protocol=2))
+    with pytest.raises((RuntimeError, pickle.UnpicklingError)):
+        model.load_training_state(str(legacy))
+    assert not marker.exists()
 
 
 def test_bench_spawns_one_rank_per_gpu_with_the_rendezvous_environment(tmp_path):

@@ -495,42 +495,6 @@ def test_conv_winograd4_matches_direct_and_fp64(force_wino4, B, C0, C1, Cout, H,
     _check_wino4_case(force_wino4, B, C0, C1, Cout, H, W, variant)
 
 
-W4X_CASES = [
-    (2, 64, 0, 64, 32, 32, "plain"), (1, 8, 0, 128, 16, 64, "plain"), (2, 64, 0, 64, 16, 96, "prologue"), (1, 24, 40, 192, 32, 32, "concat"),
-    (2, 32, 0, 64, 16, 16, "upsample"), (1, 128, 0, 256, 64, 64, "epilogue"), (2, 32, 0, 80, 16, 32, "plain"), (1, 64, 0, 144, 16, 32, "epilogue"),
-    (2, 32, 0, 64, 28, 56, "plain"), (1, 64, 0, 64, 8, 112, "prologue"), (1, 24, 16, 64, 20, 40, "concat"), (2, 32, 0, 64, 28, 28, "epilogue"),
-    (21, 8, 0, 64, 64, 64, "epilogue"), (17, 40, 0, 64, 64, 96, "plain"),
-]
-
-
-W4X_CHILD = os.environ.get("IDIFF_TEST_WINO4X") == "1"
-
-
-def test_conv_winograd4x_cases_in_a_process_of_their_own():
-    """The experimental split-operand F(4x4,3x3) kernel is exercised in a child process: a process that has run it aborts (SIGABRT from
-    the runtime, no message) when it later runs the opt-in fused-GroupNorm-tail launches of conv_wino4*.hip unless kernels are
-    serialised (AMD_SERIALIZE_KERNEL=3) -- open issue; neither path is a default.  The child runs the
-    parametrised cases below (IDIFF_TEST_WINO4X=1) and must report them all passed."""
-    import subprocess
-    import sys
-    env = dict(os.environ, IDIFF_TEST_WINO4X="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "winograd4x_split_operand", "-p", "no:cacheprovider"],
-                       env=env, capture_output=True, text=True, timeout=600)
-    tail = (r.stdout + r.stderr)[-1500:]
-    assert r.returncode == 0 and f"{len(W4X_CASES)} passed" in r.stdout, tail
-
-
-@pytest.mark.skipif(not W4X_CHILD, reason="run by test_conv_winograd4x_cases_in_a_process_of_their_own (IDIFF_TEST_WINO4X=1)")
-@pytest.mark.parametrize("B,C0,C1,Cout,H,W,variant", W4X_CASES)
-def test_conv_winograd4x_split_operand_kernel_matches_direct_and_fp64(B, C0, C1, Cout, H, W, variant):
-    """csrc/conv_wino4x.hip (experimental, by request only): F(4x4,3x3) on the bf16 matrix cores, operands split three ways, 16
-    channels x two planes per matrix instruction -- the same cases and tolerances as the f32 F(4x4,3x3) kernels"""
-    with ops.request_conv3x3_algo(ops.CONV_ALGO_WINOGRAD4X):
-        lib = ops._lib.load()
-        lib.expected_algo = ops.CONV_ALGO_WINOGRAD4X
-        _check_wino4_case(lib, B, C0, C1, Cout, H, W, variant)
-
-
 def _check_wino4_case(lib, B, C0, C1, Cout, H, W, variant):
     g = _g(21)
     Cin = C0 + C1
@@ -562,8 +526,7 @@ def _check_wino4_case(lib, B, C0, C1, Cout, H, W, variant):
     wd = w.to(DEV)
 
     def pk():
-        p = _pack(wd, True, wino4=True)
-        return ops.attach_wino4x(p, wd) if lib.expected_algo == ops.CONV_ALGO_WINOGRAD4X else p
+        return _pack(wd, True, wino4=True)
     out_w, st_w = ops.conv2d(x0.to(DEV), pk(), b.to(DEV), 3, Cout, want_stats=True, **kw)
     assert lib.idiff_conv2d_last_algo() == lib.expected_algo, "the requested F(4x4,3x3) kernel did not run"
     out_d, st_d = ops.conv2d(x0.to(DEV), _pack(wd, False), b.to(DEV), 3, Cout, want_stats=True, algo=ops.CONV_ALGO_DIRECT, **kw)
@@ -689,11 +652,9 @@ def test_conv_winograd4_bits_do_not_depend_on_the_batch(force_wino4):
 ])
 def test_conv_groupnorm_finalize_fused_equals_separate_launch(B, C0, C1, Cout, H, W, G, film, pro, algo):
     """idiff_conv_desc.gn_*: the GroupNorm(+FiLM) finalize riding on the conv call gives the SAME BITS as idiff_gn_finalize on the conv's
-    statistics, launch after launch, with and without a ticket.  With IDIFF_GN_FUSED=1 in the environment a ticket selects the
-    experimental fused tail (last-arriving workgroups reduce the partials, gn_tail.h; the arrival counters clean themselves);
-    without it -- the default, and what the round's test tier runs -- the library ignores the ticket (an intermittent GPU memory
-    fault of the fused tail in a cold process is an open issue: scripts/abort_repro.py) and enqueues the
-    finalize launch: the assertions are the same either way."""
+    statistics, launch after launch, with and without a ticket.  A ticket selects the fused tail of the F(4x4,3x3) kernels (the
+    last-arriving workgroups reduce the partials, gn_tail.h; the arrival counters clean themselves); kernels without the tail, and
+    calls without a ticket, get the finalize launch enqueued by the library: the assertions are the same either way."""
     lib = ops._lib.load()
     g = _g(500 + B + Cout)
     x0 = torch.randn(B, C0, H, W, generator=g).to(DEV)
@@ -720,6 +681,70 @@ def test_conv_groupnorm_finalize_fused_equals_separate_launch(B, C0, C1, Cout, H
     out, (a, b) = ops.conv2d(x0, wp, bias, 3, Cout, gn=dict(groups=G, gamma=gamma, beta=beta, film=fl, eps=1e-5), **kw)   # no ticket
     assert torch.equal(a, a_ref) and torch.equal(b, b_ref)
     print(f"conv algo {algo}: fused finalize == separate launch (bitwise), B={B} Cout={Cout} {H}x{W}")
+
+
+@pytest.mark.parametrize("algo", [None, 3])
+def test_conv_groupnorm_fused_tail_addresses_with_bit31_set_and_guard_bands(algo):
+    """The r03 abort of the fused tail, pinned.  gn_tail.h rebuilt the partials row address for a buffer resource as
+    (u64)readfirstlane(hi) << 32 | readfirstlane(lo) with the builtin's int result, which sign-extends the low half: any row address
+    with bit 31 set got 0xffff in its upper 16 bits -> "Memory access fault by GPU", or not, by where the caching allocator happened
+    to put `stats`.  Here every buffer the tail touches is placed by the test inside one 4-GiB-plus arena, once
+    with bit 31 of the statistics address clear and once with it set, between guard bands holding a canary: results must equal the
+    separate finalize launch bit for bit and no canary may change."""
+    lib = ops._lib.load()
+    B, C0, Cout, H, W, G = 16, 64, 64, 64, 64, 8
+    g = _g(77)
+    x0 = torch.randn(B, C0, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cout, C0, 3, 3, generator=g) / math.sqrt(9 * C0)).to(DEV)
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    gamma, beta = torch.randn(Cout, generator=g).to(DEV), torch.randn(Cout, generator=g).to(DEV)
+    wp = ops.pack_conv_weight(w)
+    nt = lib.idiff_conv2d_num_tiles(H, W)
+    arena = torch.empty((1 << 32) + (64 << 20), dtype=torch.uint8, device=DEV)
+    base = arena.data_ptr()
+    GUARD = 4096
+    CANARY = 0x5A
+
+    def place(off, shape, dtype=torch.float32):
+        n = int(torch.tensor(shape).prod()) * 4
+        t = arena[off:off + n].view(dtype).view(shape)
+        return t, off + n + GUARD
+
+    for want_bit31 in (False, True):
+        # first 1-MiB-aligned offset whose address has bit 31 as wanted and 16 MiB of room inside the same 2-GiB stripe
+        off = 1 << 20
+        while ((((base + off) >> 31) & 1) == 1) != want_bit31 or ((((base + off + (16 << 20)) >> 31) & 1) == 1) != want_bit31:
+            off += 1 << 20
+        start = off - GUARD
+        stats, off = place(off, (B, nt, Cout, 2))
+        ga, off = place(off, (B, Cout))
+        gb, off = place(off, (B, Cout))
+        mr, off = place(off, (B, G, 2))
+        film_full, off = place(off, (B, 2 * Cout + 8))
+        ticket, off = place(off, (4,), torch.int32)
+        end = off
+        assert ((stats.data_ptr() >> 31) & 1) == int(want_bit31)
+        arena[start:end].fill_(CANARY)
+        film_full.copy_((torch.randn(B, 2 * Cout + 8, generator=g) * 0.3).to(DEV))
+        fl = film_full[:, :2 * Cout]   # row-strided, as the UNet's films are
+        ticket.zero_()
+        out_ref, st = ops.conv2d(x0, wp, bias, 3, Cout, want_stats=True, algo=algo)
+        a_ref, b_ref, mr_ref = ops.gn_finalize(st, G, H * W, gamma, beta, film=fl, eps=1e-5, want_mean_rstd=True)
+        for rep in range(2):
+            out, (a, b, m) = ops.conv2d(x0, wp, bias, 3, Cout, algo=algo,
+                                        gn=dict(groups=G, gamma=gamma, beta=beta, film=fl, eps=1e-5, ticket=ticket, want_mean_rstd=True,
+                                                bufs=(stats, ga, gb, mr)))
+            assert lib.idiff_conv2d_last_algo() in (ops.CONV_ALGO_WINOGRAD4, ops.CONV_ALGO_WINOGRAD4H)
+            assert torch.equal(out, out_ref) and torch.equal(stats, st)
+            assert torch.equal(a, a_ref) and torch.equal(b, b_ref) and torch.equal(m, mr_ref), (want_bit31, rep)
+            assert ticket.tolist() == [0, 0, 0, 0], (want_bit31, rep, ticket.tolist())
+        # guard bands: everything between the placed tensors still holds the canary
+        mask = torch.ones(end - start, dtype=torch.bool, device=DEV)
+        for t in (stats, ga, gb, mr, film_full, ticket):
+            o = t.data_ptr() - base - start
+            mask[o:o + t.numel() * 4] = False
+        assert bool((arena[start:end][mask] == CANARY).all()), ("guard band overwritten", want_bit31)
+        print(f"fused tail, stats at {stats.data_ptr():#x} (bit 31 {'set' if want_bit31 else 'clear'}): bitwise equal, guard bands intact")
 
 
 # ---- 1x1 conv on the bf16 matrix cores, fp32 operands split three ways (csrc/conv1x1_x3.hip) ------------------------------------------
