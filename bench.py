@@ -57,6 +57,7 @@ def parse():
                     "is estimated to fit --cpu-budget-s, else 4)")
     ap.add_argument("--cpu-budget-s", type=float, default=140.0, help="time budget of the CPU-baseline leg (warm + timed steps)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the `train` key of the default line (BASELINE c3 at N=1, ~40 s)")
     ap.add_argument("--attn", choices=["f32", "bf16", "f16"], default="f32", help="bf16 / f16 = REDUCED-PRECISION VARIANT line (self-attention "
                     "contractions on the bf16 / fp16 matrix cores; f16 with operands clamped to +-255 is the reference's own form, BASELINE "
                     "config c5): own metric label, PSNR delta vs the fp32 path stated")
@@ -258,6 +259,8 @@ def pmc_evidence(kernel):
         if mine:
             n = sum(k["launches_per_step"] for k in mine)
             out["traffic"] = int(sum(k["hbm_bytes_per_launch"] * k["launches_per_step"] for k in mine) / n)
+            # the profile's own clock for the same kernel (rocprofv3 kernel trace), next to this run's HIP-event avg_launch_ms
+            out["profile_avg_launch_ms"] = round(sum(k["avg_us"] * k["launches_per_step"] for k in mine) / n / 1e3, 4)
             out["traffic_GBps"] = round(sum(k["hbm_bytes_per_launch"] * k["launches_per_step"] for k in mine) /
                                         sum(k["avg_us"] * 1e3 * k["launches_per_step"] for k in mine), 1)
         else:
@@ -268,6 +271,8 @@ def pmc_evidence(kernel):
                                "share_of_step_kernel_time": k["share_of_step_kernel_time"], "bytes_per_launch": k["hbm_bytes_per_launch"],
                                "achieved": k["achieved_GBps"], "peak": k["peak_GBps"], "unit": "GB/s", "frac": k["frac"]}
                               for k in doc["kernels"] if "frac" in k and not k["kernel"].startswith("conv_wino") and k["share_of_step_kernel_time"] >= 0.02]
+        if doc.get("mfma_util"):  # SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), separate --pmc pass (scripts/pmc_kernel.sh)
+            out["mfma_util_measured"] = doc["mfma_util"]
         out["step_hbm_bytes"] = doc.get("step_hbm_bytes")
         out["step_hbm_GBps_over_kernel_time"] = doc.get("step_hbm_GBps_over_kernel_time")
         return out
@@ -306,9 +311,9 @@ def log(msg):
 _T0 = time.time()
 
 
-def train_bench(args, world, rank, dev):
-    """Secondary line (BASELINE config c3): training iterations/sec of CLIPDriftModel.optimize_parameters --
-    feed_data (forward diffusion) + 2 UNet forwards + losses + backward + flat RCCL all-reduce + fused Adam."""
+def train_measure(args, world, rank, dev, batch_size, steps, warmup):
+    """feed_data (forward diffusion) + 2 UNet forwards + losses + backward + flat RCCL all-reduce + fused Adam, `steps` timed
+    iterations after `warmup`; returns (seconds, last loss) -- max over ranks."""
     import torch.distributed as dist
     from instancediff_amd import pipeline
     from instancediff_amd.utils.synthetic import make_batch
@@ -316,7 +321,7 @@ def train_bench(args, world, rank, dev):
     model, sde = pipeline.build(phase="train", device=dev, T=T, seed=0, dist=world > 1)
     model.set_train()
     sde.set_seed(1234 + rank)
-    batch = make_batch(args.batch, args.size, seed=1234 + rank, mixed=True)
+    batch = make_batch(batch_size, args.size, seed=1234 + rank, mixed=True)
     torch.manual_seed(99 + rank)
 
     def it():
@@ -330,11 +335,11 @@ def train_bench(args, world, rank, dev):
         torch.cuda.synchronize()
 
     log("train: model built; warmup")
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         loss = it()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = it()
     barrier()
     el = time.perf_counter() - t0
@@ -342,6 +347,13 @@ def train_bench(args, world, rank, dev):
         tmax = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         el = float(tmax.item())
+    return el, loss, float(getattr(model, "score_map_dropout", 0.1))
+
+
+def train_bench(args, world, rank, dev):
+    """Secondary line (BASELINE config c3): training iterations/sec of CLIPDriftModel.optimize_parameters."""
+    import torch.distributed as dist
+    el, loss, _ = train_measure(args, world, rank, dev, args.batch, args.steps, args.warmup)
     if rank == 0:
         value = world * args.steps / el
         label = "training iterations/sec (%dx%d bs%d/GPU)" % (args.size, args.size, args.batch)
@@ -357,6 +369,60 @@ def train_bench(args, world, rank, dev):
                                      "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def train_leg(args, dev):
+    """The BASELINE c3 workload as an extra key of the default line (N = 1): 256x256, batch 32, fp32, decoder dropout 0.1, a few timed
+    iterations after the headline measurement (same process, the sampling model already freed by the caller)."""
+    steps, warmup, bs = 6, 2, 32
+    t0 = time.time()
+    el, loss, p_drop = train_measure(args, 1, 0, dev, bs, steps, warmup)
+    return {"it_per_s": round(steps / el, 4), "ms_per_step": round(el / steps * 1e3, 2), "batch": bs, "dropout": p_drop, "steps": steps,
+            "warmup": warmup, "dtype": "f32", "last_loss": loss, "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+            "workload": "%dx%d synthetic, batch %d, drift+noise UNet fwd/bwd, pyramid losses, 2 fused Adam steps (BASELINE c3 at N=1, fp32)"
+                        % (args.size, args.size, bs), "leg_seconds": round(time.time() - t0, 1)}
+
+
+def train_dryrun(args, world, rank):
+    """IDIFF_BENCH_DRYRUN=1 on a box WITHOUT a GPU (tests/test_host_cpu.py): what `bench.py --gpus N --mode train` does around the HIP
+    compute -- rendezvous from the launcher's environment (gloo), train-phase model build with its GradSync, rank-0 parameter
+    broadcast, one start()/finish() exchange of the optimizers' flat gradient buffers in the train step's order -- with rank-valued
+    stand-in gradients.  No forward / backward runs (there is no CPU fallback for it) and no rate is reported."""
+    import torch.distributed as dist
+    from instancediff_amd import pipeline
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    os.environ["IDIFF_GRAD_WIRE"] = args.grad_wire
+    torch.manual_seed(1000 + rank)  # ranks start from DIFFERENT weights: the broadcast must make them equal
+    model, _ = pipeline.build(phase="train", device=torch.device("cpu"), T=4, seed=1000 + rank, dist=world > 1)
+    sync = model.grad_sync
+    assert (sync is not None and sync.active and sync.world == world) if world > 1 else sync is None
+    first = next(model.drift_net.parameters()).detach().reshape(-1)[:8].clone()
+    ok = True
+    scale = 1.0
+    if world > 1:
+        got = [torch.empty_like(first) for _ in range(world)]
+        dist.all_gather(got, first)
+        ok = all(torch.equal(g, got[0]) for g in got)
+        for opt in (model.drift_optimizer, model.noise_optimizer):  # the train step's order: drift first, then noise, one finish()
+            for f in opt.flat_grads():
+                f.fill_(float(rank + 1))
+            sync.start(opt.flat_grads())
+        scale = sync.finish()
+        want = float(world * (world + 1) // 2)
+        ok = ok and all(bool((f == want).all()) for opt in (model.drift_optimizer, model.noise_optimizer) for f in opt.flat_grads())
+        ok = ok and abs(scale - 1.0 / world) < 1e-12
+        dist.barrier()
+    if rank == 0:
+        nparam = sum(f.numel() for opt in (model.drift_optimizer, model.noise_optimizer) for f in opt.flat_grads())
+        print(json.dumps({"metric": "training iterations/sec (%dx%d bs%d/GPU)" % (args.size, args.size, args.batch), "value": None,
+                          "dryrun": "no GPU: rendezvous + model build + parameter broadcast + flat gradient all-reduce only",
+                          "n_gpus": world, "grad_wire": args.grad_wire, "grad_sync_ok": ok, "flat_gradient_floats": nparam,
+                          "scale": scale}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
 
 
 def irsde_bench(args, world, rank, dev):
@@ -429,6 +495,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
+        if os.environ.get("IDIFF_BENCH_DRYRUN") == "1" and args.mode == "train":
+            return train_dryrun(args, world, rank)  # CPU test hook: everything of the N>1 train line EXCEPT the HIP compute
         print("bench.py needs a GPU: the hot path has no CPU fallback", file=sys.stderr)
         sys.exit(2)
     # IDIFF_BENCH_REHEARSAL=1: several ranks share the one GPU of a development box over gloo -- exercises the N>1 code path
@@ -493,6 +561,7 @@ def main():
 
     roof = None
     launches_per_step = None
+    graph_mode = run.stepper.mode == "graph"
     if rank == 0 and not args.no_roofline:
         # second pass over the same K steps, on ONE stream (the timed region overlaps the two nets on two streams, which
         # would smear per-launch event times), every conv launch bracketed by HIP events on its launch stream
@@ -562,6 +631,22 @@ def main():
                 cpu = cpu_baseline(args, batch)
             except Exception as e:  # the baseline is a reported side measurement; never hide the GPU result
                 cpu = {"error": repr(e)}
+        elif world > 1:
+            cpu = "N=1 line only"
+        train = None
+        default_workload = args.size == 256 and args.batch == 16 and variant is None
+        if world > 1:
+            train = "N=1 line only (bench.py --gpus N --mode train is the multi-GPU training line)"
+        elif args.no_train_leg or not default_workload:
+            train = "skipped (%s)" % ("--no-train-leg" if args.no_train_leg else "not the default 256x256 batch-16 fp32 line")
+        else:
+            log("train leg (BASELINE c3 at N=1) ...")
+            try:
+                del run
+                torch.cuda.empty_cache()
+                train = train_leg(args, dev)
+            except Exception as e:  # a reported side measurement; never hide the headline
+                train = {"error": repr(e)}
         value = world * args.steps / el
         label = "denoising steps/sec (%dx%d bs%d)" % (args.size, args.size, args.batch)
         if variant is not None:
@@ -569,14 +654,19 @@ def main():
         line = {"metric": label, "value": round(value, 4),
                 "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32" if variant is None else "f32 + %s attention" % args.attn, "data": "synthetic", "graph": run.stepper.mode == "graph",
+                "dtype": "f32" if variant is None else "f32 + %s attention" % args.attn, "data": "synthetic", "graph": graph_mode,
+                "arithmetic": {"conv3x3": "f32 MFMA (v_mfma_f32_16x16x4_f32), Winograd F(4x4,3x3); F(2x2,3x3) / direct form on the shapes it does not tile",
+                               "conv1x1": "bf16x3 split of fp32 operands, 6 bf16 MFMAs (v_mfma_f32_16x16x32_bf16) per product, fp32 accumulate: "
+                                          "fp32-class result (2e-6 vs fp64, tests/test_ops_gpu.py); f32 MFMA where the pixels do not tile by 256",
+                               "attention": "f32 MFMA" if variant is None else "%s MFMA self-attention (operands clamped to +-255 for f16), fp32 softmax" % args.attn,
+                               "groupnorm_statistics": "fp32 partials, fp64 fixed-order reduce", "sde_update": "f32 (one rounding per op)"},
                 "two_streams": bool(sde.two_streams), "variant": variant,
                 "launches_per_step": launches_per_step,
                 "config": {"workload": "%dx%d 1-ch synthetic, %d-step reverse chain, batch %d per GPU, 2 UNet fwd + reverse update per step"
                                        % (args.size, args.size, args.T, args.batch),
                            "global_batch": args.batch * world, "parallelism": "replicas x%d (no collective)" % world,
                            "image_steps_per_s": round(value * args.batch, 2)},
-                "roofline": roof, "cpu_baseline": cpu}
+                "roofline": roof, "cpu_baseline": cpu, "train": train}
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

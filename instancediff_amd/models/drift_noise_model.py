@@ -95,6 +95,7 @@ class CLIPDriftModel():
             p.requires_grad_(False)
         self.text_encoder = text_encoder.to(self.device)
         self.token_embed_dim = token_embed_dim
+        self.score_map_dropout = float(score_map_dropout)
 
         def prompts(settings):
             if settings.get('text_module') != 'scoremap':

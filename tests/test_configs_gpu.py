@@ -95,6 +95,17 @@ def test_c5_512_chain_vs_oracle_and_batch8_invariance():
     assert torch.equal(out8[7:], out_last)
     ref1 = _oracle_chain(model, T, _slice(b8, 1), x_T[:1], noises[:, :1])
     _check_vs_oracle(out1, ref1, b8['target'][:1], "c5 512x512")
+    # BASELINE c5 names "fp16 MFMA attention": the same chain with the mid self-attention (N = 4096 tokens) on the fp16 matrix cores,
+    # operands clamped to +-255 -- the reference's own half-precision form (Attention_flash, models/_modified_BiomedCLIP.py:509-513)
+    # -- against the SAME fp32 oracle chain and the same 1e-3 dB bar
+    ops.ATTN_DTYPE = "f16"
+    try:
+        out1_h = _chain(model, _slice(b8, 1), x_T[:1], noises[:, :1].contiguous())
+    finally:
+        ops.ATTN_DTYPE = "f32"
+    assert not torch.equal(out1_h, out1), "the fp16 attention kernel did not run"
+    _check_vs_oracle(out1_h, ref1, b8['target'][:1], "c5 512x512, fp16 MFMA self-attention")
+    print(f"c5 fp16 attention vs fp32 path: max|diff| {float((out1_h - out1).abs().max()):.3e}")
 
 
 def test_c5_self_attention_4096_tokens_vs_fp64():

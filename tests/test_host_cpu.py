@@ -394,3 +394,21 @@ def test_bench_spawns_one_rank_per_gpu_with_the_rendezvous_environment(tmp_path)
                        capture_output=True, text=True, timeout=600)
     if not torch.cuda.is_available():
         assert r.returncode == 2 and r.stderr.count("needs a GPU") >= 1 and "rank" in r.stderr
+
+
+def test_bench_train_mode_reaches_the_gradient_exchange_at_world_2(tmp_path):
+    """`python bench.py --gpus 2 --mode train --grad-wire bf16` (BASELINE c3, the only configuration with a collective; reference
+    launch README.md:35, trainUM.py:50-66) through spawn_ranks: both ranks rendezvous, build the train-phase model with its GradSync,
+    take rank 0's weights and exchange the flat gradient buffers -- everything around the HIP compute, which needs a GPU
+    (IDIFF_BENCH_DRYRUN=1 runs exactly that much and says so in its line)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(IDIFF_BENCH_DRYRUN="1", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "train", "--grad-wire", "bf16", "--steps", "1",
+                        "--warmup", "0"], env=env, capture_output=True, text=True, timeout=900)
+    if torch.cuda.is_available():
+        pytest.skip("dry run is the no-GPU hook; on a GPU box the rehearsal (IDIFF_BENCH_REHEARSAL=1) runs the real step")
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["grad_sync_ok"] is True and line["grad_wire"] == "bf16" and line["scale"] == 0.5
+    assert line["flat_gradient_floats"] > 60e6 and "dryrun" in line   # both nets' parameters in the flat buffers
