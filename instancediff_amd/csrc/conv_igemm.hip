@@ -734,10 +734,13 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
     const long long items16 = (req == -1 || req4 || req4h) ? idiff_detail::conv_wino4_items(a, d->ks, d->mode, req4 || req4h) : 0;
     if (items16 > 0) {
         const long long items8 = (long long)a.ntiles * a.ncob;
+        // the 16x32 kernel streams its requests four chunks ahead, into the next item: an item has at least four chunks there
+        const bool w4_ok = a.Cin >= 16;
+        IDIFF_CHECK_ARG(!(hard && req4) || w4_ok, "conv2d: algo_request F(4x4,3x3) 16x32-item kernel needs Cin >= 16 (got %d)", a.Cin);
         bool half;
         if (req4h) half = true;
-        else if (req4) half = false;
-        else if (items16 >= 16) half = w4h_mode == 2 || (w4h_mode == 1 && a.src1 != nullptr);
+        else if (req4 && w4_ok) half = false;
+        else if (items16 >= 16 && w4_ok) half = w4h_mode == 2 || (w4h_mode == 1 && a.src1 != nullptr);
         else half = w4h_mode >= 1 && items8 >= 16;
         // The GroupNorm finalize as the tail of the conv launch (gn_tail.h) is opt-in per call: the caller passes a ticket buffer.
         const bool fuse = want_gn && d->gn_ticket != nullptr;
@@ -752,7 +755,7 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
             const int rc = idiff_detail::launch_conv_wino4h(a, d->mode, st);
             return fuse ? rc : finalize_after(rc);
         }
-        if (req4 || items16 >= 16) {
+        if (w4_ok && (req4 || items16 >= 16)) {
             g_last_algo = IDIFF_CONV_ALGO_WINOGRAD4;
             const int rc = idiff_detail::launch_conv_wino4(a, d->mode, st);
             return fuse ? rc : finalize_after(rc);

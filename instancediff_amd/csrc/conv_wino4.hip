@@ -45,7 +45,6 @@ constexpr int NL = 6;           // gathered elements per thread per chunk (eleme
 constexpr int R_FLOATS = NL * NT;
 constexpr int V_FLOATS = 9 * 2 * 64 * 4;   // 4608
 constexpr int U_FLOATS = 9 * 4 * 64 * 4;   // 9216
-constexpr int NU = 5;                      // float4 of weights per thread per chunk (2304 in all: the fifth only for tid < 256)
 
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 
@@ -79,9 +78,10 @@ __device__ __forceinline__ float row_sum16(float v) {
 #ifdef IDIFF_WINO_TRACE
 #define TRACE_PARAM , long long* trace
 #define TRACE_INIT long long tr_t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define TRACE_MARK(k)                       \
-    tr_t[k] = __builtin_readcyclecounter(); \
-    if (k > 0) tr_acc[k - 1] += tr_t[k] - tr_t[k - 1];
+#define TRACE_MARK(k)                                                  \
+    tr_t[k] = __builtin_readcyclecounter();                            \
+    if (k > 0) tr_acc[k - 1] += tr_t[k] - tr_t[k - 1];                 \
+    else if (tr_t[3] != 0) tr_acc[3] += tr_t[0] - tr_t[3];
 #define TRACE_FINI                                                                                                      \
     if (tid == 0) {                                                                                                     \
         for (int q_ = 0; q_ < 8; ++q_) atomicAdd((unsigned long long*)trace + q_, (unsigned long long)tr_acc[q_]);      \
@@ -146,14 +146,34 @@ __device__ __forceinline__ void at6(const float x0, const float x1, const float 
 
 // SPEC: 1 = single source, no prologue; 2 = single source + GN/FiLM/SiLU prologue; 3 = two sources (virtual concat)
 // RAG: the image is not a multiple of the 16x32 patch (partial patches at the right / bottom border are masked)
-template <int MODE, int SPEC, bool RAG>
-__global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const Geo4 g TRACE_PARAM) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const Rb = smem;                   // [2][R_FLOATS]
-    float* const Vb = smem + 2 * R_FLOATS;    // [2][V_FLOATS]
+// HEAVY: the wave's transform class (waves 0-3 / 4-7).  The whole body -- thread constants, fill, item loop, epilogue -- exists once
+// per class: constants of the other class are never live.
+//
+// Round 4 form.  (1) EVERY global load of the main loop is an LDS-DMA (`buffer_load_dword[x4] ... offen lds`): the weights of a
+// chunk land verbatim in U (the weight image is the lane-linear LDS image), the gathered input patch lands in R (destination of a
+// wave-instruction = M0 + lane * size and thread t stages R[t + i*512]: lane-linear by construction; a lane whose offset fails the
+// range check -- padding, outside the image -- writes 0.0: scripts/proto/lds_dma_probe.hip).  No load result ever sits in a VGPR:
+// 32 registers fewer than the register-staged form, no scratch traffic at all (a spill reload behind the epilogue's stores would
+// drain them: vmcnt retires in order), no ds_write of the operands.  The copies are inline asm, invisible to hipcc's wait counts:
+// every wait for them is a counted s_waitcnt before the chunk's barrier.  R has three buffers: position p is requested behind the
+// barrier of chunk p-4, has landed by the barrier of chunk p-2 (SPEC 2: p-3, then activated in place -- GroupNorm/FiLM affine +
+// SiLU, padding re-zeroed -- during chunk p-2 by the thread that requested it: thread-private, no barrier) and is transformed
+// during chunk p-1.  (2) The chunk pipeline is CONTINUOUS ACROSS THE ITEMS of a workgroup: positions >= n are the next item's chunks
+// (other resource bases and affine rows by scalar selects; the ONE gather table is rewritten for the next item at the chunk whose
+// request crosses over), so an item's main loop starts right behind its predecessor's epilogue -- no fill (9 k cycles of an 83 k
+// item at Cin = 64), no barrier at the item's top -- and its first chunk waits for nothing younger than the epilogue's 128 KB of
+// stores (their drain overlaps the first chunks).  A workgroup without a next item streams through zero-record resources.
+template <int MODE, int SPEC, bool RAG, bool HEAVY>
+__device__ __forceinline__ void conv_wino4_body(const ConvArgs& a, const Geo4& g, float* smem TRACE_PARAM) {
+    float* const Rb = smem;                   // [3][R_FLOATS]
+    float* const Vb = smem + 3 * R_FLOATS;    // [2][V_FLOATS]
     float* const Ub = Vb + 2 * V_FLOATS;      // [2][U_FLOATS]
-    float* const econst = Ub + 2 * U_FLOATS;  // [4][64] bias, vec, aux_a, aux_b of the item's 64 output channels
-    int* const gtab = reinterpret_cast<int*>(econst + 256);  // [NL][NT] gather byte offsets of the current item (thread-private)
+    float* const econst = Ub + 2 * U_FLOATS;  // [2 item parities][4][64] bias, vec, aux_a, aux_b of an item's 64 output channels
+    int* const gtab = reinterpret_cast<int*>(econst + 512);  // [NL][NT] gather byte offsets (thread-private entries)
+    constexpr unsigned R_BYTES = R_FLOATS * 4, U_BYTES = U_FLOATS * 4;
+    // LDS byte address of the dynamic segment (the DMA destinations are absolute LDS addresses in M0): the low half of its flat address
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<unsigned long long>(smem));
+    const unsigned U_LDS0 = lds_base + (3 * R_FLOATS + 2 * V_FLOATS) * 4;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -162,19 +182,21 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
     const int cb = wave & 3;   // MFMA role: 16-channel block
     const int tblk = wave >> 2;  // MFMA role: upper / lower 8x32 half-patch
     const int HWin = a.Hin * a.Win;
-    const int nchunks = a.Cin / CK;  // even (Cin % 8 == 0)
+    const int nchunks = a.Cin / CK;  // even, >= 4 (Cin % 8 == 0, Cin >= 16: conv_wino4_items)
+    const std::integral_constant<bool, HEAVY> hvt{};
 
-    // ---- per-thread gather descriptors ------------------------------------------------------------------------------------
-    // Thread stages R[tid + i*512]: the R index itself enumerates (ci, row, col), so the LDS writes are linear and unmasked.
-    // An element's load offset (bytes inside the sample) is -1 for pad slots and for elements outside the image, which the raw
-    // buffer load answers with 0.0.  The six offsets are decoded once per item -- a few dozen integer ops -- and parked in LDS
-    // (each thread reads back only its own entries): 144 accumulators leave no registers to hold them across the item.
+    // ---- per-item state.  Set A = the item being accumulated, set B = the next one (or the null item) ----------------------
     constexpr int RSRC_FLAGS = 0x00020000;
-    __amdgpu_buffer_rsrc_t rs0, rs1, rsu;
-    unsigned omask = 0;  // bit i: element i is padding / outside the image
+    struct View {  // the epilogue's view of an item (scalars)
+        int b, co0, y0, x0;
+    };
+    const float *p0A = a.src0, *p1A = a.src0, *puA = a.wwino4, *p0B = a.src0, *p1B = a.src0, *puB = a.wwino4;
+    View vA = {0, 0, 0, 0}, vB = {0, 0, 0, 0};
+    int nrB = 0;                      // num_records of set B's resources: 0 = the null item
+    unsigned omaskA = 0, omaskB = 0;  // SPEC 2: bit i = element i is padding / outside the image (zero AFTER the activation)
     // The item index advances by the grid size G: (channel block, patch column, patch row, sample) are carried as a mixed-radix
     // counter with a constant increment -- scalar adds and compares per item instead of five integer divisions.
-    int it_b = 0, it_cob = 0, it_px = 0, it_py = 0, it_co0 = 0, it_y0 = 0, it_x0 = 0;
+    int it_b = 0, it_cob = 0, it_px = 0, it_py = 0;
     const int tiles_y = g.np / a.tiles_x;
     int d_cob, d_px, d_py, d_b;
     {
@@ -206,17 +228,20 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
         it_py -= carry ? tiles_y : 0;
         it_b += d_b + carry;
     };
-    auto setup_item = [&]() {
-        const int cob = it_cob;
-        it_co0 = cob * 64;
-        it_y0 = it_py * TH;
-        it_x0 = it_px * TW;
-        rsu = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(scalar_ptr(a.wwino4 + (long long)cob * U_FLOATS)), 0, 0x7fffffff, RSRC_FLAGS);
-        rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(scalar_ptr(a.src0 + (long long)it_b * a.bs0)), 0, 0x7fffffff, RSRC_FLAGS);
-        rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(scalar_ptr(SPEC == 3 ? a.src1 + (long long)it_b * a.bs1 : a.src0)), 0, 0x7fffffff, RSRC_FLAGS);
+    auto decode_B = [&]() {  // the item (it_b, it_cob, it_px, it_py) becomes set B: scalars only
+        vB.b = it_b, vB.co0 = it_cob * 64, vB.y0 = it_py * TH, vB.x0 = it_px * TW;
+        puB = scalar_ptr(a.wwino4 + (long long)it_cob * U_FLOATS);
+        p0B = scalar_ptr(a.src0 + (long long)it_b * a.bs0);
+        p1B = scalar_ptr(SPEC == 3 ? a.src1 + (long long)it_b * a.bs1 : a.src0);
+        nrB = 0x7fffffff;
+    };
+    // Thread requests R[tid + i*512]: the R index itself enumerates (ci, row, col).  An element's load offset (bytes inside the
+    // sample) is -1 for pad slots and for elements outside the image: the range check fails and the DMA writes 0.0.  The six
+    // offsets of an item are decoded once and parked in LDS (thread-private entries); returns the item's padding mask.
+    auto write_table = [&](const View& v) {
         int t = tid;
         asm volatile("" : "+v"(t));  // opaque: keeps the decode here, once per item, instead of hoisted and held in registers
-        omask = 0;
+        unsigned om = 0;
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             const int e = t + i * NT;
@@ -224,77 +249,108 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
             const int rem = e - ci * PSP;
             const int r = rem / RS;
             const int c = rem - r * RS;
-            const int oy = it_y0 - 1 + r, ox = it_x0 - 1 + c;  // output-grid coordinates of the element
+            const int oy = v.y0 - 1 + r, ox = v.x0 - 1 + c;  // output-grid coordinates of the element
             const bool in = rem < PS && c < RCOLS && (unsigned)oy < (unsigned)a.Hout && (unsigned)ox < (unsigned)a.Wout;
             const int sp = MODE == IDIFF_CONV_UPSAMPLE2 ? (oy >> 1) * a.Win + (ox >> 1) : oy * a.Win + ox;
             gtab[i * NT + tid] = in ? (ci * HWin + sp) * 4 : -1;
-            omask |= (in ? 0u : 1u) << i;
+            om |= (in ? 0u : 1u) << i;
         }
+        return om;
     };
+    auto shift_B_to_A = [&]() { p0A = p0B, p1A = p1B, puA = puB, vA = vB, omaskA = omaskB; };
     const int ustride_b = a.ncob * U_FLOATS * 4;  // bytes between chunks of one channel block
 
-    float rinA[NL], rinB[NL];  // raw patches in flight: even / odd chunks
     // SPEC 2: the GroupNorm/FiLM affine of a chunk's four input channels comes through the scalar cache (uniform addresses;
-    // constant address space makes them s_load_dwordx4) -- a wave's 64 staged elements never straddle a channel (768 = 12 * 64),
-    // so an element's channel, and with it the affine, is wave-uniform.
+    // constant address space makes them s_load_dwordx4) -- a wave's 64 elements never straddle a channel (768 = 12 * 64), so an
+    // element's channel, and with it the affine, is wave-uniform.
     typedef const __attribute__((address_space(4))) floatx4* cfloatx4p;
     struct Pro {
         floatx4 a, b;
     };
-    auto load_pro = [&](int bb, int cc) {
-        Pro p;
+    // Stream positions: p < n is chunk p of set A, p >= n chunk p - n of set B (n >= 4 and p <= n + 3: never beyond B).
+    auto load_pro = [&](int p) {
+        Pro r;
         if (SPEC == 2) {
-            const long long o = (long long)bb * a.C0r + cc * CK;
-            p.a = *(cfloatx4p)(a.pro_a + o);
-            p.b = *(cfloatx4p)(a.pro_b + o);
+            const bool inA = p < nchunks;
+            const long long o = (long long)(inA ? vA.b : vB.b) * a.C0r + (inA ? p : p - nchunks) * CK;
+            r.a = *(cfloatx4p)(a.pro_a + o);
+            r.b = *(cfloatx4p)(a.pro_b + o);
         }
-        return p;
+        return r;
     };
-    floatx4 ru[NU];
 
-    auto load_raw = [&](float (&dst)[NL], int cc) {
+    // ---- LDS-DMA.  M0 (the destination base of a wave-instruction) is written inside the statement that uses it: hipcc does not
+    // preserve it around asm.  None of these loads is in hipcc's vmcnt bookkeeping.  Every statement opens with `s_nop 4`: an "s"
+    // operand may be fresh from a VALU write (readfirstlane, the v_readlane of an SGPR spill reload) and a buffer instruction that
+    // reads it as descriptor or soffset needs five wait states hipcc's hazard recognizer does not insert for inline asm.
+    // The 2304 float4 of weight chunk p -> U[buf]: four 1-KB pieces per wave, the last 256 float4 by the light waves.
+    const unsigned u_voff = tid * 16;
+    auto dma_u = [&](int p, int buf) {
+        const bool inA = p < nchunks;
+        const int so = (inA ? p : p - nchunks) * ustride_b;
+        const __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(inA ? puA : puB), 0, inA ? 0x7fffffff : nrB, RSRC_FLAGS);
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane(U_LDS0 + (unsigned)buf * U_BYTES + (unsigned)wave * 1024u);
+        asm volatile(
+            "s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %4 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %5 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %6 offen lds"
+            ::"v"(u_voff), "s"(rsu), "s"(lds0), "s"(so), "s"(so + NT * 16), "s"(so + 2 * NT * 16), "s"(so + 3 * NT * 16)
+            : "memory", "scc");
+        if (!HEAVY) {  // waves 4-7: float4 2048 + (tid - 256) of the chunk
+            const unsigned lds4 = __builtin_amdgcn_readfirstlane(lds0 + 4 * NT * 16 - 256 * 16);
+            asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(u_voff), "s"(rsu), "s"(lds4),
+                         "s"(so + 4 * NT * 16 - 256 * 16)
+                         : "memory");
+        }
+    };
+    // The gathered patch of position p -> R slot at byte offset rslot: six dwords per thread, element tid + i*512
+    auto dma_raw = [&](int p, unsigned rslot) {
+        const bool inA = p < nchunks;
+        const int cbase = (inA ? p : p - nchunks) * CK;
         int goff[NL];
 #pragma unroll
         for (int i = 0; i < NL; ++i) goff[i] = gtab[i * NT + tid];
-        const int cbase = cc * CK;
-        if (SPEC == 3 && cbase >= a.C0v) {  // chunk-uniform: C0v % 4 == 0
-            const int so = (cbase - a.C0v) * HWin * 4;
-#pragma unroll
-            for (int i = 0; i < NL; ++i) dst[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, goff[i], so, 0));
-        } else {
-            const int so = cbase * HWin * 4;
-#pragma unroll
-            for (int i = 0; i < NL; ++i) dst[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs0, goff[i], so, 0));
-        }
+        const int C0v = a.C0v;
+        const bool second = SPEC == 3 && cbase >= C0v;  // chunk-uniform: C0v % 4 == 0
+        // (selected as integers: a select of selects of pointers next to a field of `a` kept the whole argument block in scratch)
+        const unsigned long long b0 = reinterpret_cast<unsigned long long>(inA ? p0A : p0B), b1 = reinterpret_cast<unsigned long long>(inA ? p1A : p1B);
+        const float* const base = reinterpret_cast<const float*>(second ? b1 : b0);
+        const int so = (second ? cbase - C0v : cbase) * HWin * 4;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, inA ? 0x7fffffff : nrB, RSRC_FLAGS);
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_base + rslot + (unsigned)wave * 256u);
+        asm volatile(
+            "s_nop 4\n\ts_mov_b32 m0, %8\n\ts_nop 0\n\tbuffer_load_dword %0, %6, %7 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x800\n\ts_nop 0\n\tbuffer_load_dword %1, %6, %7 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x800\n\ts_nop 0\n\tbuffer_load_dword %2, %6, %7 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x800\n\ts_nop 0\n\tbuffer_load_dword %3, %6, %7 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x800\n\ts_nop 0\n\tbuffer_load_dword %4, %6, %7 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x800\n\ts_nop 0\n\tbuffer_load_dword %5, %6, %7 offen lds"
+            ::"v"(goff[0]), "v"(goff[1]), "v"(goff[2]), "v"(goff[3]), "v"(goff[4]), "v"(goff[5]), "s"(rs), "s"(so), "s"(lds0)
+            : "memory", "scc");
     };
-    // the 2304 float4 of a weight chunk: four per thread, the last 256 by the light waves (tid >= 256)
-    auto load_u = [&](int cc, auto hv_tag) {
-        constexpr bool HV = decltype(hv_tag)::value;
+    // SPEC 2: the thread's own six elements of position p, in place: x -> silu(a_c * x + b_c), padding back to zero
+    auto activate = [&](int p, unsigned rslot, int i0, int i1) {
+        if (SPEC != 2) return;
+        const Pro pro = load_pro(p);
+        const unsigned om = p < nchunks ? omaskA : omaskB;
+        float* const R = reinterpret_cast<float*>(reinterpret_cast<char*>(Rb) + rslot) + tid;
+        constexpr bool hiw = !HEAVY;
 #pragma unroll
-        for (int i = 0; i < NU - 1; ++i)
-            ru[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsu, tid * 16, cc * ustride_b + i * NT * 16, 0));
-        if (!HV) ru[NU - 1] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsu, tid * 16, cc * ustride_b + (NU - 1) * NT * 16 - 256 * 16, 0));
-    };
-    auto stage_raw = [&](const float (&src)[NL], int i, const Pro& pro, int rbuf, auto hv_tag) {
-        constexpr bool hiw = !decltype(hv_tag)::value;
-        float x = src[i];
-        if (SPEC == 2) {  // channel of element tid + i*512: (i*512 + wave*64) / 768 = {0, 0|1, 1, 2, 2|3, 3}[i]
+        for (int i = 0; i < NL; ++i) {
+            if (i < i0 || i >= i1) continue;
+            // channel of element tid + i*512: (i*512 + wave*64) / 768 = {0, 0|1, 1, 2, 2|3, 3}[i]
             const float pa = i == 0 ? pro.a.x : i == 1 ? (hiw ? pro.a.y : pro.a.x) : i == 2 ? pro.a.y : i == 3 ? pro.a.z : i == 4 ? (hiw ? pro.a.w : pro.a.z) : pro.a.w;
             const float pb = i == 0 ? pro.b.x : i == 1 ? (hiw ? pro.b.y : pro.b.x) : i == 2 ? pro.b.y : i == 3 ? pro.b.z : i == 4 ? (hiw ? pro.b.w : pro.b.z) : pro.b.w;
-            x = silu_fast(pa * x + pb);
+            const float x = silu_fast(pa * R[i * NT] + pb);
+            R[i * NT] = ((om >> i) & 1u) ? 0.f : x;
         }
-        Rb[rbuf * R_FLOATS + tid + i * NT] = (SPEC == 2 && ((omask >> i) & 1u)) ? 0.f : x;  // padding is zero AFTER the activation
-    };
-    auto stage_u = [&](int i, int buf, auto hv_tag) {
-        constexpr bool HV = decltype(hv_tag)::value;
-        if (i < NU - 1) reinterpret_cast<floatx4*>(Ub + buf * U_FLOATS)[tid + i * NT] = ru[i];
-        else if (!HV) reinterpret_cast<floatx4*>(Ub + buf * U_FLOATS)[tid + i * NT - 256] = ru[i];
     };
 
-    // ---- input transform B^T d B of R[rbuf] -> V[buf].  Thread = (ci = k4, tile (tyl, tx) of half-patch thalf) x row set:
+    // ---- input transform B^T d B of an R slot -> V[buf].  Thread = (ci = k4, tile (tyl, tx) of half-patch thalf) x row set:
     //   heavy waves 0-3: Winograd rows (1,2) (trole 0) or (3,4) (trole 1):  X = d4 + al*d2, Y = d3 + al*d1, rows X +- be*Y
     //   light waves 4-7: row 0 (from d0, d2, d4) or row 5 (from d1, d3, d5): 4*dA - 5*dB + dC
-    const bool heavy = wave < 4;  // wave class: uniform; the main loop is instantiated once per class, branch-free
+    constexpr bool heavy = HEAVY;
     const int trole = wave & 1;
     const int thalf = (wave >> 1) & 1;
     const int tx = lane & 7, tyl = (lane >> 3) & 1;
@@ -311,9 +367,8 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
         const floatx2 hi = *reinterpret_cast<const floatx2*>(p + 4);
         d[0] = lo.x, d[1] = lo.y, d[2] = lo.z, d[3] = lo.w, d[4] = hi.x, d[5] = hi.y;
     };
-    auto tr_piece = [&](int piece, int rbuf, int buf, auto hv_tag) {
-        constexpr bool heavy = decltype(hv_tag)::value;
-        const float* p = trbase + rbuf * R_FLOATS;
+    auto tr_piece = [&](int piece, unsigned rslot, int buf) {
+        const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(trbase) + rslot);
         if (piece == 0) {
             if (heavy) rd_row(p + 1 * RS, ta), rd_row(p + 3 * RS, tb);  // d2, d4
             else rd_row(p, ta), rd_row(p + 2 * RS, tb);                 // dA, dB
@@ -350,7 +405,6 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
             *reinterpret_cast<floatx2*>(V + PH(u) * 512 + 2 * (u & 1)) = floatx2{o[4], o[5]};
         }
     };
-    auto clampc = [&](int c) { return c < nchunks ? c : nchunks - 1; };
 
     const int G = gridDim.x;
     const int first = (int)xcd_remap(blockIdx.x, G);
@@ -359,99 +413,102 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
         if (a.gn.ticket) idiff_detail::gn_arrive_and_finalize(a, Rb);
         return;
     }
-    float pre_e = 0.f;
-    auto fetch_consts = [&]() {
-        if (tid < 256) {
-            const int which = tid >> 6, co = it_co0 + (tid & 63);
-            pre_e = 0.f;
+    auto fetch_consts = [&](const View& v) {  // an item's epilogue constants: threads 0..255 (= the heavy waves), one each
+        float e = 0.f;
+        if (HEAVY) {
+            const int which = tid >> 6, co = v.co0 + (tid & 63);
             if (co < a.Cout) {
-                if (which == 0 && a.bias) pre_e = a.bias[co];
-                if (which == 1 && a.vec) pre_e = a.vec[(long long)it_b * a.Cout + co];
-                if (which == 2 && a.aux) pre_e = a.aux_a[(long long)it_b * a.Cout + co];
-                if (which == 3 && a.aux) pre_e = a.aux_b[(long long)it_b * a.Cout + co];
+                if (which == 0 && a.bias) e = a.bias[co];
+                if (which == 1 && a.vec) e = a.vec[(long long)v.b * a.Cout + co];
+                if (which == 2 && a.aux) e = a.aux_a[(long long)v.b * a.Cout + co];
+                if (which == 3 && a.aux) e = a.aux_b[(long long)v.b * a.Cout + co];
             }
         }
+        return e;
     };
-    decode_first(first);
-    setup_item();
-    load_raw(rinA, 0);
-    load_raw(rinB, 1);
-    if (heavy) load_u(0, std::true_type{});
-    else load_u(0, std::false_type{});
-    fetch_consts();
     TRACE_INIT
     SLOT_INIT
 
+    // ---- the workgroup's first item: the only pipeline fill of the launch --------------------------------------------------------
+    // leaves what every item's last chunk leaves: V[0] <- chunk 0, R slot 1 <- chunk 1 (activated), R slot 2 <- chunk 2 (landed),
+    // U[0], U[1]; chunk 3 requested into slot 0 behind the last barrier
+    decode_first(first);
+    decode_B();
+    shift_B_to_A();
+    omaskA = write_table(vA);
+    if (first + G < last) {
+        advance_item();
+        decode_B();
+    } else {
+        nrB = 0, vB = vA;
+    }
+    dma_u(0, 0);
+    dma_raw(0, 0 * R_BYTES);
+    dma_raw(1, 1 * R_BYTES);
+    dma_raw(2, 2 * R_BYTES);
+    {
+        const float e0 = fetch_consts(vA);  // (hipcc-visible global loads: waited for by hipcc)
+        if (HEAVY) econst[tid] = e0;
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPEC == 2 ? 0 : NL) : "memory");  // U(0), raw(0), raw(1) have landed (SPEC 2: raw(2) too)
+    __syncthreads();  // an LDS-DMA is ordered for a ds_read only by the issuer's vmcnt FOLLOWED by a barrier the reader has passed
+    if (SPEC == 2) {
+        activate(0, 0 * R_BYTES, 0, NL);
+        activate(1, 1 * R_BYTES, 0, NL);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int piece = 0; piece < 5; ++piece) tr_piece(piece, 0 * R_BYTES, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    dma_u(1, 1);
+    dma_raw(3, 0 * R_BYTES);
+
+    unsigned r_t = 1 * R_BYTES, r_a = 2 * R_BYTES, r_x = 0 * R_BYTES;  // R slots: transformed this chunk / activated this chunk / landing
+    int epar = 0;        // parity of the item being accumulated: its set of epilogue constants
+    bool young = false;  // the requests in flight were issued BEFORE an epilogue: its >= 16 stores are younger than they are
     for (int item = first; item < last; item += G) {
-        const int b = it_b, co0 = it_co0, y0 = it_y0, x0 = it_x0;  // the epilogue's view of this item
         TRACE_MARK(0)
-
-        // ---- pipeline fill: V[0], U[0] hold chunk 0, R[1] chunk 1; raw(2), raw(3) and U(1) are in registers ---------------
-        __syncthreads();  // every wave is done with the previous item's LDS
-        TRACE_MARK(1)
-        const Pro pro0 = load_pro(b, 0), pro1 = load_pro(b, 1);
-        if (tid < 256) econst[tid] = pre_e;
         floatx4 acc[36];
-        // fill + main loop, instantiated per wave class (heavy: waves 0-3, light: waves 4-7) so that the role-dependent pieces
-        // are straight-line code; every wave passes the same barriers
-        auto run_item = [&](auto hv) {
 #pragma unroll
-            for (int i = 0; i < NL; ++i) stage_raw(rinA, i, pro0, 0, hv);
-#pragma unroll
-            for (int i = 0; i < NU; ++i) stage_u(i, 0, hv);
-#pragma unroll
-            for (int i = 0; i < NL; ++i) stage_raw(rinB, i, pro1, 1, hv);
-            load_raw(rinA, clampc(2));
-            load_raw(rinB, clampc(3));
-            load_u(1, hv);
-            TRACE_MARK(2)
-            __syncthreads();
-            TRACE_MARK(3)
-#pragma unroll
-            for (int piece = 0; piece < 5; ++piece) tr_piece(piece, 0, 0, hv);
-
-#pragma unroll
-            for (int p = 0; p < 36; ++p) acc[p] = floatx4{0.f, 0.f, 0.f, 0.f};
-            __syncthreads();
-            TRACE_MARK(4)
-
-            // ---- main loop, ONE barrier per chunk.  Iteration c runs the 18 position pairs of chunk c and, one slice per pair:
-            //   stage raw(c+2) registers -> R[c&1], then load raw(c+4) into them;  stage U(c+1) -> U[(c+1)&1], then load U(c+2);
-            //   transform R[(c+1)&1] (staged one iteration ago) -> V[(c+1)&1].
+        for (int p = 0; p < 36; ++p) acc[p] = floatx4{0.f, 0.f, 0.f, 0.f};
+        {
+            // ONE barrier per chunk.  Chunk c runs its 9 position quads and, one slice per quad:
+            //   transform position c+1 (slot r_t) -> V[(c+1)&1];  SPEC 2: activate position c+2 in place (slot r_a);
+            //   behind the barrier: request U(c+2) -> U[c&1] and position c+4 -> slot r_t (just transformed).
+            // At the barrier U(c+1) and position c+2 (SPEC 2: c+3) must have landed; the six requests of position c+3 may fly on.
             const int opoff = lane * 4;
             floatx4 ob[2], oa[2];
             ob[0] = *reinterpret_cast<const floatx4*>(Vb + tblk * 256 + opoff);  // quad 0 of chunk 0
             oa[0] = *reinterpret_cast<const floatx4*>(Ub + cb * 256 + opoff);
-            const bool have_next = item + G < last;
-            auto chunk = [&](int cc, auto par_tag, auto more_tag) {
-                constexpr int PAR = decltype(par_tag)::value;      // cc & 1: LDS buffers and the raw register set
-                constexpr bool MORE = decltype(more_tag)::value;   // false: last chunk, nothing left to stage
+            auto chunk = [&](int cc, auto par_tag) {
+                constexpr int PAR = decltype(par_tag)::value;      // cc & 1: V / U buffers
                 const float* V = Vb + PAR * V_FLOATS + tblk * 256 + opoff;
                 const float* U = Ub + PAR * U_FLOATS + cb * 256 + opoff;
-                float(&rin)[NL] = PAR ? rinB : rinA;
-                Pro pro;
-                if (MORE) pro = load_pro(b, clampc(cc + 2));  // the affine of the chunk staged below
                 // Operand quads alternate between two register sets; the parity flips from chunk to chunk (9 quads), so quad 8 of
                 // this chunk and quad 0 of the next never share a set: the next chunk's first operands are requested right after
                 // the barrier and arrive while the four MFMAs of this chunk's last quad run.
                 const float* Vn = Vb + (PAR ^ 1) * V_FLOATS + tblk * 256 + opoff;
                 const float* Un = Ub + (PAR ^ 1) * U_FLOATS + cb * 256 + opoff;
-                if (MORE) { SLOT_START }
+                SLOT_START
 #pragma unroll
                 for (int q = 0; q < 9; ++q) {
                     if (q + 1 < 9) {
                         ob[(q + 1 + PAR) & 1] = *reinterpret_cast<const floatx4*>(V + (q + 1) * 512);
                         oa[(q + 1 + PAR) & 1] = *reinterpret_cast<const floatx4*>(U + (q + 1) * 1024);
-                    } else if (MORE) {
-#ifndef W4_NO_RAW
-#ifndef W4_NO_RAWLOAD
-                        load_raw(rin, clampc(cc + 4));
-#endif
-#endif
+                    } else {
+                        // the request of position c+4 crosses into the next item: from here on the table is that item's
+                        if (cc + 4 == nchunks) omaskB = write_table(vB);
+                        // (partial patches: a wave wholly outside the image issues no store -- nothing to count on)
+                        if (young) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SPEC == 2 ? 0 : NL) + (RAG ? 0 : 16)) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPEC == 2 ? 0 : NL) : "memory");
+                        young = false;
                         __builtin_amdgcn_sched_barrier(0);
                         SLOT_MARK(8)
                         __syncthreads();
                         SLOT_MARK(9)
+                        dma_u(cc + 2, PAR);
+                        dma_raw(cc + 4, r_t);
                         ob[PAR ^ 1] = *reinterpret_cast<const floatx4*>(Vn);
                         oa[PAR ^ 1] = *reinterpret_cast<const floatx4*>(Un);
                     }
@@ -460,69 +517,68 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
                     acc[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[4 * q + 1], 0, 0, 0);
                     acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[4 * q + 2], 0, 0, 0);
                     acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[4 * q + 3], 0, 0, 0);
-                    if (MORE) {
-#ifndef W4_NO_TR
-                        if (q < 5) tr_piece(q, PAR ^ 1, PAR ^ 1, hv);
-#endif
-#ifndef W4_NO_U
-                        if (q >= 1 && q < 5) stage_u(q - 1, PAR ^ 1, hv);
-                        if (q == 5) stage_u(4, PAR ^ 1, hv);
-#ifndef W4_NO_ULOAD
-                        if (q == 6) load_u(clampc(cc + 2), hv);
-#endif
-#endif
-#ifndef W4_NO_RAW
-                        if (q == 5) stage_raw(rin, 0, pro, PAR, hv), stage_raw(rin, 1, pro, PAR, hv);
-                        if (q == 6) stage_raw(rin, 2, pro, PAR, hv), stage_raw(rin, 3, pro, PAR, hv);
-                        if (q == 7) stage_raw(rin, 4, pro, PAR, hv), stage_raw(rin, 5, pro, PAR, hv);
-#endif
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (q < 8) { SLOT_MARK(q) }
-                    } else if (have_next) {
-                        // Nothing is staged in the last chunk, so the item state is free: switch it to the next item between the
-                        // MFMAs and let its first patches and weights travel during the rest of the chunk and the epilogue.
-                        if (q == 0) advance_item(), setup_item();
-                        if (q == 2) load_raw(rinA, 0);
-                        if (q == 3) load_raw(rinB, 1);
-                        if (q == 4) load_u(0, hv);
-                        if (q == 5) fetch_consts();
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                    if (q < 5) tr_piece(q, r_t, PAR ^ 1);
+                    if (q == 5) activate(cc + 2, r_a, 0, 2);
+                    if (q == 6) activate(cc + 2, r_a, 2, 4);
+                    if (q == 7) activate(cc + 2, r_a, 4, 6);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (q < 8) { SLOT_MARK(q) }
                 }
+                const unsigned t = r_t;  // next chunk: transform what was activated, activate what has landed, land into the freed slot
+                r_t = r_a, r_a = r_x, r_x = t;
             };
-            for (int cc = 0; cc + 2 < nchunks; cc += 2) {
-                chunk(cc, std::integral_constant<int, 0>{}, std::true_type{});
-                chunk(cc + 1, std::integral_constant<int, 1>{}, std::true_type{});
+            for (int cc = 0; cc < nchunks; cc += 2) {
+                chunk(cc, std::integral_constant<int, 0>{});
+                chunk(cc + 1, std::integral_constant<int, 1>{});
             }
-            chunk(nchunks - 2, std::integral_constant<int, 0>{}, std::true_type{});
-            chunk(nchunks - 1, std::integral_constant<int, 1>{}, std::false_type{});
-        };
-        if (heavy) run_item(std::true_type{});
-        else run_item(std::false_type{});
-        TRACE_MARK(5)
+        }
+        TRACE_MARK(1)
+
+        // ---- item switch: the accumulators belong to `v`; set B (streamed in by the last chunks) becomes set A, the item after it
+        // is decoded (scalars; its table is written when the requests reach it), and the new A's epilogue constants are requested
+        // BEFORE this epilogue's stores
+        const View v = vA;
+        const float* const ebase_item = econst + epar * 256;
+        const bool more = item + G < last;
+        float pre_e = 0.f;
+        if (more) {
+            shift_B_to_A();
+            if (item + 2 * G < last) {
+                advance_item();
+                decode_B();
+            } else {
+                nrB = 0, vB = vA;
+            }
+            pre_e = fetch_consts(vA);
+        }
+        young = true;
 
         // ---- epilogue: in-lane output transform A^T m A, then the conv_igemm epilogue contract ---------------------------
         // C layout of 16x16x4: lane holds column j (tile) and rows 4*k4 + r (channels) of the wave's 16-channel block
-        if (co0 + cb * 16 < a.Cout) {  // uniform: a 16-channel block beyond a partial Cout has nothing to store
-            // lane-derived constants are recomputed here from an opaque copy of the lane id: hoisted out of the item loop they
-            // would be spilled (the main loop has no register to spare) and reloaded through the same in-order vmcnt queue as
-            // the output stores
+        const int b = v.b, co0 = v.co0, y0 = v.y0, x0 = v.x0;
+        {
+            // lane-derived constants are recomputed here from an opaque copy of the lane id (not held through the main loop)
             int lane_e = lane;
             asm volatile("" : "+v"(lane_e));
             const int j = lane_e & 15, k4 = lane_e >> 4;
             const int HWo = a.Hout * a.Wout;
             const int ty0 = y0 + 8 * tblk;  // first row of the wave's half-patch
+            const bool wave_live = co0 + cb * 16 < a.Cout;  // uniform: a 16-channel block beyond a partial Cout stores nothing
+            // Stores go through buffer resources: a dead wave's resource has zero records -- the range check drops its stores, but
+            // they are issued and counted.  Without partial patches (!RAG) no branch surrounds a store: every wave issues the same
+            // 16 (+4) stores per item, which is what lets the next item's first chunk COUNT them (vmcnt) instead of draining them.
             const long long wave_org = (long long)(co0 + cb * 16) * HWo + (long long)ty0 * a.Wout + x0;
-            float* const outb = a.out + (long long)b * a.obs + wave_org;
+            const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(scalar_ptr(a.out + (long long)b * a.obs + wave_org)), 0, wave_live ? 0x7fffffff : 0, RSRC_FLAGS);
             const float* const resb = a.res ? a.res + (long long)b * a.rbs + wave_org : nullptr;
             const float* const auxb = a.aux ? a.aux + (long long)b * a.abs_ + wave_org : nullptr;
-            const unsigned lane_off = (unsigned)(4 * k4) * (unsigned)HWo + (unsigned)(4 * (j >> 3)) * (unsigned)a.Wout + 4u * (j & 7);
-            const float* const ebase = econst + cb * 16 + 4 * k4;
-            const bool want_stats = a.stats != nullptr && ty0 < a.Hout;
-            const bool has_res = a.res != nullptr, has_aux = a.aux != nullptr;
-            // partial patches: H and W are multiples of 4, so a 4x4 tile lies inside the image or outside it
             const bool inside = !RAG || ((ty0 + 4 * (j >> 3) < a.Hout) && (x0 + 4 * (j & 7) < a.Wout));
-            float* const stp = want_stats ? a.stats + (((long long)b * a.ntiles + (ty0 >> 3) * a.tiles_x + (x0 >> 5)) * a.Cout + co0 + cb * 16 + 4 * k4) * 2 : nullptr;
+            const unsigned lane_off = (unsigned)(4 * k4) * (unsigned)HWo + (unsigned)(4 * (j >> 3)) * (unsigned)a.Wout + 4u * (j & 7);
+            const float* const ebase = ebase_item + cb * 16 + 4 * k4;
+            const bool want_stats = a.stats != nullptr && ty0 < a.Hout && wave_live;
+            const bool has_res = a.res != nullptr && wave_live, has_aux = a.aux != nullptr && wave_live;
+            const float* const stbase = a.stats ? a.stats + (((long long)b * a.ntiles + (ty0 >> 3) * a.tiles_x + (x0 >> 5)) * a.Cout + co0 + cb * 16) * 2 : a.out;
+            const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(scalar_ptr(stbase)), 0, want_stats ? 0x7fffffff : 0, RSRC_FLAGS);
+            constexpr int AUX_SC1 = 1 << 4;  // write-through: the partials are read by another workgroup (gn_tail.h) / the next launch
             // Phase 1: A^T along the Winograd columns v of every row u and channel r -- 144 accumulators shrink to 96 values
             // (the accumulators of a row die as soon as it is done, so the registers hold either form, never both).
             float zz[6][4][4];  // [u][r][dx]
@@ -531,17 +587,21 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     at6(acc[pos(u, 0)][r], acc[pos(u, 1)][r], acc[pos(u, 2)][r], acc[pos(u, 3)][r], acc[pos(u, 4)][r], acc[pos(u, 5)][r], zz[u][r]);
-                    // pinned here: left alone, the optimiser sinks these sums to their uses in phase 2 and keeps the accumulators --
-                    // spilled -- until then, reloading them through the same in-order vmcnt queue as the output stores
+                    // pinned here: left alone, the optimiser sinks these sums to their uses in phase 2 and keeps the accumulators
+                    // alive until then
                     asm volatile("" : "+v"(zz[u][r][0]), "+v"(zz[u][r][1]), "+v"(zz[u][r][2]), "+v"(zz[u][r][3]));
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            TRACE_MARK(6)
+            TRACE_MARK(2)
             // Phase 2, per channel r: A^T along u, bias, GroupNorm partials, then four row steps.  The residual / aux row of
             // step s+1 is requested BEFORE the store of step s (vmcnt counts loads and stores in order: a load behind a store
-            // would wait for it).  has_res / has_aux are uniform branches.
+            // would wait for it).  has_res / has_aux are uniform branches (around loads only).
             floatx4 nres = floatx4{0.f, 0.f, 0.f, 0.f}, naux = nres;
+#ifdef W4_STATS_LAST
+            typedef unsigned uintx2_ __attribute__((ext_vector_type(2)));
+            uintx2_ spr[4];
+#endif
             auto fetch = [&](int s) {
                 if (!inside) return;
                 const long long so = (long long)(s >> 2) * HWo + (s & 3) * a.Wout;  // uniform
@@ -560,17 +620,26 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
 #pragma unroll
                     for (int dy = 0; dy < 4; ++dy) y[dy][x] = col[dy] + bv;
                 }
-                if (want_stats) {
+                {
                     float ssum = 0.f, ssq = 0.f;
+                    if (a.stats != nullptr) {  // uniform; around arithmetic only
 #pragma unroll
-                    for (int dy = 0; dy < 4; ++dy) {
-                        ssum += (y[dy][0] + y[dy][1]) + (y[dy][2] + y[dy][3]);
-                        ssq += (y[dy][0] * y[dy][0] + y[dy][1] * y[dy][1]) + (y[dy][2] * y[dy][2] + y[dy][3] * y[dy][3]);
+                        for (int dy = 0; dy < 4; ++dy) {
+                            ssum += (y[dy][0] + y[dy][1]) + (y[dy][2] + y[dy][3]);
+                            ssq += (y[dy][0] * y[dy][0] + y[dy][1] * y[dy][1]) + (y[dy][2] * y[dy][2] + y[dy][3] * y[dy][3]);
+                        }
+                        if (!inside) ssum = 0.f, ssq = 0.f;
+                        ssum = row_sum16(ssum);
+                        ssq = row_sum16(ssq);
                     }
-                    if (!inside) ssum = 0.f, ssq = 0.f;
-                    ssum = row_sum16(ssum);
-                    ssq = row_sum16(ssq);
-                    if (j == 15) idiff_detail::gn_store_partial(stp + 2 * r, ssum, ssq);  // write-through: read by another workgroup (gn_tail.h)
+                    // lane 15 of each 16-lane row holds the sums of the wave's cell for channel 4*k4 + r
+                    typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
+                    const uintx2 pr = {__builtin_bit_cast(unsigned, ssum), __builtin_bit_cast(unsigned, ssq)};
+#ifndef W4_STATS_LAST
+                    __builtin_amdgcn_raw_buffer_store_b64(pr, rst, j == 15 ? (4 * k4 + r) * 8 : -1, 0, AUX_SC1);
+#else
+                    spr[r] = pr;
+#endif
                 }
                 const float add = ebase[64 + r];
                 float aa = 0.f, ab = 0.f;
@@ -579,32 +648,52 @@ __global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const 
                 for (int dy = 0; dy < 4; ++dy) {
                     const floatx4 cres = nres, caux = naux;
                     if (4 * r + dy + 1 < 16) fetch(4 * r + dy + 1);
-                    floatx4 v = floatx4{y[dy][0] + add, y[dy][1] + add, y[dy][2] + add, y[dy][3] + add};
-                    if (has_res) v += cres;
+                    floatx4 v4 = floatx4{y[dy][0] + add, y[dy][1] + add, y[dy][2] + add, y[dy][3] + add};
+                    if (has_res) v4 += cres;
                     if (has_aux) {
-                        v.x += silu_fast(aa * caux.x + ab), v.y += silu_fast(aa * caux.y + ab);
-                        v.z += silu_fast(aa * caux.z + ab), v.w += silu_fast(aa * caux.w + ab);
+                        v4.x += silu_fast(aa * caux.x + ab), v4.y += silu_fast(aa * caux.y + ab);
+                        v4.z += silu_fast(aa * caux.z + ab), v4.w += silu_fast(aa * caux.w + ab);
                     }
-#ifdef W4_NO_STORE  // diagnostic: keeps the arithmetic alive, stores (almost) nothing
-                    if (inside && v.x == 12345.678f) *reinterpret_cast<floatx4*>(outb + ((long long)r * HWo + dy * a.Wout) + lane_off) = v;
-#else
-                    if (inside) *reinterpret_cast<floatx4*>(outb + ((long long)r * HWo + dy * a.Wout) + lane_off) = v;
-#endif
+                    typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+                    // RAG: lanes outside the image are masked by EXEC, not by the range check -- a 16-byte buffer store with SOME
+                    // lanes out of range loses 8 of the 16 bytes of in-range neighbours (measured: profiles/r04/x_wino4_dma_notes.txt);
+                    // all lanes out of range (the zero-record resource of a dead wave) is fine
+                    if (!RAG || inside) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v4), rso, (int)(lane_off * 4u), (r * HWo + dy * a.Wout) * 4, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+#ifdef W4_STATS_LAST
+#pragma unroll
+            for (int r = 0; r < 4; ++r) __builtin_amdgcn_raw_buffer_store_b64(spr[r], rst, j == 15 ? (4 * k4 + r) * 8 : -1, 0, AUX_SC1);
+#endif
         }
-        TRACE_MARK(7)
-        TRACE_MARK(8)
+        TRACE_MARK(3)
+        // the next item's epilogue constants into the other set: its last readers (the epilogue two items back) are behind at least
+        // one chunk barrier of the item just finished; its next readers are ordered by the chunk barriers of the item now starting
+        if (HEAVY && more) econst[(epar ^ 1) * 256 + tid] = pre_e;
+        epar ^= 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the null item's requests (answered with zeros) still target this workgroup's LDS
     if (a.gn.ticket) idiff_detail::gn_arrive_and_finalize(a, Rb);  // GroupNorm finalize as the tail of this launch (gn_tail.h)
     TRACE_FINI
     SLOT_FINI
 }
 
 template <int MODE, int SPEC, bool RAG>
+__global__ __launch_bounds__(NT) void conv_wino4_kernel(const ConvArgs a, const Geo4 g TRACE_PARAM) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef IDIFF_WINO_TRACE
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < 4) conv_wino4_body<MODE, SPEC, RAG, true>(a, g, smem, trace);
+    else conv_wino4_body<MODE, SPEC, RAG, false>(a, g, smem, trace);
+#else
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < 4) conv_wino4_body<MODE, SPEC, RAG, true>(a, g, smem);
+    else conv_wino4_body<MODE, SPEC, RAG, false>(a, g, smem);
+#endif
+}
+
+template <int MODE, int SPEC, bool RAG>
 int launch_rag(const ConvArgs& a, hipStream_t st) {
-    const size_t lds = ((size_t)2 * R_FLOATS + 2 * V_FLOATS + 2 * U_FLOATS + 256 + NL * NT) * sizeof(float);
+    const size_t lds = ((size_t)3 * R_FLOATS + 2 * V_FLOATS + 2 * U_FLOATS + 2 * 256 + NL * NT) * sizeof(float);  // 158 KB
     if (lds > 160 * 1024) IDIFF_FAIL(IDIFF_E_UNSUPPORTED, "conv2d(winograd4): LDS budget exceeded (%zu bytes)", lds);
     static idiff_dyn_lds_cache lds_cache;
     auto kern = conv_wino4_kernel<MODE, SPEC, RAG>;
@@ -636,8 +725,8 @@ int launch_rag(const ConvArgs& a, hipStream_t st) {
     long long h[32];
     (void)hipMemcpyAsync(h, tr, sizeof(h), hipMemcpyDeviceToHost, st);
     (void)hipStreamSynchronize(st);
-    fprintf(stderr, "[wino4 trace] Cin=%d Cout=%d H=%d items=%d per=%d | topbar %lld stage %lld bar2 %lld tr+bar3 %lld loop %lld epi1 %lld epi2 %lld (cycles/item, wave 0)\n",
-            a.Cin, a.Cout, a.Hout, g.total, per, h[0] / g.total, h[1] / g.total, h[2] / g.total, h[3] / g.total, h[4] / g.total, h[5] / g.total, h[6] / g.total);
+    fprintf(stderr, "[wino4 trace] Cin=%d Cout=%d H=%d items=%d per=%d | main loop %lld | switch + output transform %lld | statistics + stores %lld | to next item %lld (cycles/item, wave 0)\n",
+            a.Cin, a.Cout, a.Hout, g.total, per, h[0] / g.total, h[1] / g.total, h[2] / g.total, h[3] / g.total);
 #ifdef IDIFF_WINO_SLOTS
     {
         const long long nch = (long long)g.total * (a.Cin / CK - 1);  // staged chunks

@@ -470,7 +470,7 @@ def force_wino4(request):
 
 @pytest.mark.parametrize("B,C0,C1,Cout,H,W,variant", [
     (2, 64, 0, 64, 32, 32, "plain"),
-    (1, 8, 0, 128, 16, 64, "plain"),        # two chunks, two channel blocks, 1x2 patches
+    (1, 16, 0, 128, 16, 64, "plain"),       # four chunks (the fewest the 16x32 kernel takes), two channel blocks, 1x2 patches
     (2, 64, 0, 64, 16, 96, "prologue"),
     (1, 24, 40, 192, 32, 32, "concat"),
     (2, 32, 0, 64, 16, 16, "upsample"),     # out 32x32
@@ -485,9 +485,9 @@ def force_wino4(request):
     (1, 24, 16, 64, 20, 40, "concat"),
     (2, 32, 0, 64, 28, 28, "epilogue"),     # narrower than a patch (the 224 / 8 level)
     (1, 16, 0, 32, 24, 24, "plain"),
-    (1, 8, 0, 64, 56, 56, "prologue"),      # 56 = 3.5 patches high
-    # several items per workgroup, two to ten chunks per item: the software pipeline runs across item boundaries
-    (21, 8, 0, 64, 64, 64, "epilogue"),
+    (1, 16, 0, 64, 56, 56, "prologue"),     # 56 = 3.5 patches high
+    # several items per workgroup, four to ten chunks per item: the software pipeline runs across item boundaries
+    (21, 16, 0, 64, 64, 64, "epilogue"),
     (20, 16, 0, 128, 64, 64, "prologue"),
     (17, 40, 0, 64, 64, 96, "plain"),
 ])
@@ -591,6 +591,8 @@ def test_conv_winograd4_random_shapes_match_direct(force_wino4):
         C1 = 4 * int(rng.randint(1, 9)) if two else 0
         if (C0 + C1) % 8:
             C1 += 4
+        if C0 + C1 < 16:   # the 16x32-item kernel streams four chunks ahead: Cin >= 16
+            C0 += 8
         Cout = 16 * int(rng.randint(1, 13))
         H = 4 * int(rng.randint(1, 13))
         W = 4 * int(rng.randint(6, 25))
