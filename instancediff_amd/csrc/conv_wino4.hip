@@ -304,6 +304,15 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a, const Geo4& g
                          : "memory");
         }
     };
+    // one 1-KB piece of the same copy: i = 0..3, and 4 = the light waves' fifth.  Between two barriers a chunk's pieces are dealt
+    // out one per quad: eight waves issuing 36 of them at once right behind the barrier held the last wave in line ~1 k cycles
+    auto dma_u_piece = [&](int p, int buf, int i) {
+        const bool inA = p < nchunks;
+        const int so = (inA ? p : p - nchunks) * ustride_b + (i < 4 ? i * NT * 16 : 4 * NT * 16 - 256 * 16);
+        const __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(inA ? puA : puB), 0, inA ? 0x7fffffff : nrB, RSRC_FLAGS);
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane(U_LDS0 + (unsigned)buf * U_BYTES + (unsigned)wave * 1024u + (unsigned)(i < 4 ? i * NT * 16 : 4 * NT * 16 - 256 * 16));
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(u_voff), "s"(rsu), "s"(lds0), "s"(so) : "memory");
+    };
     // The gathered patch of position p -> R slot at byte offset rslot: six dwords per thread, element tid + i*512
     auto dma_raw = [&](int p, unsigned rslot) {
         const bool inA = p < nchunks;
@@ -328,6 +337,20 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a, const Geo4& g
             "s_add_u32 m0, m0, 0x800\n\ts_nop 0\n\tbuffer_load_dword %5, %6, %7 offen lds"
             ::"v"(goff[0]), "v"(goff[1]), "v"(goff[2]), "v"(goff[3]), "v"(goff[4]), "v"(goff[5]), "s"(rs), "s"(so), "s"(lds0)
             : "memory", "scc");
+    };
+    // the same, one element per call (SPEC 1 / 3: dealt out over the quads of a chunk -- eight waves issuing all their copies right
+    // behind the barrier queue ~85 wave-instructions at the CU's one address unit: 1.3 k cycles of a 4.1 k chunk for the last in line)
+    auto dma_raw_piece = [&](int p, unsigned rslot, int i, int goff_i) {
+        const bool inA = p < nchunks;
+        const int cbase = (inA ? p : p - nchunks) * CK;
+        const int C0v = a.C0v;
+        const bool second = SPEC == 3 && cbase >= C0v;
+        const unsigned long long b0 = reinterpret_cast<unsigned long long>(inA ? p0A : p0B), b1 = reinterpret_cast<unsigned long long>(inA ? p1A : p1B);
+        const float* const base = reinterpret_cast<const float*>(second ? b1 : b0);
+        const int so = (second ? cbase - C0v : cbase) * HWin * 4;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, inA ? 0x7fffffff : nrB, RSRC_FLAGS);
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_base + rslot + (unsigned)wave * 256u + (unsigned)i * 2048u);
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %0, %1, %2 offen lds" ::"v"(goff_i), "s"(rs), "s"(so), "s"(lds0) : "memory");
     };
     // SPEC 2: the thread's own six elements of position p, in place: x -> silu(a_c * x + b_c), padding back to zero
     auto activate = [&](int p, unsigned rslot, int i0, int i1) {
@@ -462,7 +485,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a, const Geo4& g
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     dma_u(1, 1);
-    dma_raw(3, 0 * R_BYTES);
+    if (SPEC == 2) dma_raw(3, 0 * R_BYTES);  // (SPEC 1 / 3: requested during chunk 0)
 
     unsigned r_t = 1 * R_BYTES, r_a = 2 * R_BYTES, r_x = 0 * R_BYTES;  // R slots: transformed this chunk / activated this chunk / landing
     int epar = 0;        // parity of the item being accumulated: its set of epilogue constants
@@ -475,7 +498,8 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a, const Geo4& g
         {
             // ONE barrier per chunk.  Chunk c runs its 9 position quads and, one slice per quad:
             //   transform position c+1 (slot r_t) -> V[(c+1)&1];  SPEC 2: activate position c+2 in place (slot r_a);
-            //   behind the barrier: request U(c+2) -> U[c&1] and position c+4 -> slot r_t (just transformed).
+            //   behind the barrier: request U(c+2) -> U[c&1]; position c+4 -> the slot just transformed: SPEC 2 right there (it must
+            //   land within the chunk), SPEC 1 / 3 one element per quad of the NEXT chunk (as its position c+3).
             // At the barrier U(c+1) and position c+2 (SPEC 2: c+3) must have landed; the six requests of position c+3 may fly on.
             const int opoff = lane * 4;
             floatx4 ob[2], oa[2];
@@ -490,6 +514,14 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a, const Geo4& g
                 // the barrier and arrive while the four MFMAs of this chunk's last quad run.
                 const float* Vn = Vb + (PAR ^ 1) * V_FLOATS + tblk * 256 + opoff;
                 const float* Un = Ub + (PAR ^ 1) * U_FLOATS + cb * 256 + opoff;
+                // SPEC 1 / 3: position c+3 is requested during this chunk, one element per quad, into the slot freed by the previous
+                // chunk's transform (r_x); when that request crosses into the next item the table becomes that item's first
+                int goff[NL];
+                if (SPEC != 2) {
+                    if (cc + 3 == nchunks) omaskB = write_table(vB);
+#pragma unroll
+                    for (int i = 0; i < NL; ++i) goff[i] = gtab[i * NT + tid];
+                }
                 SLOT_START
 #pragma unroll
                 for (int q = 0; q < 9; ++q) {
@@ -497,8 +529,8 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a, const Geo4& g
                         ob[(q + 1 + PAR) & 1] = *reinterpret_cast<const floatx4*>(V + (q + 1) * 512);
                         oa[(q + 1 + PAR) & 1] = *reinterpret_cast<const floatx4*>(U + (q + 1) * 1024);
                     } else {
-                        // the request of position c+4 crosses into the next item: from here on the table is that item's
-                        if (cc + 4 == nchunks) omaskB = write_table(vB);
+                        // SPEC 2: the request of position c+4 crosses into the next item: from here on the table is that item's
+                        if (SPEC == 2 && cc + 4 == nchunks) omaskB = write_table(vB);
                         // (partial patches: a wave wholly outside the image issues no store -- nothing to count on)
                         if (young) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SPEC == 2 ? 0 : NL) + (RAG ? 0 : 16)) : "memory");
                         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPEC == 2 ? 0 : NL) : "memory");
@@ -507,8 +539,11 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a, const Geo4& g
                         SLOT_MARK(8)
                         __syncthreads();
                         SLOT_MARK(9)
-                        dma_u(cc + 2, PAR);
-                        dma_raw(cc + 4, r_t);
+                        // U(c+2): before an epilogue all of it at once (its stores must stay younger than these copies), else the
+                        // first piece here and the others over the next chunk's first quads
+                        if (cc + 1 == nchunks) dma_u(cc + 2, PAR);
+                        else dma_u_piece(cc + 2, PAR, 0);
+                        if (SPEC == 2) dma_raw(cc + 4, r_t);
                         ob[PAR ^ 1] = *reinterpret_cast<const floatx4*>(Vn);
                         oa[PAR ^ 1] = *reinterpret_cast<const floatx4*>(Un);
                     }
@@ -517,6 +552,18 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a, const Geo4& g
                     acc[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[4 * q + 1], 0, 0, 0);
                     acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[4 * q + 2], 0, 0, 0);
                     acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[4 * q + 3], 0, 0, 0);
+                    if (cc != 0) {  // (chunk 0: U(1) was copied whole before the epilogue / by the fill)
+                        if (q < 3) dma_u_piece(cc + 1, PAR ^ 1, q + 1);
+                        if (q == 3 && !HEAVY) dma_u_piece(cc + 1, PAR ^ 1, 4);
+                    }
+                    if (SPEC != 2) {  // position c+3, behind the last piece of U(c+1): the counted wait leaves exactly these six in flight
+                        if (HEAVY && q == 3) dma_raw_piece(cc + 3, r_x, 0, goff[0]);
+                        if (!HEAVY && q == 4) dma_raw_piece(cc + 3, r_x, 0, goff[0]);
+                        if (q == 4) dma_raw_piece(cc + 3, r_x, 1, goff[1]);
+                        if (q == 5) dma_raw_piece(cc + 3, r_x, 2, goff[2]);
+                        if (q == 6) dma_raw_piece(cc + 3, r_x, 3, goff[3]);
+                        if (q == 7) dma_raw_piece(cc + 3, r_x, 4, goff[4]), dma_raw_piece(cc + 3, r_x, 5, goff[5]);
+                    }
                     if (q < 5) tr_piece(q, r_t, PAR ^ 1);
                     if (q == 5) activate(cc + 2, r_a, 0, 2);
                     if (q == 6) activate(cc + 2, r_a, 2, 4);
