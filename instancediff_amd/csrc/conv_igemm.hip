@@ -722,11 +722,11 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
         }
     }
     // Which F(4x4,3x3) kernel (both read the same weight image): decided on the layer's PER-SAMPLE shape only.
-    //   >= 16 items of 16x32 pixels x 64 channels per sample: the 16x32 kernel -- except two-source (virtual concat) layers, whose long
-    //      K favours the half-patch kernel (weights straight into the A operand: -4..8 % measured on the up-path layers at c2);
-    //   fewer, but >= 16 half-patch (8x32) items: the half-patch kernel (the 32x32 level at c2: -7..17 % against F(2x2,3x3));
+    //   >= 16 items of 16x32 pixels x 64 channels per sample: the 16x32 kernel (r04: with its loads by LDS-DMA and the pipeline
+    //      continuous across items it also wins the two-source layers the half-patch kernel held in r03: 144->64 at 256^2 484 vs 547 us);
+    //   fewer, but >= 16 half-patch (8x32) items: the half-patch kernel (the 32x32 level at c2: 576->256 136 vs 210 us);
     //   fewer still: F(2x2,3x3) / direct below.
-    static const int w4h_mode = [] {  // IDIFF_W4H (A/B runs): 0 = never by itself, 1 (default) = the rule above, 2 = wherever it tiles
+    static const int w4h_mode = [] {  // IDIFF_W4H (A/B runs): 0 = never by itself, 1 (default) = the rule above, 2 = wherever it tiles, 3 = the r03 rule (two-source layers too)
         const char* e = getenv("IDIFF_W4H");
         return e ? atoi(e) : 1;
     }();
@@ -740,7 +740,7 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
         bool half;
         if (req4h) half = true;
         else if (req4 && w4_ok) half = false;
-        else if (items16 >= 16 && w4_ok) half = w4h_mode == 2 || (w4h_mode == 1 && a.src1 != nullptr);
+        else if (items16 >= 16 && w4_ok) half = w4h_mode == 2 || (w4h_mode == 3 && a.src1 != nullptr);
         else half = w4h_mode >= 1 && items8 >= 16;
         // The GroupNorm finalize as the tail of the conv launch (gn_tail.h) is opt-in per call: the caller passes a ticket buffer.
         const bool fuse = want_gn && d->gn_ticket != nullptr;

@@ -412,3 +412,22 @@ def test_bench_train_mode_reaches_the_gradient_exchange_at_world_2(tmp_path):
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["grad_sync_ok"] is True and line["grad_wire"] == "bf16" and line["scale"] == 0.5
     assert line["flat_gradient_floats"] > 60e6 and "dryrun" in line   # both nets' parameters in the flat buffers
+
+
+def test_hidden_register_loads_of_conv_wino4_are_only_touched_behind_a_wait(tmp_path):
+    """conv_wino4.hip (SPEC 2: GroupNorm/FiLM + SiLU prologue) requests its input patch with inline-asm buffer loads that hipcc does
+    not count: scripts/lint_asm_loads.py checks the generated ISA -- no instruction may name a destination register between the load
+    and a counted s_waitcnt of ours (a compiler copy or spill there would read a register whose data has not landed)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    asm = tmp_path / "conv_wino4.s"
+    src = os.path.join(ROOT, "instancediff_amd", "csrc", "conv_wino4.hip")
+    subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "--cuda-device-only", "-S", src, "-o", str(asm)],
+                   check=True, capture_output=True, timeout=900)
+    syms = sorted({ln.split(":")[0] for ln in asm.read_text().splitlines() if ln.startswith("_ZN") and "conv_wino4_kernelILi0ELi2E" in ln.split(":")[0] and ":" in ln})
+    assert len(syms) == 2, syms   # whole and partial patches
+    for sym in syms:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "lint_asm_loads.py"), str(asm), sym], capture_output=True, text=True)
+        assert r.returncode == 0 and "violations: 0" in r.stdout, r.stdout[-2000:]
+        assert "asm register loads: 0 " not in r.stdout   # the lint did see them

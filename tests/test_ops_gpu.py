@@ -572,7 +572,7 @@ def test_conv_winograd4_policy_and_fallback():
     _close(two, ref_big, 4e-5, "half-patch kernel, two sources")
     big3 = torch.randn(2, 32, 128, 128, generator=g).to(DEV)
     ops.conv2d(big3[:, :16].contiguous(), wpk, None, 3, 64, src1=big3[:, 16:].contiguous())
-    assert lib.idiff_conv2d_last_algo() == 4               # two-source layers take the half-patch kernel at every size
+    assert lib.idiff_conv2d_last_algo() == 3               # r04: from 16 items per sample up the 16x32 kernel, two sources or one
     big = torch.randn(3, 32, 128, 128, generator=g).to(DEV)   # 32 items per sample
     out = ops.conv2d(big, wpk, None, 3, 64)
     assert lib.idiff_conv2d_last_algo() == 3
