@@ -519,9 +519,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a, const Geo4& g
     bool young = false;  // the requests in flight were issued BEFORE an epilogue: its >= 16 stores are younger than they are
     for (int item = first; item < last; item += G) {
         TRACE_MARK(0)
-        floatx4 acc[36];
-#pragma unroll
-        for (int p = 0; p < 36; ++p) acc[p] = floatx4{0.f, 0.f, 0.f, 0.f};
+        floatx4 acc[36];  // started from C = 0 by the first chunk's MFMAs (no 144 v_mov per item)
         {
             // ONE barrier per chunk.  Chunk c runs its 9 position quads and, one slice per quad:
             //   transform position c+1 (slot r_t) -> V[(c+1)&1];  SPEC 2: activate position c+2 from its registers into slot r_a;
@@ -531,8 +529,9 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a, const Geo4& g
             floatx4 ob[2], oa[2];
             ob[0] = *reinterpret_cast<const floatx4*>(Vb + tblk * 256 + opoff);  // quad 0 of chunk 0
             oa[0] = *reinterpret_cast<const floatx4*>(Ub + cb * 256 + opoff);
-            auto chunk = [&](int cc, auto par_tag) {
+            auto chunk = [&](int cc, auto par_tag, auto zero_tag) {
                 constexpr int PAR = decltype(par_tag)::value;      // cc & 1: V / U buffers
+                constexpr bool ZERO = decltype(zero_tag)::value;   // the item's first chunk
                 const float* V = Vb + PAR * V_FLOATS + tblk * 256 + opoff;
                 const float* U = Ub + PAR * U_FLOATS + cb * 256 + opoff;
                 // Operand quads alternate between two register sets; the parity flips from chunk to chunk (9 quads), so quad 8 of
@@ -574,11 +573,12 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a, const Geo4& g
                         oa[PAR ^ 1] = *reinterpret_cast<const floatx4*>(Un);
                     }
                     const floatx4 bv = ob[(q + PAR) & 1], av = oa[(q + PAR) & 1];
-                    acc[4 * q + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[4 * q + 0], 0, 0, 0);
-                    acc[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[4 * q + 1], 0, 0, 0);
-                    acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[4 * q + 2], 0, 0, 0);
-                    acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[4 * q + 3], 0, 0, 0);
-                    if (cc != 0) {  // (chunk 0: U(1) was copied whole before the epilogue / by the fill)
+                    const floatx4 z4 = floatx4{0.f, 0.f, 0.f, 0.f};
+                    acc[4 * q + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, ZERO ? z4 : acc[4 * q + 0], 0, 0, 0);
+                    acc[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, ZERO ? z4 : acc[4 * q + 1], 0, 0, 0);
+                    acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, ZERO ? z4 : acc[4 * q + 2], 0, 0, 0);
+                    acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, ZERO ? z4 : acc[4 * q + 3], 0, 0, 0);
+                    if (!ZERO) {  // (chunk 0: U(1) was copied whole before the epilogue / by the fill)
                         if (q < 3) dma_u_piece(cc + 1, PAR ^ 1, q + 1);
                         if (q == 3 && !HEAVY) dma_u_piece(cc + 1, PAR ^ 1, 4);
                     }
@@ -609,9 +609,11 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a, const Geo4& g
                 const unsigned t = r_t;  // next chunk: transform what was activated, activate what has landed, land into the freed slot
                 r_t = r_a, r_a = r_x, r_x = t;
             };
-            for (int cc = 0; cc < nchunks; cc += 2) {
-                chunk(cc, std::integral_constant<int, 0>{});
-                chunk(cc + 1, std::integral_constant<int, 1>{});
+            chunk(0, std::integral_constant<int, 0>{}, std::true_type{});
+            chunk(1, std::integral_constant<int, 1>{}, std::false_type{});
+            for (int cc = 2; cc < nchunks; cc += 2) {
+                chunk(cc, std::integral_constant<int, 0>{}, std::false_type{});
+                chunk(cc + 1, std::integral_constant<int, 1>{}, std::false_type{});
             }
         }
         TRACE_MARK(1)

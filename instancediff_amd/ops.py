@@ -18,7 +18,7 @@ SDE_STEP, SDE_MEAN, SDE_ODE = 0, 1, 2
 # bench.py sets this to a list to time every conv launch with events on the launch stream (roofline leg)
 PROFILE = None
 # IDIFF_GN_FUSED=1: GroupNorm finalize as the tail of the producing conv launch (gn_tail.h) instead of a finalize launch behind it.
-# Off by default: 270 instead of 346 launches per step, but +0.45 ms per step at c2 (profiles/r03/x_gn_fused_finalize.txt).
+# Off by default: 270 instead of 346 launches per step, but +0.27 ms per step at c2 (profiles/r04/ab_gn_*.json).
 GN_FUSED = bool(int(os.environ.get("IDIFF_GN_FUSED", "0")))
 # tests set this to a collections.Counter: (algo, ks, Cin, Cout, Hout, Wout) -> calls, to assert which kernel served a layer
 ALGO_TRACE = None
