@@ -83,9 +83,10 @@ typedef struct {
                                Hout % 4 == 0, Wout % 4 == 0, Wout >= 24, Cin % 8 == 0, Cout % 16 == 0 and a sample has at
                                least 16 items of 16x32 pixels x 64 channels (4x fewer matrix-core flops than direct) */
     /* Optional GroupNorm finalize of `stats` behind this conv (gn_out_a != NULL; requires stats): the per-(sample, channel) affine
-       idiff_gn_finalize would compute, written by this call -- as the tail of the conv launch itself where the kernel supports it
-       (the F(4x4,3x3) kernels with gn_ticket set: the last workgroups to arrive reduce the partials, bit-identical to the separate
-       launch), otherwise by an idiff_gn_finalize launch enqueued behind the conv.  Arguments as idiff_gn_finalize. */
+       idiff_gn_finalize would compute, by an idiff_gn_finalize launch enqueued behind the conv by this call (one C call per conv +
+       finalize).  Arguments as idiff_gn_finalize.  (r03 / r04 also had the finalize as the TAIL of the F(4x4,3x3) launches -- last
+       arriving workgroups reducing the partials, bit-identical -- behind a `gn_ticket` field: measured slower in both rounds,
+       +0.78 ms per step on the r04 kernel, and removed) */
     const float* gn_gamma;
     const float* gn_beta;
     const float* gn_film;
@@ -95,10 +96,6 @@ typedef struct {
     float* gn_out_a;
     float* gn_out_b;
     float* gn_mean_rstd;    /* optional [B, groups, 2] */
-    uint32_t* gn_ticket;    /* 4 zero-initialised words owned by the LAYER (not shared with a conv that may run concurrently); the
-                               kernel leaves them zero again.  Non-NULL selects the finalize as the TAIL of the F(4x4,3x3) conv launch
-                               (gn_tail.h: the last-arriving workgroups reduce the partials; same bits as the separate launch);
-                               NULL, and kernels without the tail: the finalize launch enqueued behind the conv by this call */
     int32_t algo_request;   /* 0 = the library picks (by the layer's per-sample shape only, never by the batch); 1 + IDIFF_CONV_ALGO_x =
                                run exactly that kernel or fail with IDIFF_E_ARG if the shape does not tile for it (a per-call
                                request: profiling, parity tests of a kernel at small sizes; a request for the F(4x4,3x3) kernel

@@ -32,7 +32,7 @@ class ConvDesc(C.Structure):
         ("wwino", C.c_void_p),
         ("wwino4", C.c_void_p),
         ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p), ("gn_film", C.c_void_p), ("gn_film_ld", C.c_int64), ("gn_eps", C.c_float),
-        ("gn_groups", C.c_int32), ("gn_out_a", C.c_void_p), ("gn_out_b", C.c_void_p), ("gn_mean_rstd", C.c_void_p), ("gn_ticket", C.c_void_p),
+        ("gn_groups", C.c_int32), ("gn_out_a", C.c_void_p), ("gn_out_b", C.c_void_p), ("gn_mean_rstd", C.c_void_p),
         ("algo_request", C.c_int32),
         ("wx3", C.c_void_p),
     ]

@@ -4,7 +4,7 @@
 
 namespace idiff_detail {
 
-// GroupNorm finalize fused behind the launch that writes the partials (gn_tail.h); ticket == nullptr: not requested
+// arguments of the GroupNorm finalize that rides on a conv call (idiff_conv_desc.gn_*; the finalize is a launch behind the conv)
 struct GnTail {
     const float* gamma;
     const float* beta;
@@ -15,8 +15,6 @@ struct GnTail {
     float* out_a;
     float* out_b;
     float* mean_rstd;
-    unsigned* ticket;  // [4] zero-initialised words owned by the layer: arrivals, finalizers done, timeout flag, spare
-    unsigned max_finalizers;  // upper bound on the workgroups that stay for the finalize (they hold their CUs until the last arrival)
 };
 
 struct ConvArgs {

@@ -635,7 +635,6 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
                         "conv2d: GroupNorm finalize needs stats, gn_out_b and groups dividing Cout (<= 256 channels per group)");
         a.gn.gamma = d->gn_gamma, a.gn.beta = d->gn_beta, a.gn.film = d->gn_film, a.gn.film_ld = d->gn_film_ld, a.gn.eps = d->gn_eps;
         a.gn.groups = d->gn_groups, a.gn.out_a = d->gn_out_a, a.gn.out_b = d->gn_out_b, a.gn.mean_rstd = d->gn_mean_rstd;
-        a.gn.ticket = nullptr;  // set below for the kernels that finish the job themselves
     }
     // the separate finalize launch behind kernels without the fused tail
     auto finalize_after = [&](int rc) -> int {
@@ -742,25 +741,14 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
         else if (req4 && w4_ok) half = false;
         else if (items16 >= 16 && w4_ok) half = w4h_mode == 2 || (w4h_mode == 3 && a.src1 != nullptr);
         else half = w4h_mode >= 1 && items8 >= 16;
-        // The GroupNorm finalize as the tail of the conv launch (gn_tail.h) is opt-in per call: the caller passes a ticket buffer.
-        const bool fuse = want_gn && d->gn_ticket != nullptr;
-        static const unsigned gn_nfin = [] {  // IDIFF_GN_FINALIZERS: workgroups kept for the finalize (default 32)
-            const char* e = getenv("IDIFF_GN_FINALIZERS");
-            const int v = e ? atoi(e) : 32;
-            return (unsigned)(v < 1 ? 1 : v);
-        }();
-        if (fuse) a.gn.ticket = d->gn_ticket, a.gn.max_finalizers = gn_nfin;
         if (half) {
             g_last_algo = IDIFF_CONV_ALGO_WINOGRAD4H;
-            const int rc = idiff_detail::launch_conv_wino4h(a, d->mode, st);
-            return fuse ? rc : finalize_after(rc);
+            return finalize_after(idiff_detail::launch_conv_wino4h(a, d->mode, st));
         }
         if (w4_ok && (req4 || items16 >= 16)) {
             g_last_algo = IDIFF_CONV_ALGO_WINOGRAD4;
-            const int rc = idiff_detail::launch_conv_wino4(a, d->mode, st);
-            return fuse ? rc : finalize_after(rc);
+            return finalize_after(idiff_detail::launch_conv_wino4(a, d->mode, st));
         }
-        a.gn.ticket = nullptr;
     }
     IDIFF_CHECK_ARG(!hard || !(req4 || req4h), "conv2d: algo_request F(4x4,3x3) but the shape does not tile for it");
     if ((req == -1 || req == IDIFF_CONV_ALGO_WINOGRAD || !hard) && req != IDIFF_CONV_ALGO_DIRECT && idiff_detail::conv_wino_eligible(a, d->ks, d->mode)) {

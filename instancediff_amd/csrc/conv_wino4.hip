@@ -27,7 +27,6 @@
 #include <type_traits>
 
 #include "conv_args.h"
-#include "gn_tail.h"
 
 using idiff_detail::ConvArgs;
 
@@ -443,10 +442,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a, const Geo4& g
     const int G = gridDim.x;
     const int first = (int)xcd_remap(blockIdx.x, G);
     const int last = g.total;
-    if (first >= last) {  // no item for this workgroup (the launchers size the grid so that it cannot happen): it still arrives
-        if (a.gn.ticket) idiff_detail::gn_arrive_and_finalize(a, Rb);
-        return;
-    }
+    if (first >= last) return;  // (the launchers size the grid so that it cannot happen)
     auto fetch_consts = [&](const View& v) {  // an item's epilogue constants: threads 0..255 (= the heavy waves), one each
         float e = 0.f;
         if (HEAVY) {
@@ -662,7 +658,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a, const Geo4& g
             const bool has_res = a.res != nullptr && wave_live, has_aux = a.aux != nullptr && wave_live;
             const float* const stbase = a.stats ? a.stats + (((long long)b * a.ntiles + (ty0 >> 3) * a.tiles_x + (x0 >> 5)) * a.Cout + co0 + cb * 16) * 2 : a.out;
             const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(scalar_ptr(stbase)), 0, want_stats ? 0x7fffffff : 0, RSRC_FLAGS);
-            constexpr int AUX_SC1 = 1 << 4;  // write-through: the partials are read by another workgroup (gn_tail.h) / the next launch
+            constexpr int AUX_SC1 = 1 << 4;  // write-through
             // Phase 1: A^T along the Winograd columns v of every row u and channel r -- 144 accumulators shrink to 96 values
             // (the accumulators of a row die as soon as it is done, so the registers hold either form, never both).
             float zz[6][4][4];  // [u][r][dx]
@@ -758,7 +754,6 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a, const Geo4& g
         epar ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the null item's requests (answered with zeros) still target this workgroup's LDS
-    if (a.gn.ticket) idiff_detail::gn_arrive_and_finalize(a, Rb);  // GroupNorm finalize as the tail of this launch (gn_tail.h)
     TRACE_FINI
     SLOT_FINI
 }

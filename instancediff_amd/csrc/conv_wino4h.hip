@@ -29,7 +29,6 @@
 #include <type_traits>
 
 #include "conv_args.h"
-#include "gn_tail.h"
 
 using idiff_detail::ConvArgs;
 
@@ -289,10 +288,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int G = gridDim.x;
     const int first = (int)xcd_remap(blockIdx.x, G);
     const int last = g.total;
-    if (first >= last) {  // no item for this workgroup (the launchers size the grid so that it cannot happen): it still arrives
-        if (a.gn.ticket) idiff_detail::gn_arrive_and_finalize(a, Rb);
-        return;
-    }
+    if (first >= last) return;  // (the launchers size the grid so that it cannot happen)
     float pre_e = 0.f;
     auto fetch_consts = [&]() {
         const int which = tid >> 6, co = it_co0 + (tid & 63);
@@ -457,7 +453,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     if (!inside) ssum = 0.f, ssq = 0.f;
                     ssum = row_sum16(ssum);
                     ssq = row_sum16(ssq);
-                    if (j == 15) idiff_detail::gn_store_partial(stp + 2 * r, ssum, ssq);  // write-through: read by another workgroup (gn_tail.h)
+                    if (j == 15) stp[2 * r] = ssum, stp[2 * r + 1] = ssq;
                 }
                 const float add = ebase[64 + r];
                 float aa = 0.f, ab = 0.f;
@@ -478,7 +474,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             }
         }
     }
-    if (a.gn.ticket) idiff_detail::gn_arrive_and_finalize(a, Rb);  // GroupNorm finalize as the tail of this launch (gn_tail.h)
 }
 
 template <int MODE, int SPEC, bool RAG>

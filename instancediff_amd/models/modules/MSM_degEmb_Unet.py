@@ -449,25 +449,16 @@ class ResBlock(nn.Module):
         self.norm2 = nn.GroupNorm(groups, dim_out)
         self.res_conv = nn.Conv2d(dim_in, dim_out, 1) if dim_in != dim_out else nn.Identity()
 
-    def _tickets(self, device):
-        """arrival counters of the two fused GroupNorm finalizes (gn_tail.h): 2 x 4 zeroed words owned by this block, so that no
-        launch that may run concurrently (the other net on its stream) shares them; the kernels leave them zero"""
-        t = getattr(self, "_gn_tickets", None)
-        if t is None or t.device != device:
-            t = self._gn_tickets = torch.zeros((2, 4), dtype=torch.int32, device=device)
-        return t
-
     def run(self, src0, src1, film, vec=None, out=None):
         """conv3x3 -> GN -> FiLM -> SiLU -> conv3x3 -> GN -> SiLU, + res(src) [+ vec]; src = cat(src0, src1)."""
         B, _, H, W = src0.shape
         Co, G, HW = self.dim_out, self.groups, H * W
         # GroupNorm finalize (statistics -> per-(sample, channel) affine, FiLM folded in) rides on the conv that produces the statistics
-        # (one C call; the finalize is a launch enqueued behind the conv, or -- IDIFF_GN_FUSED=1 -- the tail of the conv launch itself)
-        tk = self._tickets(src0.device) if ops.GN_FUSED else (None, None)
+        # (one C call; the finalize is a launch enqueued behind the conv)
         h1, ab1 = ops.conv2d(src0, packed(self.conv1), self.conv1.bias, 3, Co, src1=src1,
-                             gn=dict(groups=G, gamma=self.norm1.weight, beta=self.norm1.bias, film=film, eps=self.norm1.eps, ticket=tk[0]))
+                             gn=dict(groups=G, gamma=self.norm1.weight, beta=self.norm1.bias, film=film, eps=self.norm1.eps))
         h2, (a2, b2) = ops.conv2d(h1, packed(self.conv2), self.conv2.bias, 3, Co, pro=ab1,
-                                  gn=dict(groups=G, gamma=self.norm2.weight, beta=self.norm2.bias, eps=self.norm2.eps, ticket=tk[1]))
+                                  gn=dict(groups=G, gamma=self.norm2.weight, beta=self.norm2.bias, eps=self.norm2.eps))
         if isinstance(self.res_conv, nn.Identity):
             assert src1 is None
             return ops.affine_silu_add(h2, (a2, b2), res=src0, vec=vec, out=out)

@@ -17,9 +17,6 @@ SDE_STEP, SDE_MEAN, SDE_ODE = 0, 1, 2
 
 # bench.py sets this to a list to time every conv launch with events on the launch stream (roofline leg)
 PROFILE = None
-# IDIFF_GN_FUSED=1: GroupNorm finalize as the tail of the producing conv launch (gn_tail.h) instead of a finalize launch behind it.
-# Off by default: 270 instead of 346 launches per step, but +0.27 ms per step at c2 (profiles/r04/ab_gn_*.json).
-GN_FUSED = bool(int(os.environ.get("IDIFF_GN_FUSED", "0")))
 # tests set this to a collections.Counter: (algo, ks, Cin, Cout, Hout, Wout) -> calls, to assert which kernel served a layer
 ALGO_TRACE = None
 
@@ -121,9 +118,9 @@ def conv2d(src0, wpk, bias, ks, Cout, src1=None, mode=CONV_NORMAL, pro=None, out
     """Implicit-GEMM conv.  pro=(a,b): per-(b,c) affine+SiLU applied to src0 while it is gathered;
     aux=(tensor,a,b): adds silu(a*tensor+b) in the epilogue.  Returns out or (out, stats).
     algo: None = the library picks; CONV_ALGO_x = that kernel or an error (idiff_conv_desc.algo_request).
-    gn = dict(groups, gamma, beta, film=None, eps=1e-5, ticket=None, want_mean_rstd=False): the GroupNorm(+FiLM) finalize of this conv's
-    statistics rides on the call (as the tail of the conv launch where the kernel supports it and `ticket` -- 4 zeroed int32 words
-    owned by the layer -- is given, else as a finalize launch enqueued by the library): returns (out, (a, b)) or (out, (a, b, mean_rstd))."""
+    gn = dict(groups, gamma, beta, film=None, eps=1e-5, want_mean_rstd=False): the GroupNorm(+FiLM) finalize of this conv's
+    statistics rides on the call (a finalize launch enqueued by the library behind the conv): returns (out, (a, b)) or
+    (out, (a, b, mean_rstd))."""
     lib = _lib.load()
     B, C0, Hin, Win = src0.shape
     d = ConvDesc()
@@ -201,10 +198,6 @@ def conv2d(src0, wpk, bias, ks, Cout, src1=None, mode=CONV_NORMAL, pro=None, out
             assert tuple(mr.shape) == (B, d.gn_groups, 2) and mr.is_contiguous()
             d.gn_mean_rstd = mr.data_ptr()
             gn_out = (ga, gb, mr)
-        tk = gn.get("ticket")
-        if tk is not None:
-            assert tk.dtype == torch.int32 and tk.numel() >= 4 and tk.is_cuda and tk.is_contiguous()
-            d.gn_ticket = tk.data_ptr()
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

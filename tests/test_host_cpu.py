@@ -431,3 +431,34 @@ def test_hidden_register_loads_of_conv_wino4_are_only_touched_behind_a_wait(tmp_
         r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "lint_asm_loads.py"), str(asm), sym], capture_output=True, text=True)
         assert r.returncode == 0 and "violations: 0" in r.stdout, r.stdout[-2000:]
         assert "asm register loads: 0 " not in r.stdout   # the lint did see them
+
+
+def test_pointer_rebuilt_from_a_signed_low_half_breaks_when_bit_31_is_set():
+    """The arithmetic of the r03 GPU abort: __builtin_amdgcn_readfirstlane returns int; `(u64)hi << 32 | lo` with
+    lo still an int converts lo to 64 bits by SIGN extension, so a wave-uniform pointer rebuilt that way for a buffer resource gets
+    0xffff.... as its upper half whenever bit 31 of the address is set.  Every such rebuild in csrc/ goes through `unsigned`
+    (scalar_ptr); this pins the lesson, and a source check keeps the pattern out."""
+    import glob
+    import re
+
+    import numpy as np
+
+    def rebuild_r03(addr):
+        lo = np.int32(np.uint32(addr & 0xffffffff))
+        hi = np.int32(np.uint32(addr >> 32))
+        v = (np.uint64(np.uint32(hi)) << np.uint64(32)) | np.uint64(np.int64(lo))   # usual arithmetic conversions: int -> u64
+        return int(v) & 0xffffffffffff                                                # 48-bit base of a buffer resource
+
+    def rebuild_fixed(addr):
+        lo, hi = np.uint32(addr & 0xffffffff), np.uint32(addr >> 32)
+        return int((np.uint64(hi) << np.uint64(32)) | np.uint64(lo)) & 0xffffffffffff
+    clear, set_ = 0x7f2a_1234_5600, 0x7f2a_9234_5600
+    assert rebuild_r03(clear) == clear and rebuild_r03(set_) == 0xffff_9234_5600 != set_
+    assert rebuild_fixed(clear) == clear and rebuild_fixed(set_) == set_
+    # no kernel source ORs a readfirstlane result into a wider value without going through an unsigned variable first
+    bad = []
+    for path in glob.glob(os.path.join(ROOT, "instancediff_amd", "csrc", "*.h*")):
+        for n, line in enumerate(open(path), 1):
+            if re.search(r"<<\s*32\)?\s*\|\s*__builtin_amdgcn_readfirstlane", line) or re.search(r"\(unsigned long long\)\s*__builtin_amdgcn_readfirstlane", line):
+                bad.append(f"{os.path.basename(path)}:{n}")
+    assert not bad, bad

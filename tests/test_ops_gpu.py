@@ -643,20 +643,19 @@ def test_conv_winograd4_bits_do_not_depend_on_the_batch(force_wino4):
 
 
 @pytest.mark.parametrize("B,C0,C1,Cout,H,W,G,film,pro,algo", [
-    (16, 64, 0, 64, 64, 64, 8, True, False, None),    # half-patch kernel by the library's choice; 128 pairs, 256 workgroups
-    (16, 64, 0, 64, 64, 64, 8, True, False, 3),       # the same on the 16x32-item kernel (128 workgroups = 128 finalizers)
+    (16, 64, 0, 64, 64, 64, 8, True, False, None),    # half-patch kernel by the library's choice
+    (16, 64, 0, 64, 64, 64, 8, True, False, 3),       # the same on the 16x32-item kernel
     (3, 64, 0, 64, 128, 128, 8, False, True, None),   # 16x32-item kernel, prologue instantiation
     (2, 32, 48, 128, 32, 64, 8, True, False, None),   # two sources: half-patch kernel, 2 workgroups per CU
     (5, 128, 0, 256, 32, 32, 8, True, False, None),   # half-patch kernel below 16 items of 16x32 per sample
-    (1, 16, 0, 32, 28, 28, 8, False, False, 4),       # 4 workgroups, 8 (sample, group) pairs: a finalizer takes several pairs
+    (1, 16, 0, 32, 28, 28, 8, False, False, 4),       # 4 workgroups, 8 (sample, group) pairs
     (1, 16, 0, 32, 28, 28, 4, False, False, None),    # F(2x2,3x3): the library enqueues the separate finalize launch
     (2, 16, 0, 32, 16, 16, 8, True, False, None),     # direct kernel: likewise
 ])
-def test_conv_groupnorm_finalize_fused_equals_separate_launch(B, C0, C1, Cout, H, W, G, film, pro, algo):
-    """idiff_conv_desc.gn_*: the GroupNorm(+FiLM) finalize riding on the conv call gives the SAME BITS as idiff_gn_finalize on the conv's
-    statistics, launch after launch, with and without a ticket.  A ticket selects the fused tail of the F(4x4,3x3) kernels (the
-    last-arriving workgroups reduce the partials, gn_tail.h; the arrival counters clean themselves); kernels without the tail, and
-    calls without a ticket, get the finalize launch enqueued by the library: the assertions are the same either way."""
+def test_conv_groupnorm_finalize_riding_on_the_conv_call_equals_separate_launch(B, C0, C1, Cout, H, W, G, film, pro, algo):
+    """idiff_conv_desc.gn_*: the GroupNorm(+FiLM) finalize riding on the conv call (one C call: the library enqueues the finalize
+    launch behind whichever conv kernel it picked) gives the SAME BITS as idiff_gn_finalize on the conv's statistics, launch after
+    launch.  (r03 / r04 also ran the finalize as the tail of the F(4x4,3x3) launches; removed as slower -- DESIGN.md section 8.)"""
     lib = ops._lib.load()
     g = _g(500 + B + Cout)
     x0 = torch.randn(B, C0, H, W, generator=g).to(DEV)
@@ -672,81 +671,14 @@ def test_conv_groupnorm_finalize_fused_equals_separate_launch(B, C0, C1, Cout, H
     out_ref, st = ops.conv2d(x0, wp, bias, 3, Cout, want_stats=True, **kw)
     algo = lib.idiff_conv2d_last_algo()
     a_ref, b_ref, mr_ref = ops.gn_finalize(st, G, H * W, gamma, beta, film=fl, eps=1e-5, want_mean_rstd=True)
-    ticket = torch.zeros(4, dtype=torch.int32, device=DEV)
     for rep in range(3):
-        out, (a, b, mr) = ops.conv2d(x0, wp, bias, 3, Cout, gn=dict(groups=G, gamma=gamma, beta=beta, film=fl, eps=1e-5, ticket=ticket,
-                                                                        want_mean_rstd=True), **kw)
+        out, (a, b, mr) = ops.conv2d(x0, wp, bias, 3, Cout, gn=dict(groups=G, gamma=gamma, beta=beta, film=fl, eps=1e-5, want_mean_rstd=True), **kw)
         assert lib.idiff_conv2d_last_algo() == algo
         assert torch.equal(out, out_ref)
         assert torch.equal(a, a_ref) and torch.equal(b, b_ref) and torch.equal(mr, mr_ref), (rep, algo)
-        assert ticket.tolist() == [0, 0, 0, 0], (rep, ticket.tolist())   # counters back to zero, no timeout flag
-    out, (a, b) = ops.conv2d(x0, wp, bias, 3, Cout, gn=dict(groups=G, gamma=gamma, beta=beta, film=fl, eps=1e-5), **kw)   # no ticket
+    out, (a, b) = ops.conv2d(x0, wp, bias, 3, Cout, gn=dict(groups=G, gamma=gamma, beta=beta, film=fl, eps=1e-5), **kw)
     assert torch.equal(a, a_ref) and torch.equal(b, b_ref)
-    print(f"conv algo {algo}: fused finalize == separate launch (bitwise), B={B} Cout={Cout} {H}x{W}")
-
-
-@pytest.mark.parametrize("algo", [None, 3])
-def test_conv_groupnorm_fused_tail_addresses_with_bit31_set_and_guard_bands(algo):
-    """The r03 abort of the fused tail, pinned.  gn_tail.h rebuilt the partials row address for a buffer resource as
-    (u64)readfirstlane(hi) << 32 | readfirstlane(lo) with the builtin's int result, which sign-extends the low half: any row address
-    with bit 31 set got 0xffff in its upper 16 bits -> "Memory access fault by GPU", or not, by where the caching allocator happened
-    to put `stats`.  Here every buffer the tail touches is placed by the test inside one 4-GiB-plus arena, once
-    with bit 31 of the statistics address clear and once with it set, between guard bands holding a canary: results must equal the
-    separate finalize launch bit for bit and no canary may change."""
-    lib = ops._lib.load()
-    B, C0, Cout, H, W, G = 16, 64, 64, 64, 64, 8
-    g = _g(77)
-    x0 = torch.randn(B, C0, H, W, generator=g).to(DEV)
-    w = (torch.randn(Cout, C0, 3, 3, generator=g) / math.sqrt(9 * C0)).to(DEV)
-    bias = torch.randn(Cout, generator=g).to(DEV)
-    gamma, beta = torch.randn(Cout, generator=g).to(DEV), torch.randn(Cout, generator=g).to(DEV)
-    wp = ops.pack_conv_weight(w)
-    nt = lib.idiff_conv2d_num_tiles(H, W)
-    arena = torch.empty((1 << 32) + (64 << 20), dtype=torch.uint8, device=DEV)
-    base = arena.data_ptr()
-    GUARD = 4096
-    CANARY = 0x5A
-
-    def place(off, shape, dtype=torch.float32):
-        n = int(torch.tensor(shape).prod()) * 4
-        t = arena[off:off + n].view(dtype).view(shape)
-        return t, off + n + GUARD
-
-    for want_bit31 in (False, True):
-        # first 1-MiB-aligned offset whose address has bit 31 as wanted and 16 MiB of room inside the same 2-GiB stripe
-        off = 1 << 20
-        while ((((base + off) >> 31) & 1) == 1) != want_bit31 or ((((base + off + (16 << 20)) >> 31) & 1) == 1) != want_bit31:
-            off += 1 << 20
-        start = off - GUARD
-        stats, off = place(off, (B, nt, Cout, 2))
-        ga, off = place(off, (B, Cout))
-        gb, off = place(off, (B, Cout))
-        mr, off = place(off, (B, G, 2))
-        film_full, off = place(off, (B, 2 * Cout + 8))
-        ticket, off = place(off, (4,), torch.int32)
-        end = off
-        assert ((stats.data_ptr() >> 31) & 1) == int(want_bit31)
-        arena[start:end].fill_(CANARY)
-        film_full.copy_((torch.randn(B, 2 * Cout + 8, generator=g) * 0.3).to(DEV))
-        fl = film_full[:, :2 * Cout]   # row-strided, as the UNet's films are
-        ticket.zero_()
-        out_ref, st = ops.conv2d(x0, wp, bias, 3, Cout, want_stats=True, algo=algo)
-        a_ref, b_ref, mr_ref = ops.gn_finalize(st, G, H * W, gamma, beta, film=fl, eps=1e-5, want_mean_rstd=True)
-        for rep in range(2):
-            out, (a, b, m) = ops.conv2d(x0, wp, bias, 3, Cout, algo=algo,
-                                        gn=dict(groups=G, gamma=gamma, beta=beta, film=fl, eps=1e-5, ticket=ticket, want_mean_rstd=True,
-                                                bufs=(stats, ga, gb, mr)))
-            assert lib.idiff_conv2d_last_algo() in (ops.CONV_ALGO_WINOGRAD4, ops.CONV_ALGO_WINOGRAD4H)
-            assert torch.equal(out, out_ref) and torch.equal(stats, st)
-            assert torch.equal(a, a_ref) and torch.equal(b, b_ref) and torch.equal(m, mr_ref), (want_bit31, rep)
-            assert ticket.tolist() == [0, 0, 0, 0], (want_bit31, rep, ticket.tolist())
-        # guard bands: everything between the placed tensors still holds the canary
-        mask = torch.ones(end - start, dtype=torch.bool, device=DEV)
-        for t in (stats, ga, gb, mr, film_full, ticket):
-            o = t.data_ptr() - base - start
-            mask[o:o + t.numel() * 4] = False
-        assert bool((arena[start:end][mask] == CANARY).all()), ("guard band overwritten", want_bit31)
-        print(f"fused tail, stats at {stats.data_ptr():#x} (bit 31 {'set' if want_bit31 else 'clear'}): bitwise equal, guard bands intact")
+    print(f"conv algo {algo}: finalize on the conv call == separate launch (bitwise), B={B} Cout={Cout} {H}x{W}")
 
 
 # ---- 1x1 conv on the bf16 matrix cores, fp32 operands split three ways (csrc/conv1x1_x3.hip) ------------------------------------------
