@@ -355,6 +355,11 @@ int idiff_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, idiff_str
 int idiff_philox_raw(uint32_t* out, int64_t ncounters, uint64_t seed, uint64_t offset, idiff_stream_t stream);
 /* out = alpha*x + beta*y */
 int idiff_axpby(const float* x, const float* y, float* out, int64_t n, float alpha, float beta, idiff_stream_t stream);
+/* Many tensors -> one flat buffer in one launch (replaces the per-parameter gradient accumulate / copy launches of
+ * torch.autograd's AccumulateGrad + optimizer packing; models/drift_noise_model.py:292-296 semantics unchanged).  segs_dev: device
+ * array of nseg records {const float* src (NULL = zero fill); int64 dst_offset; int64 n; int64 first_block}, first_block = running
+ * sum of ceil(n / 4096), ascending; nblocks = its total. */
+int idiff_gather_segments(const void* segs_dev, int nseg, int64_t nblocks, float* dst, idiff_stream_t stream);
 /* forward marginals with per-sample coefficients (training-state samplers):
  *   out[b,:] = c0[b]*x0[b,:] + c1[b]*cond[b,:] + c2[b]*eps[b,:]      (driftSDE.forward_diffusion, IRSDE.generate_random_states) */
 int idiff_mix3_per_sample(const float* x0, const float* cond, const float* eps, const float* c0, const float* c1,
@@ -384,12 +389,14 @@ int idiff_batch_sum(const float* in_bc, float* out_c, int B, int C, int accumula
 
 /* Backward of y = silu(a[b,c]*h + b[b,c]) with (a,b) = idiff_gn_finalize(stats(h), gamma, beta, film): gradient
  * w.r.t. h THROUGH the GroupNorm statistics, dgamma/dbeta [C], dfilm [B,2C] (scale | shift).  a, b, mean_rstd as
- * produced by idiff_gn_finalize.  ws: idiff_gn_silu_bwd_ws_floats(B,C,groups) floats. */
+ * produced by idiff_gn_finalize.  ws: idiff_gn_silu_bwd_ws_floats(B,C,groups) floats.  Optional, from the same reads (no pass of
+ * their own): dh_sum [C] = sum over samples and pixels of dh (the bias gradient of the conv that produced h), dy_sum [B,C] = sum
+ * over pixels of dy (the gradient of a per-(sample, channel) vector added behind the activation); NULL = not wanted. */
 int64_t idiff_gn_silu_bwd_ws_floats(int B, int C, int groups);
 int idiff_gn_silu_bwd(const float* dy, int64_t dy_bstride, const float* h, int64_t h_bstride, const float* a, const float* b,
                       const float* mean_rstd, const float* gamma, const float* beta, const float* film, int64_t film_ld,
                       float* dh, int64_t dh_bstride, float* dgamma, float* dbeta, float* dfilm, int64_t dfilm_ld, float* ws,
-                      int B, int C, int groups, int HW, int accumulate, idiff_stream_t stream);
+                      int B, int C, int groups, int HW, int accumulate, float* dh_sum, float* dy_sum, idiff_stream_t stream);
 
 /* elementwise activations (token side) and their gradients: dx = dy * act'(x) */
 int idiff_act_fwd(const float* x, float* y, int64_t n, int act, idiff_stream_t stream);

@@ -105,8 +105,9 @@ SIGNATURES = {
     "idiff_pixel_shuffle2": (I, [P, P, I, I, I, I, c_stream]),
     "idiff_plane_sum": (I, [P, I64, P, I, I, I, c_stream]),
     "idiff_batch_sum": (I, [P, P, I, I, I, c_stream]),
+    "idiff_gather_segments": (I, [P, I, I64, P, c_stream]),
     "idiff_gn_silu_bwd_ws_floats": (I64, [I, I, I]),
-    "idiff_gn_silu_bwd": (I, [P, I64, P, I64, P, P, P, P, P, P, I64, P, I64, P, P, P, I64, P, I, I, I, I, I, c_stream]),
+    "idiff_gn_silu_bwd": (I, [P, I64, P, I64, P, P, P, P, P, P, I64, P, I64, P, P, P, I64, P, I, I, I, I, I, P, P, c_stream]),
     "idiff_act_fwd": (I, [P, P, I64, I, c_stream]),
     "idiff_act_bwd": (I, [P, P, P, I64, I, c_stream]),
     "idiff_colsum": (I, [P, I64, P, I, I, I, c_stream]),

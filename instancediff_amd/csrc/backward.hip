@@ -63,68 +63,89 @@ __device__ __forceinline__ float silu_grad(float z) {
     return sg * (1.0f + z * (1.0f - sg));
 }
 
-// GroupNorm(+FiLM)+SiLU backward, pass 1: per (b,c)  S1 = sum dz,  S2 = sum dz*xhat,  dz = dy*silu'(a*h+b)
+// GroupNorm(+FiLM)+SiLU backward, pass 1: per (b,c)  S1 = sum dz,  S2 = sum dz*xhat,  dz = dy*silu'(a*h+b); and, from the same reads,
+// S3 = sum (h - mean) and S0 = sum dy: with them the plane sums of dh (the bias gradient of the conv that produced h) and of dy (the
+// gradient of a per-(sample, channel) vector added behind the activation) need no pass of their own
 __global__ __launch_bounds__(256) void gn_silu_bwd_reduce_kernel(const float* __restrict__ dy, long long dybs, const float* __restrict__ h,
                                                                  long long hbs, const float* __restrict__ a, const float* __restrict__ bc,
-                                                                 const float* __restrict__ mean_rstd, float* __restrict__ s12, int C, int groups,
+                                                                 const float* __restrict__ mean_rstd, float* __restrict__ s4, int C, int groups,
                                                                  int HW) {
-    __shared__ float red[2][4];
+    __shared__ float red[4][4];
     const int b = blockIdx.x / C, c = blockIdx.x % C;
     const int g = c / (C / groups);
     const float mean = mean_rstd[((long long)b * groups + g) * 2], rstd = mean_rstd[((long long)b * groups + g) * 2 + 1];
     const float aa = a[blockIdx.x], bb = bc[blockIdx.x];
     const float* dp = dy + (long long)b * dybs + (long long)c * HW;
     const float* hp = h + (long long)b * hbs + (long long)c * HW;
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f, s0 = 0.f;
     for (int i = threadIdx.x; i < HW; i += 256) {
-        const float hv = hp[i];
-        const float dz = dp[i] * silu_grad(aa * hv + bb);
+        const float hv = hp[i], dv = dp[i];
+        const float dz = dv * silu_grad(aa * hv + bb);
         s1 += dz;
         s2 += dz * (hv - mean) * rstd;
+        s3 += hv - mean;
+        s0 += dv;
     }
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
+    s3 = wave_sum(s3);
+    s0 = wave_sum(s0);
     if ((threadIdx.x & 63) == 0) {
         red[0][threadIdx.x >> 6] = s1;
         red[1][threadIdx.x >> 6] = s2;
+        red[2][threadIdx.x >> 6] = s3;
+        red[3][threadIdx.x >> 6] = s0;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        s12[blockIdx.x * 2] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-        s12[blockIdx.x * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-    }
+    if (threadIdx.x < 4) s4[blockIdx.x * 4 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
-// pass 2 (tiny): group means A, Bq per (b,g); dgamma/dbeta (sum over b, fixed order); dfilm [B,2C]
-__global__ void gn_bwd_finalize_kernel(const float* __restrict__ s12, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                       const float* __restrict__ film, long long film_ld, float* __restrict__ ab, float* __restrict__ gbc,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dfilm, long long dfilm_ld, int B,
+// pass 2 (tiny): group means A, Bq per (b,g); dgamma/dbeta (sum over b, fixed order); dfilm [B,2C]; optionally the plane sums
+// dh_sum[c] = sum_{b,pixels} dh = sum_b rstd (g S1 - HW A - rstd Bq S3)  and  dy_sum[b,c] = S0
+__global__ void gn_bwd_finalize_kernel(const float* __restrict__ s4, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       const float* __restrict__ film, long long film_ld, const float* __restrict__ mean_rstd,
+                                       float* __restrict__ ab, float* __restrict__ gbc, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ dfilm, long long dfilm_ld, float* __restrict__ dh_sum, float* __restrict__ dy_sum, int B,
                                        int C, int groups, int HW, int accumulate) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int cpg = C / groups;
-    if (tid < B * groups) {  // group means
-        const int b = tid / groups, g = tid % groups;
+    auto group_means = [&](int b, int g, float& A, float& Bq) {
         float sa = 0.f, sb = 0.f;
         for (int i = 0; i < cpg; ++i) {
             const int c = g * cpg + i;
             const float sc = film ? 1.f + film[(long long)b * film_ld + c] : 1.f;
             const float gg = sc * (gamma ? gamma[c] : 1.f);
-            sa += gg * s12[((long long)b * C + c) * 2];
-            sb += gg * s12[((long long)b * C + c) * 2 + 1];
+            sa += gg * s4[((long long)b * C + c) * 4];
+            sb += gg * s4[((long long)b * C + c) * 4 + 1];
         }
         const float inv = 1.0f / ((float)cpg * (float)HW);
-        ab[tid * 2] = sa * inv;
-        ab[tid * 2 + 1] = sb * inv;
+        A = sa * inv, Bq = sb * inv;
+    };
+    if (tid < B * groups) {  // group means
+        float A, Bq;
+        group_means(tid / groups, tid % groups, A, Bq);
+        ab[tid * 2] = A;
+        ab[tid * 2 + 1] = Bq;
     }
     if (tid < C) {  // parameter gradients
-        float dg = 0.f, db = 0.f;
+        float dg = 0.f, db = 0.f, dhs = 0.f;
+        const int g = tid / cpg;
         for (int b = 0; b < B; ++b) {
             const float sc = film ? 1.f + film[(long long)b * film_ld + tid] : 1.f;
-            dg += sc * s12[((long long)b * C + tid) * 2 + 1];
-            db += sc * s12[((long long)b * C + tid) * 2];
+            const float S1 = s4[((long long)b * C + tid) * 4], S2 = s4[((long long)b * C + tid) * 4 + 1];
+            dg += sc * S2;
+            db += sc * S1;
+            if (dh_sum) {
+                float A, Bq;
+                group_means(b, g, A, Bq);
+                const float rstd = mean_rstd[((long long)b * groups + g) * 2 + 1];
+                const float gg = sc * (gamma ? gamma[tid] : 1.f);
+                dhs += rstd * (gg * S1 - (float)HW * A - rstd * Bq * s4[((long long)b * C + tid) * 4 + 2]);
+            }
         }
         if (dgamma) dgamma[tid] = accumulate ? dgamma[tid] + dg : dg;
         if (dbeta) dbeta[tid] = accumulate ? dbeta[tid] + db : db;
+        if (dh_sum) dh_sum[tid] = dhs;
     }
     if (tid < B * C) {  // per-(b,c) scale used by the apply pass, and FiLM gradients
         const int b = tid / C, c = tid % C;
@@ -132,9 +153,10 @@ __global__ void gn_bwd_finalize_kernel(const float* __restrict__ s12, const floa
         const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
         gbc[tid] = sc * ga;
         if (dfilm) {
-            dfilm[(long long)b * dfilm_ld + c] = ga * s12[tid * 2 + 1] + be * s12[tid * 2];  // d scale
-            dfilm[(long long)b * dfilm_ld + C + c] = s12[tid * 2];                           // d shift
+            dfilm[(long long)b * dfilm_ld + c] = ga * s4[tid * 4 + 1] + be * s4[tid * 4];  // d scale
+            dfilm[(long long)b * dfilm_ld + C + c] = s4[tid * 4];                          // d shift
         }
+        if (dy_sum) dy_sum[tid] = s4[tid * 4 + 3];
     }
 }
 
@@ -443,17 +465,17 @@ extern "C" int idiff_batch_sum(const float* in_bc, float* out_c, int B, int C, i
 extern "C" int idiff_gn_silu_bwd(const float* dy, int64_t dy_bstride, const float* h, int64_t h_bstride, const float* a, const float* b,
                                  const float* mean_rstd, const float* gamma, const float* beta, const float* film, int64_t film_ld, float* dh,
                                  int64_t dh_bstride, float* dgamma, float* dbeta, float* dfilm, int64_t dfilm_ld, float* ws, int B, int C,
-                                 int groups, int HW, int accumulate, idiff_stream_t stream) {
+                                 int groups, int HW, int accumulate, float* dh_sum, float* dy_sum, idiff_stream_t stream) {
     IDIFF_CHECK_ARG(dy && h && a && b && mean_rstd && dh && ws, "gn_silu_bwd: null pointer");
     IDIFF_CHECK_ARG(B > 0 && C > 0 && groups > 0 && C % groups == 0 && HW > 0, "gn_silu_bwd: bad dims");
-    float* s12 = ws;                       // [B*C*2]
-    float* ab = ws + (size_t)B * C * 2;    // [B*groups*2]
+    float* s4 = ws;                        // [B*C*4]
+    float* ab = ws + (size_t)B * C * 4;    // [B*groups*2]
     float* gbc = ab + (size_t)B * groups * 2;  // [B*C]
     hipLaunchKernelGGL(gn_silu_bwd_reduce_kernel, dim3(B * C), dim3(256), 0, ST, dy, (long long)dy_bstride, h, (long long)h_bstride, a, b,
-                       mean_rstd, s12, C, groups, HW);
+                       mean_rstd, s4, C, groups, HW);
     IDIFF_CHECK_LAUNCH("gn_silu_bwd_reduce");
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, ST, s12, gamma, beta, film, (long long)film_ld, ab, gbc,
-                       dgamma, dbeta, dfilm, (long long)dfilm_ld, B, C, groups, HW, accumulate);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, ST, s4, gamma, beta, film, (long long)film_ld, mean_rstd,
+                       ab, gbc, dgamma, dbeta, dfilm, (long long)dfilm_ld, dh_sum, dy_sum, B, C, groups, HW, accumulate);
     IDIFF_CHECK_LAUNCH("gn_bwd_finalize");
     int gx = (HW + 1023) / 1024;
     if (gx < 1) gx = 1;
@@ -463,7 +485,7 @@ extern "C" int idiff_gn_silu_bwd(const float* dy, int64_t dy_bstride, const floa
     IDIFF_CHECK_LAUNCH("gn_silu_bwd_apply");
     return IDIFF_OK;
 }
-extern "C" int64_t idiff_gn_silu_bwd_ws_floats(int B, int C, int groups) { return (int64_t)B * C * 3 + (int64_t)B * groups * 2; }
+extern "C" int64_t idiff_gn_silu_bwd_ws_floats(int B, int C, int groups) { return (int64_t)B * C * 5 + (int64_t)B * groups * 2; }
 
 extern "C" int idiff_act_fwd(const float* x, float* y, int64_t n, int act, idiff_stream_t stream) {
     IDIFF_CHECK_ARG(x && y && n > 0 && (act == IDIFF_ACT_SILU || act == IDIFF_ACT_GELU), "act_fwd: bad args");

@@ -481,3 +481,37 @@ extern "C" int idiff_bf16_to_f32(const uint16_t* x, float* out, int64_t n, idiff
     IDIFF_CHECK_LAUNCH("bf16_to_f32");
     return IDIFF_OK;
 }
+
+// ---- many tensors -> one flat buffer in ONE launch (the optimizer's flat gradient buffer from the per-parameter gradients autograd
+// produced: replaces one accumulate / copy launch per parameter tensor).  Segment table on the device: {src (NULL = zeros), dst
+// offset, n, first block}; a block finds its segment by binary search over the first-block column and moves 4096 elements.
+struct idiff_gather_seg {
+    const float* src;
+    long long dst;
+    long long n;
+    long long blk0;
+};
+__global__ __launch_bounds__(256) void gather_segments_kernel(const idiff_gather_seg* __restrict__ segs, int nseg, float* __restrict__ dst) {
+    int lo = 0, hi = nseg - 1;
+    const long long blk = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (segs[mid].blk0 <= blk) lo = mid;
+        else hi = mid - 1;
+    }
+    const idiff_gather_seg sg = segs[lo];
+    const long long i0 = (blk - sg.blk0) * 4096;
+    const long long i1 = i0 + 4096 < sg.n ? i0 + 4096 : sg.n;
+    float* d = dst + sg.dst;
+    if (sg.src) {
+        for (long long i = i0 + threadIdx.x; i < i1; i += 256) d[i] = sg.src[i];
+    } else {
+        for (long long i = i0 + threadIdx.x; i < i1; i += 256) d[i] = 0.f;
+    }
+}
+extern "C" int idiff_gather_segments(const void* segs_dev, int nseg, int64_t nblocks, float* dst, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(segs_dev && dst && nseg > 0 && nblocks > 0 && nblocks < (1ll << 31), "gather_segments: bad args");
+    hipLaunchKernelGGL(gather_segments_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, static_cast<const idiff_gather_seg*>(segs_dev), nseg, dst);
+    IDIFF_CHECK_LAUNCH("gather_segments");
+    return IDIFF_OK;
+}

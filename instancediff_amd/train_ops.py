@@ -83,19 +83,33 @@ def pixel_shuffle2(x):
     return out
 
 
-def gn_silu_bwd(dy, h, a, b, mean_rstd, gamma, beta, film, groups):
-    """-> dh, dgamma, dbeta, dfilm (or None)"""
+def gn_silu_bwd(dy, h, a, b, mean_rstd, gamma, beta, film, groups, want_sums=False):
+    """-> dh, dgamma, dbeta, dfilm (or None) [, dh_sum [C], dy_sum [B,C]]: with want_sums the plane sums of dh (bias gradient of the conv
+    that produced h) and of dy come out of the same passes (no plane_sum launch over either tensor)"""
     lib = _lib.load()
     B, Cc, H, W = h.shape
     dh = torch.empty((B, Cc, H, W), device=h.device, dtype=torch.float32)
     dgamma = torch.empty((Cc,), device=h.device, dtype=torch.float32)
     dbeta = torch.empty_like(dgamma)
     dfilm = torch.empty((B, 2 * Cc), device=h.device, dtype=torch.float32) if film is not None else None
+    dh_sum = torch.empty((Cc,), device=h.device, dtype=torch.float32) if want_sums else None
+    dy_sum = torch.empty((B, Cc), device=h.device, dtype=torch.float32) if want_sums else None
     ws = torch.empty((lib.idiff_gn_silu_bwd_ws_floats(B, Cc, groups),), device=h.device, dtype=torch.float32)
     check(lib.idiff_gn_silu_bwd(_p(dy), _bs(dy, "dy"), _p(h), _bs(h, "h"), _p(_c(a)), _p(_c(b)), _p(_c(mean_rstd)), _p(_c(gamma)), _p(_c(beta)),
                                 _p(film), film.stride(0) if film is not None else 0, _p(dh), _bs(dh), _p(dgamma), _p(dbeta), _p(dfilm),
-                                2 * Cc, _p(ws), B, Cc, groups, H * W, 0, _stream()), "gn_silu_bwd")
+                                2 * Cc, _p(ws), B, Cc, groups, H * W, 0, _p(dh_sum), _p(dy_sum), _stream()), "gn_silu_bwd")
+    if want_sums:
+        return dh, dgamma, dbeta, dfilm, dh_sum, dy_sum
     return dh, dgamma, dbeta, dfilm
+
+
+def batch_sum(bc):
+    """[B,C] -> [C] (fixed order over b)"""
+    lib = _lib.load()
+    B, Cc = bc.shape
+    out = torch.empty((Cc,), device=bc.device, dtype=torch.float32)
+    check(lib.idiff_batch_sum(_p(_c(bc)), _p(out), B, Cc, 0, _stream()), "batch_sum")
+    return out
 
 
 def bgemm(A, B, M, N, K, lda, ldb, transA, transB, sA, sB, batch, out=None, alpha=1.0, beta=0.0):
@@ -177,14 +191,14 @@ class ResBlockFn(torch.autograd.Function):
         Co = w1.shape[0]
         C0 = src0.shape[1]
         Cin = w1.shape[1]
-        dvec = channel_sums(dout, per_sample=True) if ctx.has_vec else None
         # tail: out = silu(a2*h2+c2) + res(x) + vec
-        dh2, dg2, dbe2, _ = gn_silu_bwd(dout, h2, a2, c2, mr2, g2, be2, None, G)
-        db2 = channel_sums(dh2)
+        # the bias gradients (plane sums of dh2 / dh1) and the plane sums of dout (gradient of `vec`, bias gradient of the residual
+        # 1x1 conv) come out of the GroupNorm backward's own passes: no plane_sum launch over those tensors
+        dh2, dg2, dbe2, _, db2, dout_sums = gn_silu_bwd(dout, h2, a2, c2, mr2, g2, be2, None, G, want_sums=True)
+        dvec = dout_sums if ctx.has_vec else None
         dw2 = conv2d_wgrad(h1, None, ops.CONV_NORMAL, 3, dh2, Co, pro=(a1, c1))
         dact1 = conv2d_dgrad(dh2, w2, 3, ops.CONV_NORMAL, Co)
-        dh1, dg1, dbe1, dfilm = gn_silu_bwd(dact1, h1, a1, c1, mr1, g1, be1, film, G)
-        db1 = channel_sums(dh1)
+        dh1, dg1, dbe1, dfilm, db1, _ = gn_silu_bwd(dact1, h1, a1, c1, mr1, g1, be1, film, G, want_sums=True)
         dw1 = conv2d_wgrad(src0, src1, ops.CONV_NORMAL, 3, dh1, Cin)
         if wr is None:
             dres = dout  # identity residual (single source)
@@ -192,7 +206,7 @@ class ResBlockFn(torch.autograd.Function):
         else:
             dres = conv2d_dgrad(dout, wr, 1, ops.CONV_NORMAL, Cin)
             dwr = conv2d_wgrad(src0, src1, ops.CONV_NORMAL, 1, dout, Cin)
-            dbr = channel_sums(dout)
+            dbr = batch_sum(dout_sums)
         dx = conv2d_dgrad(dh1, w1, 3, ops.CONV_NORMAL, Cin, res=dres)
         d0 = dx[:, :C0] if src1 is not None else dx
         d1 = dx[:, C0:] if src1 is not None else None
@@ -607,33 +621,73 @@ class FusedAdam(torch.optim.Optimizer):
         WEIGHT_EPOCH[0] += 1
 
     def flat_grads(self):
+        """the flat gradient buffers, complete: gradients autograd left in tensors of their own are gathered first (one launch)"""
+        self._collect()
         return [f['g'] for f in self._flat if f is not None]
 
-    def zero_grad(self, set_to_none=False):
+    def zero_grad(self, set_to_none=True):
+        """p.grad = None for every parameter: autograd's AccumulateGrad then TAKES the gradient tensor a backward produces (no
+        `grad += g` launch per parameter, no zero-fill of the flat buffer); _collect() moves them into the flat buffer in ONE launch
+        (a parameter that received no gradient gets zeros) and re-binds p.grad to its view of the flat buffer."""
         for f in self._flat:
             if f is None:
                 continue
-            f['g'].zero_()
-            o = 0
-            for p in f['params']:  # keep .grad bound to the flat buffer (autograd accumulates in place)
+            for p in f['params']:
+                p.grad = None
+
+    @torch.no_grad()
+    def _collect(self):
+        import numpy as np
+        for f in self._flat:
+            if f is None:
+                continue
+            base, o = f['g'].data_ptr(), 0
+            recs, todo = [], False
+            for p in f['params']:
                 n = p.numel()
-                if p.grad is None or p.grad.data_ptr() != f['g'].data_ptr() + 4 * o:
-                    p.grad = f['g'][o:o + n].view_as(p)
+                g = p.grad
+                if g is None:
+                    recs.append((0, o, n))
+                    todo = True
+                elif g.data_ptr() != base + 4 * o:
+                    if not (g.is_contiguous() and g.dtype == torch.float32 and g.device == f['g'].device):
+                        g = g.contiguous().to(device=f['g'].device, dtype=torch.float32)
+                        p.grad = g  # keep it alive until the gather has run (stream-ordered)
+                    recs.append((g.data_ptr(), o, n))
+                    todo = True
+                o += n
+            if not todo:
+                continue
+            if not f['g'].is_cuda:  # CPU (tests of the host logic only): no kernel library behind it
+                o = 0
+                for p in f['params']:
+                    n = p.numel()
+                    if p.grad is None:
+                        f['g'][o:o + n].zero_()
+                    elif p.grad.data_ptr() != base + 4 * o:
+                        f['g'][o:o + n].copy_(p.grad.reshape(-1))
+                    o += n
+            else:
+                tab = np.zeros((len(recs), 4), dtype=np.int64)
+                tab[:, :3] = np.asarray(recs, dtype=np.int64)
+                nb = (tab[:, 2] + 4095) // 4096
+                tab[:, 3] = np.cumsum(nb) - nb
+                dev_tab = torch.from_numpy(tab).to(f['g'].device)
+                check(_lib.load().idiff_gather_segments(dev_tab.data_ptr(), len(recs), int(nb.sum()), _p(f['g']), _stream()), "gather_segments")
+                f['_keep'] = (dev_tab, [p.grad for p in f['params']])  # alive until the next collect: the launch is asynchronous
+            o = 0
+            for p in f['params']:
+                n = p.numel()
+                p.grad = f['g'][o:o + n].view_as(p)
                 o += n
 
     @torch.no_grad()
     def step(self, closure=None):
         lib = _lib.load()
+        self._collect()
         for group, f in zip(self.param_groups, self._flat):
             if f is None:
                 continue
-            o = 0
-            for p in f['params']:  # a .grad that autograd replaced (first accumulation) is copied back into the flat buffer
-                n = p.numel()
-                if p.grad is not None and p.grad.data_ptr() != f['g'].data_ptr() + 4 * o:
-                    f['g'][o:o + n].copy_(p.grad.reshape(-1))
-                    p.grad = f['g'][o:o + n].view_as(p)
-                o += n
             f['step'] += 1
             b1, b2 = group['betas']
             check(lib.idiff_adam_step(_p(f['p']), _p(f['g']), _p(f['m']), _p(f['v']), f['p'].numel(), group['lr'], b1, b2, group['eps'],
@@ -762,8 +816,11 @@ def forward_backward_inputRes(model):
             torch.autograd.backward(outs_n, grads_n)
         main.wait_stream(s1)
         main.wait_stream(s2)
+        # the per-parameter gradient tensors autograd left behind -> the flat buffers (one gather launch per optimizer; p.grad is a
+        # view of its flat buffer from here on, zeros where a parameter received no gradient)
+        flats_d, flats_n = m.drift_optimizer.flat_grads(), m.noise_optimizer.flat_grads()
         if sync is not None:
-            sync.start(m.noise_optimizer.flat_grads())
+            sync.start(flats_n)
         return rec, iter_time, use_dsm, use_nsm
     outs_d, grads_d = fwd(m.drift_net, m.input, tgt_d, 0, 2, use_dsm)
     outs_n, grads_n = fwd(m.noise_net, m.drift_noised_x, m.std_noise, 1, 6, use_nsm)
@@ -774,8 +831,10 @@ def forward_backward_inputRes(model):
     if sync is not None:
         sync.start(m.drift_optimizer.flat_grads())
     torch.autograd.backward(outs_n, grads_n)
+    flats_n = m.noise_optimizer.flat_grads()  # gathers (see the two-stream branch)
+    m.drift_optimizer.flat_grads()
     if sync is not None:
-        sync.start(m.noise_optimizer.flat_grads())
+        sync.start(flats_n)
     return rec, iter_time, use_dsm, use_nsm
 
 

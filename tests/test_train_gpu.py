@@ -182,8 +182,8 @@ def test_losses_and_adam():
         gr = torch.randn(1000, generator=g)
         ref_p.grad = gr.clone()
         ropt.step()
-        opt.zero_grad()
-        pp.grad.copy_(gr.to(DEV))
+        opt.zero_grad()          # (p.grad = None: autograd would now hand its gradient tensor over; here the test does)
+        pp.grad = gr.to(DEV)
         opt.step()
     assert _rel(pp.data, ref_p.data) < 1e-6
 
