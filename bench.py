@@ -271,8 +271,15 @@ def pmc_evidence(kernel):
                                "share_of_step_kernel_time": k["share_of_step_kernel_time"], "bytes_per_launch": k["hbm_bytes_per_launch"],
                                "achieved": k["achieved_GBps"], "peak": k["peak_GBps"], "unit": "GB/s", "frac": k["frac"]}
                               for k in doc["kernels"] if "frac" in k and not k["kernel"].startswith("conv_wino") and k["share_of_step_kernel_time"] >= 0.02]
-        if doc.get("mfma_util"):  # SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), separate --pmc pass (scripts/pmc_kernel.sh)
-            out["mfma_util_measured"] = doc["mfma_util"]
+        # matrix-pipe utilisation of the dominant kernel per layer shape: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), its own
+        # --pmc passes (scripts/collect_mfma_util.sh), stored next to the traffic table and hash-gated like it
+        mu = os.path.join(os.path.dirname(cands[-1]), "mfma_util.json")
+        if os.path.exists(mu):
+            with open(mu) as f:
+                mdoc = json.load(f)
+            if mdoc.get("kernel_source_hash") == kernel_source_hash() and short.startswith(mdoc.get("kernel", "?")):
+                out["mfma_util_measured"] = {k: v["mfma_util"] for k, v in mdoc["shapes"].items()}
+                out["mfma_util_source"] = os.path.relpath(mu, ROOT)
         out["step_hbm_bytes"] = doc.get("step_hbm_bytes")
         out["step_hbm_GBps_over_kernel_time"] = doc.get("step_hbm_GBps_over_kernel_time")
         return out

@@ -18,4 +18,5 @@ python3 bench.py --size 512 --batch 8 --steps 5 --warmup 2 --no-cpu-baseline --n
 python3 bench.py --mode irsde > $O/d_bench_irsde.json 2>/dev/null
 python3 bench.py --mode train --batch 32 --steps 5 --warmup 2 > $O/e_bench_train_b32.json 2>/dev/null; echo "bench lines done"
 bash scripts/train_profile.sh $O/train 32 > $O/train_profile.txt 2>&1; cp $O/train/train_kernel_stats.csv $O/train_kernel_stats.csv; rm -rf $O/train
+bash scripts/collect_mfma_util.sh $O/mfma_util.json > $O/mfma_util.log 2>&1; echo "mfma util done"
 ls $O

@@ -490,6 +490,10 @@ def force_wino4(request):
     (21, 16, 0, 64, 64, 64, "epilogue"),
     (20, 16, 0, 128, 64, 64, "prologue"),
     (17, 40, 0, 64, 64, 96, "plain"),
+    # partial patches AND more items than workgroups: the stream crosses item boundaries between whole and partial patches
+    (40, 16, 0, 64, 56, 56, "plain"),
+    (36, 8, 16, 64, 40, 56, "concat"),
+    (34, 16, 0, 64, 56, 40, "prologue"),
 ])
 def test_conv_winograd4_matches_direct_and_fp64(force_wino4, B, C0, C1, Cout, H, W, variant):
     _check_wino4_case(force_wino4, B, C0, C1, Cout, H, W, variant)
