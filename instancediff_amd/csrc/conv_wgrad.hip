@@ -339,10 +339,14 @@ extern "C" int64_t idiff_conv2d_wgrad_ws_floats(const idiff_conv_desc* d) {
         wgrad1x1_geometry(Cin, d->Cout, d->B, Hout * Wout, &wcob, &wcib, &wns);
         if (wns > ns) ns = wns;
     }
-    if (d->ks == 3 && d->Cout % 64 == 0) {  // the Winograd kernel may take this shape with its own split count
+    if (d->ks == 3 && d->Cout % 64 == 0) {  // the Winograd kernels may take this shape with their own split counts
         int wcob, wcib, wns;
         idiff_detail::wino_wgrad_geometry(Cin, d->Cout, d->B, Hout, Wout, &wcob, &wcib, &wns);
         if (wns > ns) ns = wns;
+        if (Hout % 4 == 0 && Wout % 16 == 0) {
+            idiff_detail::wino4_wgrad_geometry(Cin, d->Cout, d->B, Hout, Wout, &wcob, &wcib, &wns);
+            if (wns > ns) ns = wns;
+        }
     }
     return (int64_t)ns * d->ks * d->ks * Cin * d->Cout;
 }
@@ -399,7 +403,12 @@ extern "C" int idiff_conv2d_wgrad(const idiff_conv_desc* d, const float* dy, int
     w.B = a.B, w.Hin = a.Hin, w.Win = a.Win, w.Hout = a.Hout, w.Wout = a.Wout, w.Cout = a.Cout;
     w.pro_a = a.pro_a, w.pro_b = a.pro_b, w.dy = a.dy, w.dybs = a.dybs, w.ws = a.ws;
     g_last_wgrad_algo = IDIFF_CONV_ALGO_DIRECT;
-    if (idiff_detail::wino_wgrad_eligible(w, d->ks, d->mode)) {
+    if (idiff_detail::wino4_wgrad_eligible(w, d->ks, d->mode)) {
+        g_last_wgrad_algo = IDIFF_CONV_ALGO_WINOGRAD4;
+        idiff_detail::wino4_wgrad_geometry(w.Cin, w.Cout, w.B, w.Hout, w.Wout, &w.ncob, &w.ncib, &w.nsplit);
+        a.nsplit = w.nsplit;  // for the reduction below
+        rc = idiff_detail::launch_wino4_wgrad(w, st);
+    } else if (idiff_detail::wino_wgrad_eligible(w, d->ks, d->mode)) {
         g_last_wgrad_algo = IDIFF_CONV_ALGO_WINOGRAD;
         idiff_detail::wino_wgrad_geometry(w.Cin, w.Cout, w.B, w.Hout, w.Wout, &w.ncob, &w.ncib, &w.nsplit);
         a.nsplit = w.nsplit;  // for the reduction below
