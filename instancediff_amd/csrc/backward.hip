@@ -101,11 +101,11 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_reduce_kernel(const float* __
 }
 
 // pass 2 (tiny): group means A, Bq per (b,g); dgamma/dbeta (sum over b, fixed order); dfilm [B,2C]; optionally the plane sums
-// dh_sum[c] = sum_{b,pixels} dh = sum_b rstd (g S1 - HW A - rstd Bq S3)  and  dy_sum[b,c] = S0
+// dh_terms[b,c] = sum_pixels dh = rstd (g S1 - HW A - rstd Bq S3) (summed over b by batch_sum_kernel)  and  dy_sum[b,c] = S0
 __global__ void gn_bwd_finalize_kernel(const float* __restrict__ s4, const float* __restrict__ gamma, const float* __restrict__ beta,
                                        const float* __restrict__ film, long long film_ld, const float* __restrict__ mean_rstd,
                                        float* __restrict__ ab, float* __restrict__ gbc, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ dfilm, long long dfilm_ld, float* __restrict__ dh_sum, float* __restrict__ dy_sum, int B,
+                                       float* __restrict__ dfilm, long long dfilm_ld, float* __restrict__ dh_terms, float* __restrict__ dy_sum, int B,
                                        int C, int groups, int HW, int accumulate) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int cpg = C / groups;
@@ -128,24 +128,14 @@ __global__ void gn_bwd_finalize_kernel(const float* __restrict__ s4, const float
         ab[tid * 2 + 1] = Bq;
     }
     if (tid < C) {  // parameter gradients
-        float dg = 0.f, db = 0.f, dhs = 0.f;
-        const int g = tid / cpg;
+        float dg = 0.f, db = 0.f;
         for (int b = 0; b < B; ++b) {
             const float sc = film ? 1.f + film[(long long)b * film_ld + tid] : 1.f;
-            const float S1 = s4[((long long)b * C + tid) * 4], S2 = s4[((long long)b * C + tid) * 4 + 1];
-            dg += sc * S2;
-            db += sc * S1;
-            if (dh_sum) {
-                float A, Bq;
-                group_means(b, g, A, Bq);
-                const float rstd = mean_rstd[((long long)b * groups + g) * 2 + 1];
-                const float gg = sc * (gamma ? gamma[tid] : 1.f);
-                dhs += rstd * (gg * S1 - (float)HW * A - rstd * Bq * s4[((long long)b * C + tid) * 4 + 2]);
-            }
+            dg += sc * s4[((long long)b * C + tid) * 4 + 1];
+            db += sc * s4[((long long)b * C + tid) * 4];
         }
         if (dgamma) dgamma[tid] = accumulate ? dgamma[tid] + dg : dg;
         if (dbeta) dbeta[tid] = accumulate ? dbeta[tid] + db : db;
-        if (dh_sum) dh_sum[tid] = dhs;
     }
     if (tid < B * C) {  // per-(b,c) scale used by the apply pass, and FiLM gradients
         const int b = tid / C, c = tid % C;
@@ -157,6 +147,13 @@ __global__ void gn_bwd_finalize_kernel(const float* __restrict__ s4, const float
             dfilm[(long long)b * dfilm_ld + C + c] = s4[tid * 4];                          // d shift
         }
         if (dy_sum) dy_sum[tid] = s4[tid * 4 + 3];
+        if (dh_terms) {  // this plane's share of sum dh: rstd (g S1 - HW A - rstd Bq S3); summed over b by idiff_batch_sum's kernel
+            const int g = c / cpg;
+            float A, Bq;
+            group_means(b, g, A, Bq);
+            const float rstd = mean_rstd[((long long)b * groups + g) * 2 + 1];
+            dh_terms[tid] = rstd * (sc * ga * s4[tid * 4] - (float)HW * A - rstd * Bq * s4[tid * 4 + 2]);
+        }
     }
 }
 
@@ -471,12 +468,17 @@ extern "C" int idiff_gn_silu_bwd(const float* dy, int64_t dy_bstride, const floa
     float* s4 = ws;                        // [B*C*4]
     float* ab = ws + (size_t)B * C * 4;    // [B*groups*2]
     float* gbc = ab + (size_t)B * groups * 2;  // [B*C]
+    float* dh_terms = dh_sum ? gbc + (size_t)B * C : nullptr;  // [B*C]
     hipLaunchKernelGGL(gn_silu_bwd_reduce_kernel, dim3(B * C), dim3(256), 0, ST, dy, (long long)dy_bstride, h, (long long)h_bstride, a, b,
                        mean_rstd, s4, C, groups, HW);
     IDIFF_CHECK_LAUNCH("gn_silu_bwd_reduce");
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, ST, s4, gamma, beta, film, (long long)film_ld, mean_rstd,
-                       ab, gbc, dgamma, dbeta, dfilm, (long long)dfilm_ld, dh_sum, dy_sum, B, C, groups, HW, accumulate);
+                       ab, gbc, dgamma, dbeta, dfilm, (long long)dfilm_ld, dh_terms, dy_sum, B, C, groups, HW, accumulate);
     IDIFF_CHECK_LAUNCH("gn_bwd_finalize");
+    if (dh_sum) {
+        hipLaunchKernelGGL(batch_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, dh_terms, dh_sum, B, C, 0);
+        IDIFF_CHECK_LAUNCH("gn_bwd_dh_sum");
+    }
     int gx = (HW + 1023) / 1024;
     if (gx < 1) gx = 1;
     if (gx > 64) gx = 64;
@@ -485,7 +487,7 @@ extern "C" int idiff_gn_silu_bwd(const float* dy, int64_t dy_bstride, const floa
     IDIFF_CHECK_LAUNCH("gn_silu_bwd_apply");
     return IDIFF_OK;
 }
-extern "C" int64_t idiff_gn_silu_bwd_ws_floats(int B, int C, int groups) { return (int64_t)B * C * 5 + (int64_t)B * groups * 2; }
+extern "C" int64_t idiff_gn_silu_bwd_ws_floats(int B, int C, int groups) { return (int64_t)B * C * 6 + (int64_t)B * groups * 2; }
 
 extern "C" int idiff_act_fwd(const float* x, float* y, int64_t n, int act, idiff_stream_t stream) {
     IDIFF_CHECK_ARG(x && y && n > 0 && (act == IDIFF_ACT_SILU || act == IDIFF_ACT_GELU), "act_fwd: bad args");

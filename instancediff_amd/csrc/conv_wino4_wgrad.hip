@@ -137,14 +137,21 @@ __global__ __launch_bounds__(NT) void wino4_wgrad_kernel(const WwArgs a) {
     float rin[NL];
     unsigned rin_pad = 0;  // bit i: element i of the registers is padding (outside the image / unused slot)
     auto load_raw = [&]() {
-        rin_pad = 0;
+        int off[NL];
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            int off = gtab[i * NT + tid];
-            if (((eflags >> (4 * i)) & cur_edges) != 0) off = -1;
-            rin_pad |= (off < 0 ? 1u : 0u) << i;
-            rin[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, off, 0, 0));
+        for (int i = 0; i < NL; ++i) off[i] = gtab[i * NT + tid];
+        if (cur_edges != 0) {  // border chunks only (uniform): elements outside the image
+#pragma unroll
+            for (int i = 0; i < NL; ++i)
+                if (((eflags >> (4 * i)) & cur_edges) != 0) off[i] = -1;
         }
+        if (PRO) {
+            rin_pad = 0;
+#pragma unroll
+            for (int i = 0; i < NL; ++i) rin_pad |= (off[i] < 0 ? 1u : 0u) << i;
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) rin[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, off[i], 0, 0));
     };
     // dY of (channel co0 + cb*16 + (lane & 15), tile lane >> 4): its four rows of four pixels
     floatx4 dyr[4];
@@ -213,21 +220,31 @@ __global__ __launch_bounds__(NT) void wino4_wgrad_kernel(const WwArgs a) {
     };
     // ---- E = A dY A^T of (tile lane >> 4, channel cb*16 + (lane & 15)), rows 3*ib .. 3*ib+2 of the 6x6 result, from the dY registers
     float* const ewbase = Eb + cb * 256 + lane * 4;  // [quad][cb][k = tile][co16][4]
+    // the wave's three rows of A x: rows 0-2 (x0, s + t, s - t) or rows 3-5 (p + q, p - q, x3)
+    auto a3 = [&](float x0, float x1, float x2, float x3, float (&o)[3]) {
+        if (ib == 0) {  // (uniform)
+            const float sm = x0 + x2, t = x1 + x3;
+            o[0] = x0, o[1] = sm + t, o[2] = sm - t;
+        } else {
+            const float p = __builtin_fmaf(4.f, x2, x0), q = __builtin_fmaf(8.f, x3, 2.f * x1);
+            o[0] = p + q, o[1] = p - q, o[2] = x3;
+        }
+    };
     auto e_transform = [&](int buf) {
-        float w[4][6];  // [column x][row u] = (A dY)[u][x]
-        a6(dyr[0].x, dyr[1].x, dyr[2].x, dyr[3].x, w[0]);
-        a6(dyr[0].y, dyr[1].y, dyr[2].y, dyr[3].y, w[1]);
-        a6(dyr[0].z, dyr[1].z, dyr[2].z, dyr[3].z, w[2]);
-        a6(dyr[0].w, dyr[1].w, dyr[2].w, dyr[3].w, w[3]);
+        float w[4][3];  // [column x][row uu] = (A dY)[3*ib + uu][x]
+        a3(dyr[0].x, dyr[1].x, dyr[2].x, dyr[3].x, w[0]);
+        a3(dyr[0].y, dyr[1].y, dyr[2].y, dyr[3].y, w[1]);
+        a3(dyr[0].z, dyr[1].z, dyr[2].z, dyr[3].z, w[2]);
+        a3(dyr[0].w, dyr[1].w, dyr[2].w, dyr[3].w, w[3]);
         float* const E = ewbase + buf * E_FLOATS;
 #pragma unroll
         for (int uu = 0; uu < 3; ++uu) {
+            float z[6];
+            a6(w[0][uu], w[1][uu], w[2][uu], w[3][uu], z);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                if (h != ib) continue;  // (uniform: the wave's half)
+                if (h != ib) continue;  // (uniform: the wave's half; the LDS offsets are immediates per half)
                 const int u = 3 * h + uu;
-                float z[6];
-                a6(w[0][u], w[1][u], w[2][u], w[3][u], z);
                 *reinterpret_cast<floatx4*>(E + PF(u) * 1024) = floatx4{z[0], z[1], z[2], z[3]};
                 *reinterpret_cast<floatx2*>(E + PH(u) * 1024 + 2 * (u & 1)) = floatx2{z[4], z[5]};
             }
@@ -296,13 +313,16 @@ __global__ __launch_bounds__(NT) void wino4_wgrad_kernel(const WwArgs a) {
                 acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[4 * q + 3], 0, 0, 0);
                 if (MORE) {  // the slices of the next chunk's staging, dealt out over the quads
                     if (q < 4) stage_raw(2 * q), stage_raw(2 * q + 1);
-                    if (q == 5) d_transform(buf ^ 1);
-                    if (q == 6) e_transform(buf ^ 1);
-                    if (q == 7 && c + 2 < c_end) {
+                    // the patch of chunk c+2 is requested as soon as the registers are free (staged): most of a chunk of latency
+                    // budget (requested behind quad 7 it had two quads and the kernel ran at the memory latency: 14 k cycles per
+                    // 36-MFMA chunk); dY of chunk c+2 behind the transform that consumes the registers
+                    if (q == 4 && c + 2 < c_end) {
                         nb = setup_chunk(c + 2);
                         load_raw();
-                        load_dy();
                     }
+                    if (q == 5) d_transform(buf ^ 1);
+                    if (q == 6) e_transform(buf ^ 1);
+                    if (q == 7 && c + 2 < c_end) load_dy();
                     __builtin_amdgcn_sched_barrier(0);
                     if (q == 4 || q == 8) __syncthreads();
                 }
