@@ -264,17 +264,69 @@ inline void wgrad1x1_geometry(int Cin, int Cout, int B, int HW, int* ncob, int* 
 }
 
 // dW[co][ci][tap] (+)= sum_s ws[s][tap][ci][co]   (fixed order -> deterministic)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int taps, int Cin, int Cout, int accumulate) {
+// One workgroup owns 1024/KL consecutive elements of the [tap][ci][co] image: thread = (4 consecutive elements, split lane kl); it adds
+// the splits kl, kl+KL, .. with 16-byte loads (four in flight), the KL lane sums are then added in lane order through LDS.  The
+// layers with few weights and many splits (64->64: 36 864 elements x 256 splits) were 144 workgroups whose threads each walked all
+// splits with one 4-byte load in flight: 71 us per launch on average, 9.5 ms of a training iteration.
+template <int KL>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int taps, int Cin, int Cout,
+                                                           int accumulate) {
+    constexpr int NI4 = 256 / KL;  // element quads per workgroup
+    __shared__ float4 part[KL][NI4];
     const long long n = (long long)taps * Cin * Cout;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int co = i % Cout;
-        const int ci = (i / Cout) % Cin;
-        const int tap = i / ((long long)Cout * Cin);
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += ws[(long long)k * n + i];
-        const long long o = ((long long)co * Cin + ci) * taps + tap;
-        dw[o] = accumulate ? dw[o] + s : s;
+    const int q = threadIdx.x % NI4, kl = threadIdx.x / NI4;
+    const long long i0 = ((long long)blockIdx.x * NI4 + q) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool vec = (n & 3) == 0 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0;
+    if (vec && i0 + 3 < n) {
+        const float* p = ws + i0;
+        int k = kl;
+        for (; k + 3 * KL < nsplit; k += 4 * KL) {
+            const float4 v0 = *reinterpret_cast<const float4*>(p + (long long)k * n);
+            const float4 v1 = *reinterpret_cast<const float4*>(p + (long long)(k + KL) * n);
+            const float4 v2 = *reinterpret_cast<const float4*>(p + (long long)(k + 2 * KL) * n);
+            const float4 v3 = *reinterpret_cast<const float4*>(p + (long long)(k + 3 * KL) * n);
+            s.x += v0.x, s.y += v0.y, s.z += v0.z, s.w += v0.w;
+            s.x += v1.x, s.y += v1.y, s.z += v1.z, s.w += v1.w;
+            s.x += v2.x, s.y += v2.y, s.z += v2.z, s.w += v2.w;
+            s.x += v3.x, s.y += v3.y, s.z += v3.z, s.w += v3.w;
+        }
+        for (; k < nsplit; k += KL) {
+            const float4 v = *reinterpret_cast<const float4*>(p + (long long)k * n);
+            s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+        }
+    } else if (i0 < n) {  // image size not a multiple of 4 / unaligned workspace (no layer of the path; kept for the C ABI's generality)
+        float* sp = reinterpret_cast<float*>(&s);
+        for (int e = 0; e < 4 && i0 + e < n; ++e)
+            for (int k = kl; k < nsplit; k += KL) sp[e] += ws[(long long)k * n + i0 + e];
     }
+    part[kl][q] = s;
+    __syncthreads();
+    for (int u = threadIdx.x; u < NI4 * 4; u += 256) {
+        const int qq = u / 4, e = u % 4;
+        const long long i = ((long long)blockIdx.x * NI4 + qq) * 4 + e;
+        if (i < n) {
+            float t = 0.f;
+#pragma unroll
+            for (int l = 0; l < KL; ++l) t += reinterpret_cast<const float*>(&part[l][qq])[e];
+            const int co = i % Cout;
+            const int ci = (i / Cout) % Cin;
+            const int tap = i / ((long long)Cout * Cin);
+            const long long o = ((long long)co * Cin + ci) * taps + tap;
+            dw[o] = accumulate ? dw[o] + t : t;
+        }
+    }
+}
+
+inline void launch_wgrad_reduce(const float* ws, float* dw, int nsplit, int taps, int Cin, int Cout, int accumulate, hipStream_t st) {
+    const long long n = (long long)taps * Cin * Cout;
+    // many splits of a small image: 64 split lanes x 16 elements per workgroup; otherwise 16 lanes x 64 elements
+    if (nsplit >= 64 && (n + 63) / 64 < 1024)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, ws, dw, nsplit, taps, Cin, Cout, accumulate);
+    else if (nsplit >= 4)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, ws, dw, nsplit, taps, Cin, Cout, accumulate);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, ws, dw, nsplit, taps, Cin, Cout, accumulate);
 }
 
 inline int wg_pick_twl(int Wout) { return Wout >= 32 ? 5 : (Wout >= 16 ? 4 : 3); }
@@ -438,9 +490,7 @@ extern "C" int idiff_conv2d_wgrad(const idiff_conv_desc* d, const float* dy, int
         rc = launch_wg<7, 2, IDIFF_CONV_NORMAL>(a, twl, st);
     }
     if (rc != IDIFF_OK) return rc;
-    const long long n = (long long)d->ks * d->ks * a.Cin * a.Cout;
-    const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, ws, dw, a.nsplit, d->ks * d->ks, a.Cin, a.Cout, accumulate);
+    launch_wgrad_reduce(ws, dw, a.nsplit, d->ks * d->ks, a.Cin, a.Cout, accumulate, st);
     IDIFF_CHECK_LAUNCH("conv2d_wgrad_reduce");
     return IDIFF_OK;
 }
