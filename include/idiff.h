@@ -117,6 +117,11 @@ int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream);
 #define IDIFF_CONV_ALGO_WINOGRAD4H 4 /* F(4x4,3x3), half-patch items, two workgroups per CU: conv_wino4h.hip */
 #define IDIFF_CONV_ALGO_X3 5 /* 1x1, fp32 operands as three bf16 planes, six bf16 MFMAs per product: conv1x1_x3.hip */
 int idiff_conv2d_last_algo(void);
+/* Which kernel idiff_conv2d_fwd(d, .) WOULD launch for this descriptor: every check and selection rule of the call, no launch
+ * (IDIFF_CONV_ALGO_* >= 0, or IDIFF_E_*).  The weight-image pointers of `d` only have to point at memory of the right size: a
+ * caller whose weights change every step (training) asks first and then fills only the image the chosen kernel reads -- one pack
+ * launch per use instead of three.  Does not change idiff_conv2d_last_algo(). */
+int idiff_conv2d_plan(const idiff_conv_desc* d);
 /* w [Cout][Cin] (the ks == 1 weight, torch layout) -> the three-plane bf16 image idiff_conv_desc.wx3 points to:
  * [chunk of 32 ci][block of 64 co][plane][octet of 8 ci][co][8 bf16], zero beyond Cin / Cout; x = plane0 + plane1 + plane2 exactly.
  * `image` holds idiff_conv1x1_x3_image_bytes(Cout, Cin) bytes, 16-byte aligned. */

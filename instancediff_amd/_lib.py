@@ -56,6 +56,7 @@ SIGNATURES = {
     "idiff_conv2d_num_tiles": (I, [I, I]),
     "idiff_conv2d_fwd": (I, [C.POINTER(ConvDesc), c_stream]),
     "idiff_conv2d_last_algo": (I, []),
+    "idiff_conv2d_plan": (I, [C.POINTER(ConvDesc)]),
     "idiff_pack_conv_weight": (I, [P, P, I, I, I, c_stream]),
     "idiff_pack_conv_weight_T": (I, [P, P, I, I, I, c_stream]),
     "idiff_pack_conv_weight_wino": (I, [P, P, I, I, I, c_stream]),

@@ -593,7 +593,8 @@ extern "C" int idiff_conv2d_num_tiles(int Hout, int Wout) {
     return ((Wout + TW - 1) / TW) * ((Hout + TH - 1) / TH);
 }
 
-extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream) {
+// plan = true: everything up to the choice of the kernel (argument checks, the per-sample-shape rules, g_last_algo), no launch
+static int conv2d_run(const idiff_conv_desc* d, idiff_stream_t stream, const bool plan) {
     IDIFF_CHECK_ARG(d && d->src0 && d->wpk && d->out, "conv2d: null pointer");
     IDIFF_CHECK_ARG(d->B > 0 && d->C0 > 0 && d->Cout > 0 && d->Hin > 0 && d->Win > 0, "conv2d: bad dims");
     IDIFF_CHECK_ARG(d->ks == 1 || d->ks == 3 || d->ks == 7, "conv2d: ks must be 1, 3 or 7 (got %d)", d->ks);
@@ -717,6 +718,7 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
         IDIFF_CHECK_ARG(!(hard && reqx3) || can, "conv2d: algo_request bf16x3 but the layer is not a 1x1 that tiles by 256 pixels with a split weight image");
         if (can && (reqx3 || (req == -1 && x3_on))) {
             g_last_algo = IDIFF_CONV_ALGO_X3;
+            if (plan) return IDIFF_OK;
             return idiff_detail::launch_conv1x1_x3(ax, d->mode, d->wx3, st);
         }
     }
@@ -743,20 +745,28 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
         else half = w4h_mode >= 1 && items8 >= 16;
         if (half) {
             g_last_algo = IDIFF_CONV_ALGO_WINOGRAD4H;
+            if (plan) return IDIFF_OK;
             return finalize_after(idiff_detail::launch_conv_wino4h(a, d->mode, st));
         }
         if (w4_ok && (req4 || items16 >= 16)) {
             g_last_algo = IDIFF_CONV_ALGO_WINOGRAD4;
+            if (plan) return IDIFF_OK;
             return finalize_after(idiff_detail::launch_conv_wino4(a, d->mode, st));
         }
     }
     IDIFF_CHECK_ARG(!hard || !(req4 || req4h), "conv2d: algo_request F(4x4,3x3) but the shape does not tile for it");
     if ((req == -1 || req == IDIFF_CONV_ALGO_WINOGRAD || !hard) && req != IDIFF_CONV_ALGO_DIRECT && idiff_detail::conv_wino_eligible(a, d->ks, d->mode)) {
         g_last_algo = IDIFF_CONV_ALGO_WINOGRAD;
+        if (plan) return IDIFF_OK;
         return finalize_after(idiff_detail::launch_conv_wino(a, d->mode, st));
     }
     IDIFF_CHECK_ARG(!hard || req != IDIFF_CONV_ALGO_WINOGRAD, "conv2d: algo_request F(2x2,3x3) but the shape does not tile for it");
     g_last_algo = IDIFF_CONV_ALGO_DIRECT;
+    if (plan) {
+        IDIFF_CHECK_ARG(!(d->ks == 1 && d->mode == IDIFF_CONV_UPSAMPLE2), "conv2d: upsample mode needs ks=3");
+        IDIFF_CHECK_ARG(d->ks != 7 || d->mode == IDIFF_CONV_NORMAL, "conv2d: ks=7 needs normal mode");
+        return IDIFF_OK;
+    }
     if (d->ks == 3) {
         if (d->mode == IDIFF_CONV_NORMAL) return finalize_after(dispatch_mb<3, 8, IDIFF_CONV_NORMAL>(a, twl, mb, vecw, st));
         return finalize_after(dispatch_mb<3, 8, IDIFF_CONV_UPSAMPLE2>(a, twl, mb, vecw, st));
@@ -768,6 +778,16 @@ extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream)
     }
     IDIFF_CHECK_ARG(d->mode == IDIFF_CONV_NORMAL, "conv2d: ks=7 needs normal mode");
     return finalize_after(dispatch_mb<7, 2, IDIFF_CONV_NORMAL>(a, twl, mb, vecw, st));
+}
+
+extern "C" int idiff_conv2d_fwd(const idiff_conv_desc* d, idiff_stream_t stream) { return conv2d_run(d, stream, false); }
+
+extern "C" int idiff_conv2d_plan(const idiff_conv_desc* d) {
+    const int keep = g_last_algo;
+    const int rc = conv2d_run(d, nullptr, true);
+    const int algo = g_last_algo;
+    g_last_algo = keep;  // idiff_conv2d_last_algo() keeps speaking of launches
+    return rc != IDIFF_OK ? rc : algo;
 }
 
 static int pack_common(const float* w, float* wpk, int Cout, int Cin, int ks, int tr, idiff_stream_t stream) {

@@ -163,6 +163,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
 // 16-byte aligned and makes both MFMA operand reads bank-conflict free), and multiplied on v_mfma_f32_16x16x4_f32 with
 // the pixels as the K dimension.  Two workgroups per CU keep ~128 KB of loads in flight per CU.
 constexpr int W1_PX = 128, W1_LD = W1_PX + 4;
+// UNSH: the input is the pixel-unshuffle(2) of src0 (virtual channel 4c + 2sy + sx = src0[c][2y+sy][2x+sx]): a thread's staging unit is
+// a PAIR of virtual rows (sx = 0 / 1) x 4 output pixels = 8 consecutive floats of one input row, de-interleaved in registers.
+template <bool UNSH>
 __global__ __launch_bounds__(256) void wgrad1x1_kernel(const WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const xt = smem;                 // [64 ci][W1_LD]
@@ -187,15 +190,39 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(const WgArgs a) {
 
     // staging map: 64 rows x 32 float4 = 2048 float4 per operand, 8 per thread; row = f >> 5, float4 column = f & 31
     floatx4 rx[8], ry[8];
+    const int HWx = UNSH ? a.Hin * a.Win : HW;
     auto load_unit = [&](int u) {
         const int b = u / runs, p0 = (u - b * runs) * W1_PX;
-        const float* xb = srcb + (long long)b * sbs + (long long)chan0 * HW + p0;
         const float* yb = a.dy + (long long)b * a.dybs + (long long)co0 * HW + p0;
+        if (UNSH) {
+            const float* xb = srcb + (long long)b * sbs + (long long)(chan0 >> 2) * HWx;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int f = tid + i * 256;
+                const int prow = f >> 5, p = p0 + (f & 31) * 4;  // rows 2 prow, 2 prow + 1: channel prow >> 1 of the block, sy = prow & 1
+                const int oy = p / a.Wout, ox = p - oy * a.Wout;
+                if (2 * prow < nci) {
+                    const float* q = xb + (long long)(prow >> 1) * HWx + (2 * oy + (prow & 1)) * a.Win + 2 * ox;
+                    const floatx4 l0 = *reinterpret_cast<const floatx4*>(q), l1 = *reinterpret_cast<const floatx4*>(q + 4);
+                    rx[2 * i] = floatx4{l0[0], l0[2], l1[0], l1[2]};
+                    rx[2 * i + 1] = floatx4{l0[1], l0[3], l1[1], l1[3]};
+                } else {
+                    rx[2 * i] = rx[2 * i + 1] = floatx4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        } else {
+            const float* xb = srcb + (long long)b * sbs + (long long)chan0 * HW + p0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int f = tid + i * 256;
+                const int row = f >> 5, c4 = (f & 31) * 4;
+                rx[i] = row < nci ? *reinterpret_cast<const floatx4*>(xb + (long long)row * HW + c4) : floatx4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int f = tid + i * 256;
             const int row = f >> 5, c4 = (f & 31) * 4;
-            rx[i] = row < nci ? *reinterpret_cast<const floatx4*>(xb + (long long)row * HW + c4) : floatx4{0.f, 0.f, 0.f, 0.f};
             ry[i] = *reinterpret_cast<const floatx4*>(yb + (long long)row * HW + c4);
         }
     };
@@ -204,7 +231,12 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(const WgArgs a) {
         for (int i = 0; i < 8; ++i) {
             const int f = tid + i * 256;
             const int row = f >> 5, c4 = (f & 31) * 4;
-            *reinterpret_cast<floatx4*>(xt + row * W1_LD + c4) = rx[i];
+            if (UNSH) {
+                const int fu = tid + (i >> 1) * 256;
+                *reinterpret_cast<floatx4*>(xt + (2 * (fu >> 5) + (i & 1)) * W1_LD + (fu & 31) * 4) = rx[i];
+            } else {
+                *reinterpret_cast<floatx4*>(xt + row * W1_LD + c4) = rx[i];
+            }
             *reinterpret_cast<floatx4*>(dyt + row * W1_LD + c4) = ry[i];
         }
     };
@@ -246,7 +278,8 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(const WgArgs a) {
 }
 
 inline bool wgrad1x1_eligible(const WgArgs& a, int ks, int mode) {
-    if (ks != 1 || mode != IDIFF_CONV_NORMAL || a.pro_a) return false;
+    if (ks != 1 || mode == IDIFF_CONV_UPSAMPLE2 || a.pro_a) return false;
+    if (mode == IDIFF_CONV_UNSHUFFLE2 && (a.Wout % 4 || a.src1)) return false;
     if (a.Cout % 64 || ((long long)a.Hout * a.Wout) % W1_PX) return false;
     if (a.src1 && a.C0v % 64) return false;
     if ((reinterpret_cast<uintptr_t>(a.src0) & 15) || (reinterpret_cast<uintptr_t>(a.src1) & 15) || (reinterpret_cast<uintptr_t>(a.dy) & 15)) return false;
@@ -469,13 +502,14 @@ extern "C" int idiff_conv2d_wgrad(const idiff_conv_desc* d, const float* dy, int
         g_last_wgrad_algo = IDIFF_CONV_ALGO_STREAM1X1;
         wgrad1x1_geometry(a.Cin, a.Cout, a.B, a.Hout * a.Wout, &a.ncob, &a.nchunks, &a.nsplit);
         const size_t lds = (size_t)2 * 64 * W1_LD * sizeof(float);
-        static bool attr = false;
-        if (!attr) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad1x1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const bool unsh = d->mode == IDIFF_CONV_UNSHUFFLE2;
+        auto kern = unsh ? wgrad1x1_kernel<true> : wgrad1x1_kernel<false>;
+        static idiff_dyn_lds_cache attr[2];
+        {
+            hipError_t e = idiff_ensure_dyn_lds(attr[unsh], reinterpret_cast<const void*>(kern), lds);
             if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "conv2d_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            attr = true;
         }
-        hipLaunchKernelGGL(wgrad1x1_kernel, dim3(a.ncob * a.nchunks * a.nsplit), dim3(256), lds, st, a);
+        hipLaunchKernelGGL(kern, dim3(a.ncob * a.nchunks * a.nsplit), dim3(256), lds, st, a);
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "conv2d_wgrad(1x1): %s", hipGetErrorString(le));
         rc = IDIFF_OK;

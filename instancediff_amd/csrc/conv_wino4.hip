@@ -182,7 +182,6 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a, const Geo4& g
     const int tblk = wave >> 2;  // MFMA role: upper / lower 8x32 half-patch
     const int HWin = a.Hin * a.Win;
     const int nchunks = a.Cin / CK;  // even, >= 4 (Cin % 8 == 0, Cin >= 16: conv_wino4_items)
-    const std::integral_constant<bool, HEAVY> hvt{};
 
     // ---- per-item state.  Set A = the item being accumulated, set B = the next one (or the null item) ----------------------
     constexpr int RSRC_FLAGS = 0x00020000;

@@ -12,13 +12,17 @@
 
 namespace {
 
-constexpr int GK = 16;  // K chunk
+constexpr int GK = 32;  // K chunk
 
+// The next chunk's operands travel in registers while the current one is multiplied (r04: the loop had loaded, stored, synchronised
+// and multiplied one 16-deep chunk at a time -- every chunk paid a full global-load latency, and the token-side products of the
+// training step, K = 160 ... 256 on 16 workgroups, took 31-41 us each: 650 launches, 22 ms of an iteration).
 template <int TM, int TN>
 __global__ __launch_bounds__(256) void bgemm_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N,
                                                     int K, long long lda, long long ldb, long long ldc, int transA, int transB, long long sA,
                                                     long long sB, long long sC, float alpha, float beta, int nsplit, int kper) {
     constexpr int WN = TN / 32;  // waves along n; waves along m = 4 / WN = TM / 32
+    constexpr int NA = TM * GK / 256, NB = TN * GK / 256;
     __shared__ float As[GK][TM + 1];
     __shared__ float Bs[GK][TN + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
@@ -29,37 +33,44 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const float* __restrict__ A,
     const float* Bb = B + (long long)bz * sB;
     float* Cb = C + (long long)blockIdx.z * sC;  // with nsplit > 1, C is the partial buffer [batch*nsplit][M][N]
     const int kbeg = sp * kper, kend = min(K, kbeg + kper);
+    // staging map (fixed per thread): element e = tid + 256 i of a chunk -> (k, m) / (k, n), unit stride in memory along e
+    int ak[NA], am[NA], bk[NB], bn[NB];
+    long long ao[NA], bo[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int e = tid + i * 256;
+        ak[i] = transA ? e / TM : e % GK;
+        am[i] = transA ? e % TM : e / GK;
+        ao[i] = m0 + am[i] < M ? (transA ? (long long)ak[i] * lda + m0 + am[i] : (long long)(m0 + am[i]) * lda + ak[i]) : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int e = tid + i * 256;
+        bk[i] = transB ? e % GK : e / TN;
+        bn[i] = transB ? e / GK : e % TN;
+        bo[i] = n0 + bn[i] < N ? (transB ? (long long)(n0 + bn[i]) * ldb + bk[i] : (long long)bk[i] * ldb + n0 + bn[i]) : -1;
+    }
+    const long long astep = transA ? lda : 1, bstep = transB ? 1 : ldb;  // per unit of k
+    float ra[NA], rb[NB];
+    auto load_chunk = [&](int k0) {
+        const float* Ak = Ab + (long long)k0 * astep;
+        const float* Bk = Bb + (long long)k0 * bstep;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ra[i] = (ao[i] >= 0 && k0 + ak[i] < kend) ? Ak[ao[i]] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = (bo[i] >= 0 && k0 + bk[i] < kend) ? Bk[bo[i]] : 0.f;
+    };
     floatx16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (kbeg < kend) load_chunk(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += GK) {
-        for (int e = tid; e < TM * GK; e += 256) {
-            int m, k;
-            if (transA) {  // memory [k][m]
-                k = e / TM;
-                m = e - k * TM;
-            } else {  // memory [m][k]
-                m = e / GK;
-                k = e - m * GK;
-            }
-            float v = 0.f;
-            if (m0 + m < M && k0 + k < kend) v = transA ? Ab[(long long)(k0 + k) * lda + m0 + m] : Ab[(long long)(m0 + m) * lda + k0 + k];
-            As[k][m] = v;
-        }
-        for (int e = tid; e < TN * GK; e += 256) {
-            int n, k;
-            if (transB) {  // memory [n][k]
-                n = e / GK;
-                k = e - n * GK;
-            } else {  // memory [k][n]
-                k = e / TN;
-                n = e - k * TN;
-            }
-            float w = 0.f;
-            if (n0 + n < N && k0 + k < kend) w = transB ? Bb[(long long)(n0 + n) * ldb + k0 + k] : Bb[(long long)(k0 + k) * ldb + n0 + n];
-            Bs[k][n] = w;
-        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) As[ak[i]][am[i]] = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) Bs[bk[i]][bn[i]] = rb[i];
         __syncthreads();
+        if (k0 + GK < kend) load_chunk(k0 + GK);  // in flight during the MFMAs below
 #pragma unroll
         for (int s = 0; s < GK / 2; ++s)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[2 * s + half][wm * 32 + l31], Bs[2 * s + half][wn * 32 + l31], acc, 0, 0, 0);

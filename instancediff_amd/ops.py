@@ -84,33 +84,59 @@ def request_conv3x3_algo(algo):
 
 
 # ---------------------------------------------------------------------------------------------------
-def pack_conv_weight(w, transpose=False):
-    """[Cout,Cin,k,k] -> packed [k*k][Cin][Cout] (or the flipped/transposed pack for the data gradient)."""
+def _alloc_conv_images(w, transpose):
+    """The direct image and, as attributes, whichever other images the weight's shape admits -- allocated, not filled."""
     lib = _lib.load()
     _c(w, "weight")
     co, ci, k, _ = w.shape
     out = torch.empty((k * k, co, ci) if transpose else (k * k, ci, co), device=w.device, dtype=torch.float32)
-    fn = lib.idiff_pack_conv_weight_T if transpose else lib.idiff_pack_conv_weight
-    check(fn(_p(w), _p(out), co, ci, k, _stream()), "pack_conv_weight")
     if k == 3 and WINOGRAD and co % 8 == 0 and ci % 8 == 0 and (ci if transpose else co) % 16 == 0:
         # Winograd-domain copy rides along as an attribute; conv2d hands it to the C ABI (idiff_conv_desc.wwino)
         cconv, kconv = (ci, co) if transpose else (co, ci)  # the conv's (Cout, Cin); Cout is padded to whole 64-blocks
-        wino = torch.empty((16 * kconv * ((cconv + 63) // 64) * 64,), device=w.device, dtype=torch.float32)
-        check(lib.idiff_pack_conv_weight_wino(_p(w), _p(wino), co, ci, 1 if transpose else 0, _stream()), "pack_conv_weight_wino")
-        out.wino = wino
+        out.wino = torch.empty((16 * kconv * ((cconv + 63) // 64) * 64,), device=w.device, dtype=torch.float32)
         if WINOGRAD4 and (WINOGRAD4_DGRAD or not transpose):
-            wino4 = torch.empty((36 * kconv * ((cconv + 63) // 64) * 64,), device=w.device, dtype=torch.float32)
-            check(lib.idiff_pack_conv_weight_wino4(_p(w), _p(wino4), co, ci, 1 if transpose else 0, _stream()), "pack_conv_weight_wino4")
-            out.wino4 = wino4
+            out.wino4 = torch.empty((36 * kconv * ((cconv + 63) // 64) * 64,), device=w.device, dtype=torch.float32)
     cconv1, kconv1 = (ci, co) if transpose else (co, ci)  # the conv's (Cout, Cin)
     if k == 1 and X3 and cconv1 % 64 == 0 and kconv1 >= 32 and kconv1 % 8 == 0:
         # three-plane bf16 image of a 1x1 weight (idiff_conv_desc.wx3): flattened 1x1 layers then run on the bf16 matrix cores; the
         # data-gradient pack is the image of the transposed matrix
-        wm = w.reshape(co, ci).t().contiguous() if transpose else w
-        x3 = torch.empty((lib.idiff_conv1x1_x3_image_bytes(cconv1, kconv1) // 2,), device=w.device, dtype=torch.int16)
-        check(lib.idiff_pack_conv1x1_x3(_p(wm), x3.data_ptr(), cconv1, kconv1, _stream()), "pack_conv1x1_x3")
-        out.x3 = x3
+        out.x3 = torch.empty((lib.idiff_conv1x1_x3_image_bytes(cconv1, kconv1) // 2,), device=w.device, dtype=torch.int16)
     return out
+
+
+def _fill_conv_images(out, w, transpose, algo=None):
+    """algo None: every image `out` carries; CONV_ALGO_x: the one image that kernel reads."""
+    lib = _lib.load()
+    co, ci, k, _ = w.shape
+    tr = 1 if transpose else 0
+    if algo is None or algo == CONV_ALGO_DIRECT:
+        fn = lib.idiff_pack_conv_weight_T if transpose else lib.idiff_pack_conv_weight
+        check(fn(_p(w), _p(out), co, ci, k, _stream()), "pack_conv_weight")
+    if hasattr(out, "wino") and (algo is None or algo == CONV_ALGO_WINOGRAD):
+        check(lib.idiff_pack_conv_weight_wino(_p(w), _p(out.wino), co, ci, tr, _stream()), "pack_conv_weight_wino")
+    if hasattr(out, "wino4") and (algo is None or algo in (CONV_ALGO_WINOGRAD4, CONV_ALGO_WINOGRAD4H)):
+        check(lib.idiff_pack_conv_weight_wino4(_p(w), _p(out.wino4), co, ci, tr, _stream()), "pack_conv_weight_wino4")
+    if hasattr(out, "x3") and (algo is None or algo == CONV_ALGO_X3):
+        cconv1, kconv1 = (ci, co) if transpose else (co, ci)
+        wm = w.reshape(co, ci).t().contiguous() if transpose else w
+        check(lib.idiff_pack_conv1x1_x3(_p(wm), out.x3.data_ptr(), cconv1, kconv1, _stream()), "pack_conv1x1_x3")
+
+
+def pack_conv_weight(w, transpose=False):
+    """[Cout,Cin,k,k] -> packed [k*k][Cin][Cout] (or the flipped/transposed pack for the data gradient), with the Winograd-domain /
+    split-bf16 images the shape admits as attributes (.wino, .wino4, .x3)."""
+    out = _alloc_conv_images(w, transpose)
+    _fill_conv_images(out, w, transpose)
+    return out
+
+
+class LazyConvWeight:
+    """A conv weight for ONE conv2d call whose images are packed at that call: conv2d asks the library which kernel it will launch
+    (idiff_conv2d_plan) and fills only the image that kernel reads.  For weights that change every step (training: one pack launch
+    per use instead of three); the sampling path packs once per weight version and keeps every image (pack_conv_weight)."""
+
+    def __init__(self, w, transpose=False):
+        self.w, self.transpose = _c(w, "weight"), transpose
 
 
 def conv2d(src0, wpk, bias, ks, Cout, src1=None, mode=CONV_NORMAL, pro=None, out=None, res=None, vec=None, aux=None,
@@ -123,6 +149,9 @@ def conv2d(src0, wpk, bias, ks, Cout, src1=None, mode=CONV_NORMAL, pro=None, out
     (out, (a, b, mean_rstd))."""
     lib = _lib.load()
     B, C0, Hin, Win = src0.shape
+    lazy = wpk if isinstance(wpk, LazyConvWeight) else None
+    if lazy is not None:
+        wpk = _alloc_conv_images(lazy.w, lazy.transpose)
     d = ConvDesc()
     if algo is not None:
         d.algo_request = 1 + algo
@@ -198,6 +227,11 @@ def conv2d(src0, wpk, bias, ks, Cout, src1=None, mode=CONV_NORMAL, pro=None, out
             assert tuple(mr.shape) == (B, d.gn_groups, 2) and mr.is_contiguous()
             d.gn_mean_rstd = mr.data_ptr()
             gn_out = (ga, gb, mr)
+    planned = None
+    if lazy is not None:
+        planned = lib.idiff_conv2d_plan(C.byref(d))
+        check(min(planned, 0), "conv2d_plan")
+        _fill_conv_images(wpk, lazy.w, lazy.transpose, planned)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -208,6 +242,8 @@ def conv2d(src0, wpk, bias, ks, Cout, src1=None, mode=CONV_NORMAL, pro=None, out
                             flops=2.0 * Cin * Cout * ks * ks * Hout * Wout * B))
     else:
         check(lib.idiff_conv2d_fwd(C.byref(d), _stream()), "conv2d_fwd")
+    if planned is not None and lib.idiff_conv2d_last_algo() != planned:  # the one image that was filled is not the one that was read
+        raise RuntimeError("conv2d: planned kernel %d, launched %d" % (planned, lib.idiff_conv2d_last_algo()))
     if ALGO_TRACE is not None:
         Cin = (C0 * 4 if mode == CONV_UNSHUFFLE2 else C0) + (src1.shape[1] if src1 is not None else 0)
         ALGO_TRACE[(lib.idiff_conv2d_last_algo(), ks, Cin, Cout, Hout, Wout)] += 1

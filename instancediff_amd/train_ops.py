@@ -48,7 +48,8 @@ def conv2d_wgrad(src0, src1, mode, ks, dy, Cin, pro=None, dw=None, accumulate=Fa
 
 def conv2d_dgrad(dy, weight, ks, mode, Cin_virtual, res=None):
     """data gradient w.r.t. the (virtual) conv input: [B, Cin_v, Hout, Wout]; the caller undoes upsample/unshuffle."""
-    wT = ops.pack_conv_weight(weight.detach().contiguous(), transpose=True)
+    w = weight.detach().contiguous()
+    wT = ops.LazyConvWeight(w, transpose=True) if LAZY_PACK else ops.pack_conv_weight(w, transpose=True)  # packed at the call
     return ops.conv2d(dy, wT, None, ks, Cin_virtual, res=res)
 
 
@@ -127,8 +128,24 @@ def bgemm(A, B, M, N, K, lda, ldb, transA, transB, sA, sB, batch, out=None, alph
 # =====================================================================================================
 # autograd Functions
 # =====================================================================================================
+def _samples_contiguous(t):
+    """t itself when every sample is contiguous (a channel slice of a bigger NCHW tensor: the gradient of one source of a virtual
+    concat, of torch.cat) -- the kernels take a batch stride; a copy otherwise."""
+    exp = 1
+    for d in range(t.dim() - 1, 0, -1):
+        if t.shape[d] != 1 and t.stride(d) != exp:
+            return t.contiguous()
+        exp *= t.shape[d]
+    return t if (t.shape[0] == 1 or t.stride(0) >= exp) and t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 else t.contiguous()
+
+
+LAZY_PACK = os.environ.get("IDIFF_LAZY_PACK", "1") != "0"  # A/B runs: 0 = every image of a weight packed at every use (r03)
+
+
 def _packed(w):
-    return ops.pack_conv_weight(w.detach().contiguous())
+    if not LAZY_PACK:
+        return ops.pack_conv_weight(w.detach().contiguous())
+    return ops.LazyConvWeight(w.detach().contiguous())  # packed at the conv call: only the image the chosen kernel reads
 
 
 class ConvFn(torch.autograd.Function):
@@ -145,7 +162,7 @@ class ConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         src0, src1, weight = ctx.saved_tensors
-        dout = dout.contiguous()
+        dout = _samples_contiguous(dout)
         ks, mode = ctx.ks, ctx.mode
         Cout, Cin = weight.shape[0], weight.shape[1]
         C0 = src0.shape[1]
@@ -187,7 +204,7 @@ class ResBlockFn(torch.autograd.Function):
     def backward(ctx, dout):
         src0, src1, film, w1, g1, be1, w2, g2, be2, wr, h1, h2, a1, c1, mr1, a2, c2, mr2 = ctx.saved_tensors
         G = ctx.groups
-        dout = dout.contiguous()
+        dout = _samples_contiguous(dout)
         Co = w1.shape[0]
         C0 = src0.shape[1]
         Cin = w1.shape[1]

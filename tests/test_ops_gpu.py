@@ -779,3 +779,29 @@ def test_conv1x1_bf16x3_pixel_unshuffle(B, C0, Cout, H, W, variant):
     out32 = ops.conv2d(x.to(DEV), wpk, bias.to(DEV), 1, Cout, mode=ops.CONV_UNSHUFFLE2, algo=ops.CONV_ALGO_DIRECT, **kw)
     assert ops._lib.load().idiff_conv2d_last_algo() == ops.CONV_ALGO_DIRECT
     _close(out, out32, 2e-6, "unshuffle conv1x1 bf16x3 vs the f32 kernel")
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W,ks,mode,transpose", [
+    (64, 64, 64, 64, 3, 0, False),    # F(4x4,3x3), 16x32 items
+    (64, 128, 16, 32, 3, 0, True),    # half-patch kernel, data-gradient pack
+    (32, 64, 6, 24, 3, 0, False),     # F(2x2,3x3)
+    (64, 5, 32, 32, 3, 0, False),     # direct
+    (128, 64, 32, 32, 1, 0, False),   # 1x1 on the bf16 matrix cores
+    (64, 128, 32, 32, 1, 0, True),    # its data-gradient pack (transposed matrix)
+    (16, 64, 32, 32, 1, 2, False),    # pixel-unshuffle 1x1
+    (24, 40, 16, 16, 1, 0, False),    # 1x1, direct
+    (32, 64, 8, 16, 3, 1, False),     # upsample
+])
+def test_conv_weight_packed_at_the_call_fills_the_image_the_launched_kernel_reads(Cin, Cout, H, W, ks, mode, transpose):
+    """ops.LazyConvWeight (the training path's weights): idiff_conv2d_plan names the kernel, only its image is packed, the result is
+    bit-identical to the call with every image packed, and the kernel that ran is the planned one (conv2d raises otherwise)."""
+    g = torch.Generator().manual_seed(77)
+    B = 2
+    C0 = Cin // 4 if mode == ops.CONV_UNSHUFFLE2 else Cin
+    x = torch.randn(B, C0, H, W, generator=g).to(DEV)
+    w = (torch.randn((Cin, Cout, ks, ks) if transpose else (Cout, Cin, ks, ks), generator=g) / math.sqrt(Cin * ks * ks)).to(DEV)
+    full = ops.conv2d(x, ops.pack_conv_weight(w, transpose=transpose), None, ks, Cout, mode=mode)
+    a_full = ops._lib.load().idiff_conv2d_last_algo()
+    lazy = ops.conv2d(x, ops.LazyConvWeight(w, transpose=transpose), None, ks, Cout, mode=mode)
+    assert ops._lib.load().idiff_conv2d_last_algo() == a_full
+    assert torch.equal(full, lazy)

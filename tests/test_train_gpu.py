@@ -348,6 +348,19 @@ def test_conv_wgrad_streaming_1x1_vs_fp64(B, C0, C1, Cout, H, W):
     assert _rel(dw, ref) < 5e-6
 
 
+@pytest.mark.parametrize("B,C0,Cout,H,W", [(2, 16, 64, 16, 32), (3, 64, 128, 32, 16), (1, 8, 64, 16, 64), (2, 24, 64, 64, 8)])
+def test_conv_wgrad_streaming_1x1_of_the_pixel_unshuffle_vs_fp64(B, C0, Cout, H, W):
+    """The downsample layers (pixel-unshuffle(2) + 1x1) on the streaming kernel: row pairs of virtual channels de-interleaved in registers;
+    whole and partial 64-row blocks of virtual channels, runs of 128 output pixels that span 1 / 2 / 4 / 32 output rows."""
+    g = _g(43)
+    x0 = torch.randn(B, C0, H, W, generator=g)
+    dy = torch.randn(B, Cout, H // 2, W // 2, generator=g)
+    ref = torch.einsum("bohw,bihw->oi", dy.double(), F.pixel_unshuffle(x0.double(), 2)).reshape(Cout, 4 * C0, 1, 1)
+    dw = T.conv2d_wgrad(x0.to(DEV), None, ops.CONV_UNSHUFFLE2, 1, dy.to(DEV), 4 * C0)
+    assert ops._lib.load().idiff_conv2d_wgrad_last_algo() == 2, "the streaming 1x1 weight-gradient kernel did not run"
+    assert _rel(dw, ref) < 5e-6
+
+
 def test_conv_wgrad_winograd_random_shapes_vs_fp64():
     rng = __import__("numpy").random.RandomState(9)
     lib = ops._lib.load()
