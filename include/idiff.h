@@ -432,6 +432,10 @@ int64_t idiff_bgemm_ws_floats(int M, int N, int K, int batch); /* 0 unless the s
 int idiff_bgemm(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
                 int transA, int transB, int64_t sA, int64_t sB, int64_t sC, int batch, float alpha, float beta, float* ws,
                 idiff_stream_t stream);
+/* y [R,N] = x [R,K] . w [N,K]^T (+ bias [N] or NULL) through the same kernel: the training path's token-side linear layers
+ * (reference: nn.Linear inside TransformerDecoderLayer / ContextDecoder, models/modules/_modified_BiomedCLIP.py); any R */
+int idiff_linear_mfma_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* out, int64_t ldo, int R,
+                          int K, int N, idiff_stream_t stream);
 /* out = softmax(scale * x) over each row;  ds = scale * p * (dp - <p, dp>) */
 int idiff_softmax_rows_fwd(const float* x, int64_t ldx, float* out, int64_t ldo, int R, int N, float scale,
                            idiff_stream_t stream);

@@ -121,6 +121,7 @@ SIGNATURES = {
     "idiff_scatter_channel": (I, [P, P, P, I, I, I, c_stream]),
     "idiff_bgemm_ws_floats": (I64, [I, I, I, I]),
     "idiff_bgemm": (I, [P, P, P, I, I, I, I64, I64, I64, I, I, I64, I64, I64, I, F, F, P, c_stream]),
+    "idiff_linear_mfma_fwd": (I, [P, I64, P, I64, P, P, I64, I, I, I, c_stream]),
     "idiff_softmax_rows_fwd": (I, [P, I64, P, I64, I, I, F, c_stream]),
     "idiff_softmax_rows_bwd": (I, [P, I64, P, I64, P, I64, I, I, F, c_stream]),
     "idiff_resize_bilinear": (I, [P, P, I64, I, I, I, I, c_stream]),

@@ -199,13 +199,31 @@ __global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ 
     }
 }
 
+// Column reductions over token rows (R <= a few hundred): workgroup = 16 columns x 16 row lanes; lane l adds rows l, l + 16, .. (all of
+// a lane's loads independent), the 16 lane sums are added in lane order through LDS -> fixed order.  (r04: one thread per column had
+// walked all R rows: 16-40 us per launch of pure load latency, ~330 launches per training iteration.)
+constexpr int CS_COLS = 16, CS_LANES = 16;
+__device__ __forceinline__ float colsum_lanes(float v, float (&red)[CS_LANES][CS_COLS + 1]) {
+    const int cl = threadIdx.x % CS_COLS, rl = threadIdx.x / CS_COLS;
+    red[rl][cl] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (rl == 0) {
+#pragma unroll
+        for (int l = 0; l < CS_LANES; ++l) t += red[l][cl];
+    }
+    __syncthreads();
+    return t;  // valid on row lane 0
+}
 // out[n] (+)= sum_r x[r, n]
-__global__ void colsum_kernel(const float* __restrict__ x, long long ldx, float* __restrict__ out, int R, int N, int accumulate) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long long ldx, float* __restrict__ out, int R, int N, int accumulate) {
+    __shared__ float red[CS_LANES][CS_COLS + 1];
+    const int n = blockIdx.x * CS_COLS + threadIdx.x % CS_COLS, rl = threadIdx.x / CS_COLS;
     float s = 0.f;
-    for (int r = 0; r < R; ++r) s += x[(long long)r * ldx + n];
-    out[n] = accumulate ? out[n] + s : s;
+    if (n < N)
+        for (int r = rl; r < R; r += CS_LANES) s += x[(long long)r * ldx + n];
+    s = colsum_lanes(s, red);
+    if (rl == 0 && n < N) out[n] = accumulate ? out[n] + s : s;
 }
 
 // out[r,n] = x[r,n] * g[n]
@@ -214,12 +232,14 @@ __global__ void scale_cols_kernel(const float* __restrict__ x, const float* __re
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = x[i] * g[i % N];
 }
 // out[n] = sum_r x[r,n] * y[r,n]
-__global__ void colsum_prod_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, int R, int N) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+__global__ __launch_bounds__(256) void colsum_prod_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, int R, int N) {
+    __shared__ float red[CS_LANES][CS_COLS + 1];
+    const int n = blockIdx.x * CS_COLS + threadIdx.x % CS_COLS, rl = threadIdx.x / CS_COLS;
     float s = 0.f;
-    for (int r = 0; r < R; ++r) s += x[(long long)r * N + n] * y[(long long)r * N + n];
-    out[n] = s;
+    if (n < N)
+        for (int r = rl; r < R; r += CS_LANES) s += x[(long long)r * N + n] * y[(long long)r * N + n];
+    s = colsum_lanes(s, red);
+    if (rl == 0 && n < N) out[n] = s;
 }
 
 // LayerNorm rows backward: dx (wave per row) ; dgamma/dbeta by a column pass
@@ -245,19 +265,24 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_dx_kernel(const float* __rest
         dx[(long long)r * lddx + c] = rstd * (dyr[c] * gamma[c] - s1 - xh * s2);
     }
 }
-__global__ void ln_rows_bwd_param_kernel(const float* __restrict__ dy, long long lddy, const float* __restrict__ x, long long ldx,
-                                         const float* __restrict__ mean_rstd, float* __restrict__ dgamma, float* __restrict__ dbeta, int R, int C,
-                                         int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void ln_rows_bwd_param_kernel(const float* __restrict__ dy, long long lddy, const float* __restrict__ x, long long ldx,
+                                                                const float* __restrict__ mean_rstd, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, int R, int C, int accumulate) {
+    __shared__ float red[CS_LANES][CS_COLS + 1];
+    const int c = blockIdx.x * CS_COLS + threadIdx.x % CS_COLS, rl = threadIdx.x / CS_COLS;
     float dg = 0.f, db = 0.f;
-    for (int r = 0; r < R; ++r) {
-        const float d = dy[(long long)r * lddy + c];
-        dg += d * (x[(long long)r * ldx + c] - mean_rstd[2 * r]) * mean_rstd[2 * r + 1];
-        db += d;
+    if (c < C)
+        for (int r = rl; r < R; r += CS_LANES) {
+            const float d = dy[(long long)r * lddy + c];
+            dg += d * (x[(long long)r * ldx + c] - mean_rstd[2 * r]) * mean_rstd[2 * r + 1];
+            db += d;
+        }
+    dg = colsum_lanes(dg, red);
+    db = colsum_lanes(db, red);
+    if (rl == 0 && c < C) {
+        dgamma[c] = accumulate ? dgamma[c] + dg : dg;
+        dbeta[c] = accumulate ? dbeta[c] + db : db;
     }
-    dgamma[c] = accumulate ? dgamma[c] + dg : dg;
-    dbeta[c] = accumulate ? dbeta[c] + db : db;
 }
 
 // channel LayerNorm backward (thread = pixel) ; writes dx and per-(b,c) partial sums are done by plane kernels
@@ -503,7 +528,7 @@ extern "C" int idiff_act_bwd(const float* dy, const float* x, float* dx, int64_t
 }
 extern "C" int idiff_colsum(const float* x, int64_t ldx, float* out, int R, int N, int accumulate, idiff_stream_t stream) {
     IDIFF_CHECK_ARG(x && out && R > 0 && N > 0 && ldx >= N, "colsum: bad args");
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256), dim3(256), 0, ST, x, (long long)ldx, out, R, N, accumulate);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + CS_COLS - 1) / CS_COLS), dim3(256), 0, ST, x, (long long)ldx, out, R, N, accumulate);
     IDIFF_CHECK_LAUNCH("colsum");
     return IDIFF_OK;
 }
@@ -515,7 +540,7 @@ extern "C" int idiff_scale_cols(const float* x, const float* g, float* out, int 
 }
 extern "C" int idiff_colsum_prod(const float* x, const float* y, float* out, int R, int N, idiff_stream_t stream) {
     IDIFF_CHECK_ARG(x && y && out && R > 0 && N > 0, "colsum_prod: bad args");
-    hipLaunchKernelGGL(colsum_prod_kernel, dim3((N + 255) / 256), dim3(256), 0, ST, x, y, out, R, N);
+    hipLaunchKernelGGL(colsum_prod_kernel, dim3((N + CS_COLS - 1) / CS_COLS), dim3(256), 0, ST, x, y, out, R, N);
     IDIFF_CHECK_LAUNCH("colsum_prod");
     return IDIFF_OK;
 }
@@ -527,7 +552,7 @@ extern "C" int idiff_layernorm_rows_bwd(const float* dy, int64_t lddy, const flo
                        (long long)lddx, R, C);
     IDIFF_CHECK_LAUNCH("layernorm_rows_bwd_dx");
     if (dgamma && dbeta) {
-        hipLaunchKernelGGL(ln_rows_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, dy, (long long)lddy, x, (long long)ldx, mean_rstd,
+        hipLaunchKernelGGL(ln_rows_bwd_param_kernel, dim3((C + CS_COLS - 1) / CS_COLS), dim3(256), 0, ST, dy, (long long)lddy, x, (long long)ldx, mean_rstd,
                            dgamma, dbeta, R, C, accumulate);
         IDIFF_CHECK_LAUNCH("layernorm_rows_bwd_param");
     }

@@ -20,7 +20,8 @@ constexpr int GK = 32;  // K chunk
 template <int TM, int TN>
 __global__ __launch_bounds__(256) void bgemm_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N,
                                                     int K, long long lda, long long ldb, long long ldc, int transA, int transB, long long sA,
-                                                    long long sB, long long sC, float alpha, float beta, int nsplit, int kper) {
+                                                    long long sB, long long sC, float alpha, float beta, int nsplit, int kper,
+                                                    const float* __restrict__ colbias) {
     constexpr int WN = TN / 32;  // waves along n; waves along m = 4 / WN = TM / 32
     constexpr int NA = TM * GK / 256, NB = TN * GK / 256;
     __shared__ float As[GK][TM + 1];
@@ -78,11 +79,12 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const float* __restrict__ A,
     }
     const int n = n0 + wn * 32 + l31;
     if (n < N) {
+        const float cb = colbias ? colbias[n] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (m < M) {
-                float v = alpha * acc[r];
+                float v = alpha * acc[r] + cb;
                 if (beta != 0.f) v += beta * Cb[(long long)m * ldc + n];
                 Cb[(long long)m * ldc + n] = v;
             }
@@ -178,11 +180,11 @@ extern "C" int idiff_bgemm(const float* A, const float* B, float* C, int M, int 
     if (M <= 32) {
         dim3 grid((N + 127) / 128, (M + 31) / 32, batch * ns);
         hipLaunchKernelGGL((bgemm_kernel<32, 128>), grid, dim3(256), 0, st, A, B, dst, M, N, K, (long long)lda, (long long)ldb, dld, transA, transB,
-                           (long long)sA, (long long)sB, dsC, a2, b2, ns, kper);
+                           (long long)sA, (long long)sB, dsC, a2, b2, ns, kper, nullptr);
     } else {
         dim3 grid((N + 63) / 64, (M + 63) / 64, batch * ns);
         hipLaunchKernelGGL((bgemm_kernel<64, 64>), grid, dim3(256), 0, st, A, B, dst, M, N, K, (long long)lda, (long long)ldb, dld, transA, transB,
-                           (long long)sA, (long long)sB, dsC, a2, b2, ns, kper);
+                           (long long)sA, (long long)sB, dsC, a2, b2, ns, kper, nullptr);
     }
     IDIFF_CHECK_LAUNCH("bgemm");
     if (ns > 1) {
@@ -191,6 +193,26 @@ extern "C" int idiff_bgemm(const float* A, const float* B, float* C, int M, int 
         hipLaunchKernelGGL(bgemm_reduce_kernel, grid, dim3(256), 0, st, ws, C, M, N, (long long)ldc, (long long)sC, ns, beta);
         IDIFF_CHECK_LAUNCH("bgemm_reduce");
     }
+    return IDIFF_OK;
+}
+
+// y [R,N] = x [R,K] . w [N,K]^T (+ bias) on the f32 matrix cores: the batched-GEMM kernel with a per-column bias.  The training path's
+// token-side linear layers (160 rows): idiff_linear_fwd's wave-per-column form walks K with one 256-byte row in flight, 20 us per launch.
+extern "C" int idiff_linear_mfma_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* out, int64_t ldo, int R,
+                                     int K, int N, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(x && w && out && R > 0 && K > 0 && N > 0, "linear_mfma_fwd: bad args");
+    IDIFF_CHECK_ARG(ldx >= K && ldw >= K && ldo >= N, "linear_mfma_fwd: bad leading dims");
+    hipStream_t st = (hipStream_t)stream;
+    if (R <= 32) {
+        dim3 grid((N + 127) / 128, 1, 1);
+        hipLaunchKernelGGL((bgemm_kernel<32, 128>), grid, dim3(256), 0, st, x, w, out, R, N, K, (long long)ldx, (long long)ldw, (long long)ldo, 0, 1,
+                           0ll, 0ll, 0ll, 1.f, 0.f, 1, K, bias);
+    } else {
+        dim3 grid((N + 63) / 64, (R + 63) / 64, 1);
+        hipLaunchKernelGGL((bgemm_kernel<64, 64>), grid, dim3(256), 0, st, x, w, out, R, N, K, (long long)ldx, (long long)ldw, (long long)ldo, 0, 1,
+                           0ll, 0ll, 0ll, 1.f, 0.f, 1, K, bias);
+    }
+    IDIFF_CHECK_LAUNCH("linear_mfma_fwd");
     return IDIFF_OK;
 }
 

@@ -358,7 +358,12 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b):
-        y = ops.linear(x, w, b)
+        # matrix cores (ops.linear is the sampling path's wave-per-column form: 20 us per launch at 160 rows)
+        _chk(x, "x"), _chk(w, "w")
+        assert x.dim() == 2 and w.dim() == 2 and x.stride(1) == 1 and w.stride(1) == 1 and x.shape[1] == w.shape[1]
+        y = torch.empty((x.shape[0], w.shape[0]), device=x.device, dtype=torch.float32)
+        check(_lib.load().idiff_linear_mfma_fwd(_p(x), x.stride(0), _p(w), w.stride(0), _p(_c(b)), _p(y), y.stride(0), x.shape[0], x.shape[1],
+                                                w.shape[0], _stream()), "linear_mfma_fwd")
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
         return y
