@@ -226,12 +226,19 @@ def cpu_baseline(args, batch_full):
             "batch_timed": bs, "steps_timed": n, "s_per_step": [round(v, 3) for v in per], "sample": sample}
 
 
+# translation units none of whose kernels a sampling step launches (profiles/r*/g_steady_state_step_single_stream.txt lists them all):
+# the weight-gradient / backward / batched-GEMM kernels of the training path and the PSNR metrics
+TRAIN_ONLY_SOURCES = ("backward.hip", "conv_wgrad.hip", "conv_wgrad_args.h", "conv_wino_wgrad.hip", "conv_wino4_wgrad.hip", "gemm.hip", "metrics.hip")
+
+
 def kernel_source_hash():
-    """sha256 over the HIP sources + headers of the kernel library: the staleness key of stored PMC traffic figures"""
+    """sha256 over the HIP sources + headers behind the sampling step's kernels: the staleness key of stored PMC traffic figures"""
     import glob
     import hashlib
     h = hashlib.sha256()
     for path in sorted(glob.glob(os.path.join(ROOT, "instancediff_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "instancediff_amd", "csrc", "*.h"))):
+        if os.path.basename(path) in TRAIN_ONLY_SOURCES:
+            continue
         with open(path, "rb") as f:
             h.update(os.path.basename(path).encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
