@@ -638,15 +638,8 @@ def main():
         barrier()
 
     if rank == 0:
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only: the other ranks of a multi-GPU run must not wait on it
-            log("cpu baseline (oracle) ...")
-            try:
-                cpu = cpu_baseline(args, batch)
-            except Exception as e:  # the baseline is a reported side measurement; never hide the GPU result
-                cpu = {"error": repr(e)}
-        elif world > 1:
-            cpu = "N=1 line only"
+        # the training leg runs BEFORE the CPU baseline: measured right behind the oracle's ~110 s of 16-thread host work (GPU idle)
+        # it read 4-5 % low (3.75 against 3.91-3.98 it/s, profiles/r04/README.md)
         train = None
         default_workload = args.size == 256 and args.batch == 16 and variant is None
         if world > 1:
@@ -661,6 +654,15 @@ def main():
                 train = train_leg(args, dev)
             except Exception as e:  # a reported side measurement; never hide the headline
                 train = {"error": repr(e)}
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only: the other ranks of a multi-GPU run must not wait on it
+            log("cpu baseline (oracle) ...")
+            try:
+                cpu = cpu_baseline(args, batch)
+            except Exception as e:  # the baseline is a reported side measurement; never hide the GPU result
+                cpu = {"error": repr(e)}
+        elif world > 1:
+            cpu = "N=1 line only"
         value = world * args.steps / el
         label = "denoising steps/sec (%dx%d bs%d)" % (args.size, args.size, args.batch)
         if variant is not None:

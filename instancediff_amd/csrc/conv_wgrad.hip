@@ -487,6 +487,7 @@ extern "C" int idiff_conv2d_wgrad(const idiff_conv_desc* d, const float* dy, int
     w.C0v = a.C0v, w.C1v = a.C1v, w.C0r = a.C0r, w.Cin = a.Cin;
     w.B = a.B, w.Hin = a.Hin, w.Win = a.Win, w.Hout = a.Hout, w.Wout = a.Wout, w.Cout = a.Cout;
     w.pro_a = a.pro_a, w.pro_b = a.pro_b, w.dy = a.dy, w.dybs = a.dybs, w.ws = a.ws;
+    w.ups = d->mode == IDIFF_CONV_UPSAMPLE2 ? 1 : 0;
     g_last_wgrad_algo = IDIFF_CONV_ALGO_DIRECT;
     if (idiff_detail::wino4_wgrad_eligible(w, d->ks, d->mode)) {
         g_last_wgrad_algo = IDIFF_CONV_ALGO_WINOGRAD4;

@@ -115,7 +115,9 @@ __global__ __launch_bounds__(NT) void wino4_wgrad_kernel(const WwArgs a) {
         const int rem = e - ci * PS;
         const int r = rem / PC, c = rem - r * PC;
         const bool used = e < R_FLOATS && c < 18 && ci0 + ci < a.Cin;
-        gtab[i * NT + tid] = used ? (ci * HWin + r * a.Win + c) * 4 : -1;
+        // nearest x2 upsample: output row 4 ty - 1 + r reads input row 2 ty - 1 + ((r + 1) >> 1), likewise the columns -- the same for
+        // every chunk, so only this table and the chunk origin know about the mode
+        gtab[i * NT + tid] = !used ? -1 : (a.ups ? (ci * HWin + ((r + 1) >> 1) * a.Win + ((c + 1) >> 1)) * 4 : (ci * HWin + r * a.Win + c) * 4);
         eflags |= ((r == 0 ? 1u : 0u) | (r == PR - 1 ? 2u : 0u) | (c == 0 ? 4u : 0u) | (c == 17 ? 8u : 0u)) << (4 * i);
     }
 
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(NT) void wino4_wgrad_kernel(const WwArgs a) {
         const int b = idx / (nty * nxc);
         const int rem = idx - b * (nty * nxc);
         const int ty = rem / nxc, xc = rem - ty * nxc;
-        const long long org = (long long)(4 * ty - 1) * a.Win + (16 * xc - 1);
+        const long long org = a.ups ? (long long)(2 * ty - 1) * a.Win + (8 * xc - 1) : (long long)(4 * ty - 1) * a.Win + (16 * xc - 1);
         rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(srcb + (long long)b * sbs + (long long)chan0 * HWin + org), 0, 0x7fffffff, RSRC_FLAGS);
         rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy + (long long)b * a.dybs + (long long)co0 * HWo + (long long)(4 * ty) * a.Wout + 16 * xc), 0,
                                                 0x7fffffff, RSRC_FLAGS);
@@ -388,7 +390,8 @@ namespace idiff_detail {
 
 bool wino4_wgrad_eligible(const WwArgs& a, int ks, int mode) {
     if (ks != 3 || wino4_wgrad_disabled()) return false;
-    if (mode != IDIFF_CONV_NORMAL) return false;
+    if (mode != IDIFF_CONV_NORMAL && mode != IDIFF_CONV_UPSAMPLE2) return false;
+    if (mode == IDIFF_CONV_UPSAMPLE2 && (a.src1 || a.pro_a)) return false;
     if (a.Cout % 64 || a.Cin % 16 || a.Hout % 4 || a.Wout % 16) return false;
     if (a.src1 && a.C0v % CIB) return false;
     if (a.pro_a && a.src1) return false;

@@ -304,6 +304,10 @@ def test_unet_param_gradients_and_train_steps_vs_oracle():
     (3, 48, 0, 128, 8, 48, "prologue"),       # partial last 32-channel block, two co blocks
     (2, 64, 80, 64, 32, 32, "concat"),        # second source starts on a block boundary; 144 = 4.5 blocks
     (5, 32, 0, 64, 64, 64, "plain"),          # many chunks per split
+    (3, 48, 0, 128, 8, 24, "upsample"),       # out 16x48: every border chunk kind, partial last channel block
+    (2, 32, 0, 64, 2, 8, "upsample"),         # out 4x16: a single chunk per sample
+    (2, 32, 0, 64, 6, 16, "upsample"),        # out 12x32: F(4x4) (12 % 4 == 0)
+    (2, 32, 0, 64, 5, 16, "upsample"),        # out 10x32: not tiled by 4 -> F(2x2)
 ])
 def test_conv_wgrad_winograd_vs_fp64(B, C0, C1, Cout, H, W, variant):
     g = _g(41)
@@ -325,8 +329,8 @@ def test_conv_wgrad_winograd_vs_fp64(B, C0, C1, Cout, H, W, variant):
     dy = torch.randn(y.shape, generator=g)
     y.backward(dy.double())
     dw = T.conv2d_wgrad(x0.to(DEV), None if x1 is None else x1.to(DEV), mode, 3, dy.to(DEV), Cin, pro=pro)
-    # F(4x4,3x3) form (algo 3) where the output tiles by 4 x 16 in normal mode, else the F(2x2,3x3) form (algo 1)
-    want = 3 if (mode == ops.CONV_NORMAL and y.shape[2] % 4 == 0 and y.shape[3] % 16 == 0 and (x1 is None or C0 % 32 == 0)) else 1
+    # F(4x4,3x3) form (algo 3) where the output tiles by 4 x 16 (normal and upsample mode), else the F(2x2,3x3) form (algo 1)
+    want = 3 if (y.shape[2] % 4 == 0 and y.shape[3] % 16 == 0 and (x1 is None or C0 % 32 == 0)) else 1
     assert ops._lib.load().idiff_conv2d_wgrad_last_algo() == want, "the expected Winograd weight-gradient kernel did not run"
     assert _rel(dw, w.grad) < (2e-5 if want == 3 else 1e-5), "winograd wgrad"
     # accumulate form
