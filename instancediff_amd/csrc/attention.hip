@@ -668,32 +668,51 @@ __global__ __launch_bounds__(256) void smm_xattn_w_kernel(const float* __restric
     }
 }
 
+// Merge of the key splits' partial (max, sum, P.V) triples.  Workgroup = 2 channels x 32 rows x CSL split lanes: lane sl walks the
+// splits sl, sl + CSL, .. (max pass, then the weighted sums: every load of a pass independent of the others), the CSL lane results
+// are merged in lane order through LDS -- a fixed order that is a function of the split count (of N) alone.  (r04: one thread per
+// (channel, row) had walked all 64 splits twice: 15.6 us per launch of load latency, 24 launches per step.)
+constexpr int CSL = 4;
 __global__ __launch_bounds__(256) void smm_xattn_combine_kernel(const float* __restrict__ ws, float* __restrict__ o, int rows, int nsplit, int XCM,
                                                                 float* __restrict__ lse) {
-    // thread = (channel c, row): the partials are laid out [c][32 rows], so a wave reads two full 128-byte lines per split
+    __shared__ float red[3][CSL][64];
     const int b = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over XCM * 32
-    if (i >= XCM * 32) return;
+    const int io = threadIdx.x & 63, sl = threadIdx.x >> 6;  // output of the workgroup, split lane (= wave)
+    const int i = blockIdx.x * 64 + io;                      // over XCM * 32: the partials are laid out [c][32 rows]
     const int c = i >> 5, row = i & 31;
-    if (row >= rows) return;
+    const bool live = i < XCM * 32 && row < rows;
     const long long ss = (long long)(XCM + 2) * 32;  // floats per split
     const float* wb = ws + (long long)b * nsplit * ss;
-    // the splits are walked in a fixed order (a sample's bits do not depend on who computed what when); eight splits' loads are
-    // in flight at a time -- the kernel is pure load latency
-    float M = -INFINITY;
+    float M = -INFINITY, L = 0.f, acc = 0.f;
+    if (live) {
 #pragma unroll 8
-    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, wb[s * ss + XCM * 32 + row]);
-    float L = 0.f, acc = 0.f;
+        for (int s = sl; s < nsplit; s += CSL) M = fmaxf(M, wb[s * ss + XCM * 32 + row]);
 #pragma unroll 8
-    for (int s = 0; s < nsplit; ++s) {
-        const float* w = wb + s * ss;
-        const float ms = w[XCM * 32 + row];
-        const float f = ms == -INFINITY ? 0.f : __expf(ms - M);
-        L += w[(XCM + 1) * 32 + row] * f;
-        acc += w[c * 32 + row] * f;
+        for (int s = sl; s < nsplit; s += CSL) {
+            const float* w = wb + s * ss;
+            const float ms = w[XCM * 32 + row];
+            const float f = ms == -INFINITY ? 0.f : __expf(ms - M);
+            L += w[(XCM + 1) * 32 + row] * f;
+            acc += w[c * 32 + row] * f;
+        }
     }
-    o[((long long)b * rows + row) * XCM + c] = acc / L;
-    if (lse && c == 0) lse[(long long)b * rows + row] = M + __logf(L);  // log-sum-exp of the scaled scores (training: saved for the backward)
+    red[0][sl][io] = M, red[1][sl][io] = L, red[2][sl][io] = acc;
+    __syncthreads();
+    if (sl == 0 && live) {
+        float Mt = red[0][0][io];
+#pragma unroll
+        for (int l = 1; l < CSL; ++l) Mt = fmaxf(Mt, red[0][l][io]);
+        float Lt = 0.f, At = 0.f;
+#pragma unroll
+        for (int l = 0; l < CSL; ++l) {
+            const float ml = red[0][l][io];
+            const float f = ml == -INFINITY ? 0.f : __expf(ml - Mt);
+            Lt += red[1][l][io] * f;
+            At += red[2][l][io] * f;
+        }
+        o[((long long)b * rows + row) * XCM + c] = At / Lt;
+        if (lse && c == 0) lse[(long long)b * rows + row] = Mt + __logf(Lt);  // log-sum-exp of the scaled scores (training: saved for the backward)
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1028,7 +1047,7 @@ static int smm_xattn_fwd_impl(const float* qf, const float* mem, float* o, float
     } else
         hipLaunchKernelGGL(smm_xattn_kernel<18>, dim3(ns, B), dim3(256), lds, st, qf, mem, ws, rows, N, ns, kps, scale);
     IDIFF_CHECK_LAUNCH("smm_xattn_fwd");
-    hipLaunchKernelGGL(smm_xattn_combine_kernel, dim3((32 * Cm + 255) / 256, B), dim3(256), 0, st, ws, o, rows, ns_eff, Cm, lse);
+    hipLaunchKernelGGL(smm_xattn_combine_kernel, dim3((32 * Cm + 63) / 64, B), dim3(256), 0, st, ws, o, rows, ns_eff, Cm, lse);
     IDIFF_CHECK_LAUNCH("smm_xattn_combine");
     return IDIFF_OK;
 }
