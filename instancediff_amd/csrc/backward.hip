@@ -309,6 +309,53 @@ __global__ __launch_bounds__(256) void chan_ln_bwd_dx_kernel(const float* __rest
         op[(long long)c * HW] = rstd * (dp[(long long)c * HW] * gamma[c] - s1 - xh * s2);
     }
 }
+// The same with the pixel's channels held in registers: workgroup = 64 pixels x 4 waves, wave w owns channels w, w + 4, ..; dy and x are
+// read ONCE (the thread-per-pixel form above walks them twice with a 2-KB-per-thread footprint no cache holds: 5 passes over
+// [B, 256, N] tensors instead of 3, 8.5 ms of a training iteration).  C <= 4 * JMAX.
+template <int JMAX>
+__global__ __launch_bounds__(256) void chan_ln_bwd_dx_reg_kernel(const float* __restrict__ dy, long long dybs, const float* __restrict__ x, long long xbs,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
+                                                                 float* __restrict__ dx, long long dxbs, int C, int HW) {
+    __shared__ float part[2][4][64];
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + lane;
+    const bool ok = p < HW;
+    const int pc = ok ? p : 0;
+    const float mean = mean_rstd[((long long)b * HW + pc) * 2], rstd = mean_rstd[((long long)b * HW + pc) * 2 + 1];
+    const float* dp = dy + (long long)b * dybs + pc;
+    const float* xp = x + (long long)b * xbs + pc;
+    float g[JMAX], xh[JMAX];
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        const int c = wave + 4 * j;
+        g[j] = c < C ? dp[(long long)c * HW] : 0.f;
+        xh[j] = c < C ? xp[(long long)c * HW] : 0.f;
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        const int c = wave + 4 * j;
+        if (c < C) {
+            g[j] *= gamma[c];
+            xh[j] = (xh[j] - mean) * rstd;
+            s1 += g[j];
+            s2 += g[j] * xh[j];
+        }
+    }
+    part[0][wave][lane] = s1;
+    part[1][wave][lane] = s2;
+    __syncthreads();
+    const float S1 = ((part[0][0][lane] + part[0][1][lane]) + (part[0][2][lane] + part[0][3][lane])) / (float)C;
+    const float S2 = ((part[1][0][lane] + part[1][1][lane]) + (part[1][2][lane] + part[1][3][lane])) / (float)C;
+    if (!ok) return;
+    float* op = dx + (long long)b * dxbs + p;
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        const int c = wave + 4 * j;
+        if (c < C) op[(long long)c * HW] = rstd * (g[j] - S1 - xh[j] * S2);
+    }
+}
 // per plane: out[(b*C+c)*2] = sum_p dy*xhat, [..+1] = sum_p dy   (xhat from per-pixel mean/rstd)
 __global__ __launch_bounds__(256) void chan_ln_bwd_param_kernel(const float* __restrict__ dy, long long dybs, const float* __restrict__ x,
                                                                 long long xbs, const float* __restrict__ mean_rstd, float* __restrict__ out, int C,
@@ -562,8 +609,15 @@ extern "C" int idiff_chan_layernorm_bwd(const float* dy, int64_t dy_bstride, con
                                         const float* mean_rstd, float* dx, int64_t dx_bstride, float* dgamma, float* dbeta, float* ws, int B, int C,
                                         int HW, int accumulate, idiff_stream_t stream) {
     IDIFF_CHECK_ARG(dy && x && gamma && mean_rstd && dx && ws && B > 0 && C > 0 && HW > 0, "chan_layernorm_bwd: bad args");
-    hipLaunchKernelGGL(chan_ln_bwd_dx_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, ST, dy, (long long)dy_bstride, x, (long long)x_bstride,
-                       gamma, mean_rstd, dx, (long long)dx_bstride, C, HW);
+    if (C <= 128)
+        hipLaunchKernelGGL(chan_ln_bwd_dx_reg_kernel<32>, dim3((HW + 63) / 64, B), dim3(256), 0, ST, dy, (long long)dy_bstride, x, (long long)x_bstride,
+                           gamma, mean_rstd, dx, (long long)dx_bstride, C, HW);
+    else if (C <= 256)
+        hipLaunchKernelGGL(chan_ln_bwd_dx_reg_kernel<64>, dim3((HW + 63) / 64, B), dim3(256), 0, ST, dy, (long long)dy_bstride, x, (long long)x_bstride,
+                           gamma, mean_rstd, dx, (long long)dx_bstride, C, HW);
+    else
+        hipLaunchKernelGGL(chan_ln_bwd_dx_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, ST, dy, (long long)dy_bstride, x, (long long)x_bstride,
+                           gamma, mean_rstd, dx, (long long)dx_bstride, C, HW);
     IDIFF_CHECK_LAUNCH("chan_layernorm_bwd_dx");
     if (dgamma && dbeta) {
         hipLaunchKernelGGL(chan_ln_bwd_param_kernel, dim3(B * C), dim3(256), 0, ST, dy, (long long)dy_bstride, x, (long long)x_bstride, mean_rstd,

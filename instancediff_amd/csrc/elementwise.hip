@@ -213,6 +213,9 @@ __global__ void time_embed_kernel(const float* __restrict__ t, const float* __re
 // LayerNorm across channels of an NCHW map, two-pass.  Workgroup = 64 pixels; lane = pixel (coalesced along p), the four
 // waves split the channels and combine their per-pixel partial sums through LDS (a thread-per-pixel layout leaves a 32x32
 // map with 64 workgroups for the whole chip).
+// JMAX > 0: the wave's channels of a pixel are held in registers (C <= 4 * JMAX): x is read once; the operations and their order are
+// those of the JMAX = 0 form (three walks over x), so the results are the same bits.
+template <int JMAX>
 __global__ __launch_bounds__(256) void chan_layernorm_kernel(const float* __restrict__ x, long long xbs, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ out, long long obs, int C,
                                                              int HW, float eps, float* __restrict__ mean_rstd) {
@@ -222,16 +225,36 @@ __global__ __launch_bounds__(256) void chan_layernorm_kernel(const float* __rest
     const int p = blockIdx.x * 64 + lane;
     const bool ok = p < HW;
     const float* xb = x + (long long)b * xbs + (ok ? p : 0);
+    float xr[JMAX > 0 ? JMAX : 1];
+    if (JMAX > 0) {
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) xr[j] = wave + 4 * j < C ? xb[(long long)(wave + 4 * j) * HW] : 0.f;
+    }
     float s = 0.f;
-    for (int c = wave; c < C; c += 4) s += xb[(long long)c * HW];
+    if (JMAX > 0) {
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j)
+            if (wave + 4 * j < C) s += xr[j];
+    } else {
+        for (int c = wave; c < C; c += 4) s += xb[(long long)c * HW];
+    }
     part[wave][lane] = s;
     __syncthreads();
     const float mean = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) / (float)C;
     __syncthreads();
     float q = 0.f;
-    for (int c = wave; c < C; c += 4) {
-        const float d = xb[(long long)c * HW] - mean;
-        q += d * d;
+    if (JMAX > 0) {
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j)
+            if (wave + 4 * j < C) {
+                const float d = xr[j] - mean;
+                q += d * d;
+            }
+    } else {
+        for (int c = wave; c < C; c += 4) {
+            const float d = xb[(long long)c * HW] - mean;
+            q += d * d;
+        }
     }
     part[wave][lane] = q;
     __syncthreads();
@@ -242,7 +265,15 @@ __global__ __launch_bounds__(256) void chan_layernorm_kernel(const float* __rest
         mean_rstd[((long long)b * HW + p) * 2 + 1] = rstd;
     }
     float* ob = out + (long long)b * obs + p;
-    for (int c = wave; c < C; c += 4) ob[(long long)c * HW] = (xb[(long long)c * HW] - mean) * rstd * gamma[c] + beta[c];
+    if (JMAX > 0) {
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+            const int c = wave + 4 * j;
+            if (c < C) ob[(long long)c * HW] = (xr[j] - mean) * rstd * gamma[c] + beta[c];
+        }
+    } else {
+        for (int c = wave; c < C; c += 4) ob[(long long)c * HW] = (xb[(long long)c * HW] - mean) * rstd * gamma[c] + beta[c];
+    }
 }
 
 // score map: normalized feature (per pixel over C) . normalized text vectors
@@ -419,8 +450,18 @@ extern "C" int idiff_time_embed_fwd(const float* t, const float* freqs, int B, i
 extern "C" int idiff_chan_layernorm_fwd(const float* x, int64_t x_bstride, const float* gamma, const float* beta, float* out,
                                         int64_t out_bstride, int B, int C, int HW, float eps, float* mean_rstd, idiff_stream_t stream) {
     IDIFF_CHECK_ARG(x && out && gamma && beta && B > 0 && C > 0 && HW > 0, "chan_layernorm: bad args");
-    hipLaunchKernelGGL(chan_layernorm_kernel, dim3((HW + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, x, (long long)x_bstride, gamma,
+    {
+        const dim3 grid((HW + 63) / 64, B);
+        if (C <= 128)
+            hipLaunchKernelGGL(chan_layernorm_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, x, (long long)x_bstride, gamma,
                        beta, out, (long long)out_bstride, C, HW, eps, mean_rstd);
+        else if (C <= 256)
+            hipLaunchKernelGGL(chan_layernorm_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, x, (long long)x_bstride, gamma,
+                       beta, out, (long long)out_bstride, C, HW, eps, mean_rstd);
+        else
+            hipLaunchKernelGGL(chan_layernorm_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, x, (long long)x_bstride, gamma,
+                       beta, out, (long long)out_bstride, C, HW, eps, mean_rstd);
+    }
     IDIFF_CHECK_LAUNCH("chan_layernorm");
     return IDIFF_OK;
 }
