@@ -426,6 +426,65 @@ __global__ __launch_bounds__(256) void chan_normalize_bwd_kernel(const float* __
     for (int c = 0; c < C; ++c) op[(long long)c * HW] = (dp[(long long)c * HW] - yp[(long long)c * HW] * s) * inv;
 }
 
+// The two above with a pixel's channels in registers (workgroup = 64 pixels x 4 waves, wave w owns channels w, w + 4, ..; C <= 4 * JMAX):
+// every operand is read once.
+template <int JMAX>
+__global__ __launch_bounds__(256) void chan_normalize_fwd_reg_kernel(const float* __restrict__ x, long long xbs, float* __restrict__ y,
+                                                                     float* __restrict__ nrm, int C, int HW) {
+    __shared__ float part[4][64];
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + lane;
+    const bool ok = p < HW;
+    const float* xp = x + (long long)b * xbs + (ok ? p : 0);
+    float xr[JMAX];
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) xr[j] = wave + 4 * j < C ? xp[(long long)(wave + 4 * j) * HW] : 0.f;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) s += xr[j] * xr[j];
+    part[wave][lane] = s;
+    __syncthreads();
+    const float n = fmaxf(sqrtf((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])), 1e-12f);
+    if (!ok) return;
+    if (wave == 0) nrm[(long long)b * HW + p] = n;
+    float* yp = y + (long long)b * C * HW + p;
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j)
+        if (wave + 4 * j < C) yp[(long long)(wave + 4 * j) * HW] = xr[j] / n;
+}
+template <int JMAX>
+__global__ __launch_bounds__(256) void chan_normalize_bwd_reg_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                     const float* __restrict__ nrm, float* __restrict__ dx, long long dxbs, int C,
+                                                                     int HW) {
+    __shared__ float part[4][64];
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = blockIdx.x * 64 + lane;
+    const bool ok = p < HW;
+    const int pc = ok ? p : 0;
+    const float* dp = dy + (long long)b * C * HW + pc;
+    const float* yp = y + (long long)b * C * HW + pc;
+    float dr[JMAX], yr[JMAX];
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        dr[j] = wave + 4 * j < C ? dp[(long long)(wave + 4 * j) * HW] : 0.f;
+        yr[j] = wave + 4 * j < C ? yp[(long long)(wave + 4 * j) * HW] : 0.f;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) s += dr[j] * yr[j];
+    part[wave][lane] = s;
+    __syncthreads();
+    s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (!ok) return;
+    const float inv = 1.0f / nrm[(long long)b * HW + p];
+    float* op = dx + (long long)b * dxbs + p;
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j)
+        if (wave + 4 * j < C) op[(long long)(wave + 4 * j) * HW] = (dr[j] - yr[j] * s) * inv;
+}
+
 // out[b, idx[b], p] = x[b, 0, p], other channels zero
 __global__ void scatter_channel_kernel(const float* __restrict__ x, const int* __restrict__ idx, float* __restrict__ out, int B, int C, int HW) {
     const long long n = (long long)B * C * HW;
@@ -630,14 +689,24 @@ extern "C" int idiff_chan_layernorm_bwd(const float* dy, int64_t dy_bstride, con
 }
 extern "C" int idiff_chan_normalize_fwd(const float* x, int64_t x_bstride, float* y, float* nrm, int B, int C, int HW, idiff_stream_t stream) {
     IDIFF_CHECK_ARG(x && y && nrm && B > 0 && C > 0 && HW > 0, "chan_normalize_fwd: bad args");
-    hipLaunchKernelGGL(chan_normalize_fwd_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, ST, x, (long long)x_bstride, y, nrm, C, HW);
+    if (C <= 128)
+        hipLaunchKernelGGL(chan_normalize_fwd_reg_kernel<32>, dim3((HW + 63) / 64, B), dim3(256), 0, ST, x, (long long)x_bstride, y, nrm, C, HW);
+    else if (C <= 256)
+        hipLaunchKernelGGL(chan_normalize_fwd_reg_kernel<64>, dim3((HW + 63) / 64, B), dim3(256), 0, ST, x, (long long)x_bstride, y, nrm, C, HW);
+    else
+        hipLaunchKernelGGL(chan_normalize_fwd_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, ST, x, (long long)x_bstride, y, nrm, C, HW);
     IDIFF_CHECK_LAUNCH("chan_normalize_fwd");
     return IDIFF_OK;
 }
 extern "C" int idiff_chan_normalize_bwd(const float* dy, const float* y, const float* nrm, float* dx, int64_t dx_bstride, int B, int C, int HW,
                                         idiff_stream_t stream) {
     IDIFF_CHECK_ARG(dy && y && nrm && dx && B > 0 && C > 0 && HW > 0, "chan_normalize_bwd: bad args");
-    hipLaunchKernelGGL(chan_normalize_bwd_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, ST, dy, y, nrm, dx, (long long)dx_bstride, C, HW);
+    if (C <= 128)
+        hipLaunchKernelGGL(chan_normalize_bwd_reg_kernel<32>, dim3((HW + 63) / 64, B), dim3(256), 0, ST, dy, y, nrm, dx, (long long)dx_bstride, C, HW);
+    else if (C <= 256)
+        hipLaunchKernelGGL(chan_normalize_bwd_reg_kernel<64>, dim3((HW + 63) / 64, B), dim3(256), 0, ST, dy, y, nrm, dx, (long long)dx_bstride, C, HW);
+    else
+        hipLaunchKernelGGL(chan_normalize_bwd_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, ST, dy, y, nrm, dx, (long long)dx_bstride, C, HW);
     IDIFF_CHECK_LAUNCH("chan_normalize_bwd");
     return IDIFF_OK;
 }
