@@ -188,6 +188,52 @@ def test_losses_and_adam():
     assert _rel(pp.data, ref_p.data) < 1e-6
 
 
+def test_gather_segments_fills_the_flat_gradient_buffer_in_one_launch():
+    """idiff_gather_segments through FusedAdam._collect: gradients that autograd left as separate tensors (contiguous, a strided view,
+    a parameter without gradient, one whose gradient already IS its slice of the flat buffer) end up in the flat buffer bit for bit,
+    zeros where there was none; segment sizes around the 4096-element block of the kernel."""
+    g = _g(61)
+    sizes = [1, 7, 4095, 4096, 4097, 3 * 4096 + 5, 50000, 2]
+    ps = [nn.Parameter(torch.randn(n, generator=g).to(DEV)) for n in sizes]
+    opt = T.FusedAdam(ps, lr=1e-3)
+    opt.zero_grad()
+    want = []
+    for i, (pp, n) in enumerate(zip(ps, sizes)):
+        if i == 1:
+            want.append(torch.zeros(n))            # no gradient this step
+            continue
+        gr = torch.randn(n, generator=g)
+        want.append(gr)
+        if i == 3:
+            big = torch.zeros(2 * n, device=DEV)
+            big[::2] = gr.to(DEV)
+            pp.grad = big[::2]                     # not contiguous: copied first
+        else:
+            pp.grad = gr.to(DEV)
+    flats = opt.flat_grads()
+    flat = flats[0] if isinstance(flats, (list, tuple)) else flats
+    assert torch.equal(flat.cpu(), torch.cat(want))
+    for pp, w in zip(ps, want):                    # p.grad is now the parameter's view of the flat buffer
+        assert torch.equal(pp.grad.cpu(), w)
+    opt.flat_grads()                               # nothing left to gather: a second call changes nothing
+    assert torch.equal(flat.cpu(), torch.cat(want))
+
+
+@pytest.mark.parametrize("R,K,N,strided", [(5, 29, 50, False), (37, 256, 70, True), (160, 256, 256, False), (160, 64, 1024, True), (33, 512, 64, False)])
+def test_linear_mfma_fwd_vs_fp64(R, K, N, strided):
+    """idiff_linear_mfma_fwd (LinearFn's forward): y = x W^T + b on the matrix cores for any row count; x may be a column slice."""
+    g = _g(62)
+    xb = torch.randn(R, K + (8 if strided else 0), generator=g)
+    x = xb[:, 4:4 + K] if strided else xb
+    w, b = torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    ref = x.double() @ w.double().t() + b.double()
+    xd = xb.to(DEV)
+    y = T.LinearFn.apply(xd[:, 4:4 + K] if strided else xd, w.to(DEV), b.to(DEV))
+    assert _rel(y, ref) < 3e-6
+    y0 = T.LinearFn.apply(xd[:, 4:4 + K] if strided else xd, w.to(DEV), None)
+    assert _rel(y0, ref - b.double()) < 3e-6
+
+
 def _oracle_pair(model):
     opt = pipeline.load_options()
     mo = opt['models']['DriftNoise']
