@@ -560,6 +560,38 @@ def test_training_dropout_of_the_decoder_blocks_vs_oracle_with_the_same_masks():
     assert not torch.equal(g1, g2)
 
 
+def test_training_gradients_are_the_same_bits_from_run_to_run():
+    """Every reduction of the backward is a fixed-order one (split partials of the weight gradients, GroupNorm / LayerNorm plane sums,
+    key splits of the cross-attention, the gather into the flat buffers) and the two nets' streams share no tensor: two
+    forward+backward passes from the same state and batch give bit-identical loss records and flat gradient buffers (128x128, B = 3, so
+    the F(4x4,3x3) weight-gradient kernel, its split reduce and the fused cross-attention backward all run with several splits)."""
+    B, H, T_ = 3, 128, 20
+    model, sde = pipeline.build(phase="train", device=torch.device(DEV), T=T_, seed=0, score_map_dropout=0.0)
+    model.set_train()
+    with torch.no_grad():
+        for net in (model.drift_net, model.noise_net):
+            for m in net.CLIP_ScoreMapModule:
+                m.gamma.fill_(0.3)
+    batch = make_batch(B, H, seed=5)
+    g = _g(70)
+    t = torch.tensor([3, 11, 17]).reshape(B, 1, 1, 1)
+    eps = torch.randn(batch['input'].shape, generator=g)
+    model.input, model.target = batch['input'].to(DEV), batch['target'].to(DEV)
+    model.names, model.A_emb = batch['names'], batch['A_emb'].to(DEV)
+    model.t, model.drift_noised_x, _, model.std_noise, _ = sde.forward_diffusion(model.target, model.input, t=t, eps=eps.to(DEV))
+    runs = []
+    for _ in range(2):
+        rec = T.forward_backward_inputRes(model)[0]
+        flats = [f.clone() for f in model.drift_optimizer.flat_grads() + model.noise_optimizer.flat_grads()]
+        runs.append((rec.clone(), flats))
+    torch.cuda.synchronize()
+    assert torch.equal(runs[0][0], runs[1][0]), "loss records differ from run to run"
+    assert len(runs[0][1]) == len(runs[1][1]) > 0
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert float(a.abs().max()) > 0
+        assert torch.equal(a, b), "flat gradient buffers differ from run to run"
+
+
 @pytest.mark.parametrize("B,R,N", [(2, 20, 1024), (1, 20, 4096 + 32), (3, 7, 96), (2, 32, 65536)])
 def test_fused_scoremap_cross_attention_forward_backward_vs_fp64(B, R, N):
     """SmmXattnFn (training path): o and lse of the flash-decoding forward, dqf and dmem of the one-pass fused backward, against
