@@ -104,7 +104,11 @@ class CLIPDriftModel():
                 return nn.ModuleList([ScoreMapModule(visual_dim=score_map_ngf * score_map_ch_mult[i], CLIP_Type=CLIP_Type,
                                                      token_embed_dim=token_embed_dim, dropout=score_map_dropout, decoder_type=score_map_decoder)
                                       for i in range(len(score_map_ch_mult))])
-            raise NotImplementedError("single ScoreMapModule (if_MultiScoreMap=False) is not used by config.yml")
+            # reference models/drift_noise_model.py:113-114,130-131 builds ONE default ScoreMapModule() here and hands it to create_net();
+            # the UNet that consumes it (models/modules/*, chosen by dnet_settings.module_name) is not part of the reference snapshot,
+            # so how a single module is wired into the levels cannot be restated -- config.yml sets if_MultiScoreMap: True
+            raise NotImplementedError("if_MultiScoreMap=False: the single-ScoreMapModule UNet is absent from the reference snapshot "
+                                      "(models/modules/), nothing to restate; Configurations/config.yml uses if_MultiScoreMap: True")
 
         self.drift_prompt = prompts(dnet_settings)
         self.noise_prompt = prompts(nnet_settings)
