@@ -284,3 +284,23 @@ def test_native_224_chain_vs_oracle_on_the_winograd_path():
     assert torch.equal(out2[1:], out1)
     ref = _oracle_chain(model, T, b2, x_T, noises)
     _check_vs_oracle(out2, ref, b2['target'], "224x224 (native)")
+
+
+def test_non_square_160x288_chain_vs_oracle():
+    """H != W: 160 x 288 (levels 160x288 / 80x144 / 40x72 / 20x36): whole 16x32 patches at the top, partial patches in x at 80x144,
+    in both directions at 40x72, 720 tokens in the mid attention, N = 46 080 / 11 520 / 2 880 / 720 keys in the ScoreMapModules;
+    2-step chain against the oracle, B = 2 batch invariance."""
+    T, H, W = 2, 160, 288
+    model, sde = pipeline.build(phase="test", device=torch.device(DEV), T=T, seed=0)
+    model.set_eval()
+    make_scoremap_branch_visible(model)
+    b2 = make_batch(2, H, W, seed=160)
+    g = torch.Generator().manual_seed(161)
+    x_T = b2['input'] + 0.4 * torch.randn(b2['input'].shape, generator=g)
+    noises = torch.randn((T,) + tuple(b2['input'].shape), generator=g)
+    out2 = _chain(model, b2, x_T, noises)
+    assert tuple(out2.shape[-2:]) == (H, W)
+    out1 = _chain(model, {k: v[1:] for k, v in b2.items()}, x_T[1:], noises[:, 1:].contiguous())
+    assert torch.equal(out2[1:], out1)
+    ref = _oracle_chain(model, T, b2, x_T, noises)
+    _check_vs_oracle(out2, ref, b2['target'], "160x288 (non-square)")
