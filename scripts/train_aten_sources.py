@@ -45,6 +45,17 @@ def main():
         k = (ev.name, where, tuple(ev.input_shapes[0]) if ev.input_shapes else ())
         agg[k][0] += 1
         agg[k][1] += sum(kk.duration for kk in ev.kernels)
+    # device-to-device copies (hipMemcpyAsync -> __amd_rocclr_copyBuffer) by the op that issued them
+    cp = collections.defaultdict(lambda: [0, 0.0])
+    for ev in prof.events():
+        ks = [k for k in (ev.kernels or []) if "copyBuffer" in k.name or "Memcpy" in k.name or "memcpy" in k.name]
+        if ks:
+            key = (ev.name, tuple(ev.input_shapes[0]) if ev.input_shapes else ())
+            cp[key][0] += len(ks)
+            cp[key][1] += sum(k.duration for k in ks)
+    print("device-to-device copies by issuing op:")
+    for (name, shp), (n, us) in sorted(cp.items(), key=lambda kv: -kv[1][0])[:25]:
+        print("%5d x %-28s %9.1f us %s" % (n, name, us, list(shp)))
     rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
     print("%d ATen ops with kernels; by (op, innermost package frame):" % sum(v[0] for v in agg.values()))
     for (name, where, shp), (n, us) in rows[:60]:
