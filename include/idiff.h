@@ -414,7 +414,9 @@ int idiff_colsum_prod(const float* x, const float* y, float* out, int R, int N, 
 int idiff_layernorm_rows_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                              const float* mean_rstd, float* dx, int64_t lddx, float* dgamma, float* dbeta, int R, int C,
                              int accumulate, idiff_stream_t stream);
-/* ws: 2*B*C floats */
+/* ws: idiff_chan_layernorm_bwd_ws_floats(B, C, HW) floats (>= 2*B*C): per-(sample, workgroup, channel) partials of dgamma / dbeta,
+ * reduced in a fixed order; dx and the partials come out of ONE pass over dy and x (C <= 256) */
+int64_t idiff_chan_layernorm_bwd_ws_floats(int B, int C, int HW);
 int idiff_chan_layernorm_bwd(const float* dy, int64_t dy_bstride, const float* x, int64_t x_bstride, const float* gamma,
                              const float* mean_rstd, float* dx, int64_t dx_bstride, float* dgamma, float* dbeta, float* ws,
                              int B, int C, int HW, int accumulate, idiff_stream_t stream);

@@ -115,6 +115,7 @@ SIGNATURES = {
     "idiff_scale_cols": (I, [P, P, P, I, I, c_stream]),
     "idiff_colsum_prod": (I, [P, P, P, I, I, c_stream]),
     "idiff_layernorm_rows_bwd": (I, [P, I64, P, I64, P, P, P, I64, P, P, I, I, I, c_stream]),
+    "idiff_chan_layernorm_bwd_ws_floats": (I64, [I, I, I]),
     "idiff_chan_layernorm_bwd": (I, [P, I64, P, I64, P, P, P, I64, P, P, P, I, I, I, I, c_stream]),
     "idiff_chan_normalize_fwd": (I, [P, I64, P, P, I, I, I, c_stream]),
     "idiff_chan_normalize_bwd": (I, [P, P, P, P, I64, I, I, I, c_stream]),

@@ -356,6 +356,109 @@ __global__ __launch_bounds__(256) void chan_ln_bwd_dx_reg_kernel(const float* __
         if (c < C) op[(long long)c * HW] = rstd * (g[j] - S1 - xh[j] * S2);
     }
 }
+// dx AND the parameter-gradient partials in one pass (dgamma[c] = sum dy*xhat, dbeta[c] = sum dy over batch and pixels): the workgroup
+// walks TPW consecutive 64-pixel tiles of its sample; per tile every wave turns its [64 channels][64 pixels] products through LDS (row
+// stride 65: conflict-free both ways) so that lane L sums the 64 pixels of channel wave + 4 L, and keeps the running sums in two
+// registers; one partial per (sample, workgroup, channel) leaves for ws[((b * G + g) * C + c) * 2 + {0, 1}], reduced in a fixed order
+// by pair_rows_sum_kernel.  Replaces the separate parameter pass (two more reads of dy and x).
+constexpr int CLN_TPW = 8;
+template <int JMAX>
+__global__ __launch_bounds__(256) void chan_ln_bwd_fused_kernel(const float* __restrict__ dy, long long dybs, const float* __restrict__ x, long long xbs,
+                                                                const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
+                                                                float* __restrict__ dx, long long dxbs, float* __restrict__ ws, int C, int HW,
+                                                                int tpw) {
+    extern __shared__ float cln_smem[];
+    float* part = cln_smem;                         // [2][4][64]
+    float* gam = cln_smem + 512;                    // [4 * JMAX]
+    float* tr = gam + 4 * JMAX + (threadIdx.x >> 6) * (JMAX * 65);  // this wave's [JMAX][65]
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = threadIdx.x; c < 4 * JMAX; c += 256) gam[c] = c < C ? gamma[c] : 0.f;
+    __syncthreads();
+    float accg = 0.f, accb = 0.f;  // running sums of channel wave + 4 * lane (lanes < JMAX)
+    const int tile0 = blockIdx.x * tpw;
+    for (int t = 0; t < tpw; ++t) {
+        const int p = (tile0 + t) * 64 + lane;
+        if ((tile0 + t) * 64 >= HW) break;  // uniform
+        const bool ok = p < HW;
+        const int pc = ok ? p : 0;
+        const float mean = mean_rstd[((long long)b * HW + pc) * 2], rstd = mean_rstd[((long long)b * HW + pc) * 2 + 1];
+        const float* dp = dy + (long long)b * dybs + pc;
+        const float* xp = x + (long long)b * xbs + pc;
+        float d[JMAX], xh[JMAX];
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+            const int c = wave + 4 * j;
+            d[j] = (c < C && ok) ? dp[(long long)c * HW] : 0.f;
+            xh[j] = c < C ? xp[(long long)c * HW] : 0.f;
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+            const int c = wave + 4 * j;
+            xh[j] = c < C ? (xh[j] - mean) * rstd : 0.f;
+            const float g = d[j] * gam[c];
+            s1 += g;
+            s2 += g * xh[j];
+        }
+        __syncthreads();  // the previous tile's readers of `part` are done
+        part[wave * 64 + lane] = s1;
+        part[256 + wave * 64 + lane] = s2;
+        __syncthreads();
+        const float S1 = ((part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane])) / (float)C;
+        const float S2 = ((part[256 + lane] + part[320 + lane]) + (part[384 + lane] + part[448 + lane])) / (float)C;
+        if (ok) {
+            float* op = dx + (long long)b * dxbs + p;
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j) {
+                const int c = wave + 4 * j;
+                if (c < C) op[(long long)c * HW] = rstd * (d[j] * gam[c] - S1 - xh[j] * S2);
+            }
+        }
+        // parameter partials: pixels onto the sum, channels onto the lanes (wave-private area; LDS is in order within a wave)
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) tr[j * 65 + lane] = d[j] * xh[j];
+        if (lane < JMAX) {
+            float a = 0.f;
+#pragma unroll 16
+            for (int i = 0; i < 64; ++i) a += tr[lane * 65 + i];
+            accg += a;
+        }
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) tr[j * 65 + lane] = d[j];
+        if (lane < JMAX) {
+            float a = 0.f;
+#pragma unroll 16
+            for (int i = 0; i < 64; ++i) a += tr[lane * 65 + i];
+            accb += a;
+        }
+    }
+    const int c = wave + 4 * lane;
+    if (lane < JMAX && c < C) {
+        float* o = ws + (((long long)b * gridDim.x + blockIdx.x) * C + c) * 2;
+        o[0] = accg;
+        o[1] = accb;
+    }
+}
+// dgamma[c] (+)= sum_r in[(r*C+c)*2], dbeta[c] (+)= sum_r in[(r*C+c)*2+1] over R rows: 16 channels x 16 row lanes per workgroup, lane sums
+// added in lane order
+__global__ __launch_bounds__(256) void pair_rows_sum_kernel(const float* __restrict__ in, float* __restrict__ o0, float* __restrict__ o1, int R, int C,
+                                                            int accumulate) {
+    __shared__ float red[CS_LANES][CS_COLS + 1];
+    const int c = blockIdx.x * CS_COLS + threadIdx.x % CS_COLS, rl = threadIdx.x / CS_COLS;
+    float a = 0.f, b2 = 0.f;
+    if (c < C)
+        for (int r = rl; r < R; r += CS_LANES) {
+            a += in[((long long)r * C + c) * 2];
+            b2 += in[((long long)r * C + c) * 2 + 1];
+        }
+    a = colsum_lanes(a, red);
+    b2 = colsum_lanes(b2, red);
+    if (rl == 0 && c < C) {
+        o0[c] = accumulate ? o0[c] + a : a;
+        o1[c] = accumulate ? o1[c] + b2 : b2;
+    }
+}
 // per plane: out[(b*C+c)*2] = sum_p dy*xhat, [..+1] = sum_p dy   (xhat from per-pixel mean/rstd)
 __global__ __launch_bounds__(256) void chan_ln_bwd_param_kernel(const float* __restrict__ dy, long long dybs, const float* __restrict__ x,
                                                                 long long xbs, const float* __restrict__ mean_rstd, float* __restrict__ out, int C,
@@ -664,10 +767,37 @@ extern "C" int idiff_layernorm_rows_bwd(const float* dy, int64_t lddy, const flo
     }
     return IDIFF_OK;
 }
+static inline int cln_groups(int HW, int* tpw) {  // workgroups per sample of the fused form and tiles per workgroup
+    const int ntiles = (HW + 63) / 64;
+    *tpw = ntiles >= 64 ? CLN_TPW : 1;
+    return (ntiles + *tpw - 1) / *tpw;
+}
+extern "C" int64_t idiff_chan_layernorm_bwd_ws_floats(int B, int C, int HW) {
+    if (B <= 0 || C <= 0 || HW <= 0) return -1;
+    int tpw;
+    const int G = cln_groups(HW, &tpw);
+    return 2ll * B * C * (G > 1 ? G : 1);
+}
 extern "C" int idiff_chan_layernorm_bwd(const float* dy, int64_t dy_bstride, const float* x, int64_t x_bstride, const float* gamma,
                                         const float* mean_rstd, float* dx, int64_t dx_bstride, float* dgamma, float* dbeta, float* ws, int B, int C,
                                         int HW, int accumulate, idiff_stream_t stream) {
     IDIFF_CHECK_ARG(dy && x && gamma && mean_rstd && dx && ws && B > 0 && C > 0 && HW > 0, "chan_layernorm_bwd: bad args");
+    if (dgamma && dbeta && C <= 256) {  // dx and the parameter partials in one pass
+        int tpw;
+        const int G = cln_groups(HW, &tpw);
+        const int jmax = C <= 128 ? 32 : 64;
+        const size_t lds = (size_t)(512 + 4 * jmax + 4 * jmax * 65) * sizeof(float);
+        static idiff_dyn_lds_cache lc[2];
+        auto kern = C <= 128 ? chan_ln_bwd_fused_kernel<32> : chan_ln_bwd_fused_kernel<64>;
+        hipError_t e = idiff_ensure_dyn_lds(lc[C <= 128 ? 0 : 1], reinterpret_cast<const void*>(kern), lds);
+        if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "chan_layernorm_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(kern, dim3(G, B), dim3(256), lds, ST, dy, (long long)dy_bstride, x, (long long)x_bstride, gamma, mean_rstd, dx,
+                           (long long)dx_bstride, ws, C, HW, tpw);
+        IDIFF_CHECK_LAUNCH("chan_layernorm_bwd_fused");
+        hipLaunchKernelGGL(pair_rows_sum_kernel, dim3((C + CS_COLS - 1) / CS_COLS), dim3(256), 0, ST, ws, dgamma, dbeta, B * G, C, accumulate);
+        IDIFF_CHECK_LAUNCH("chan_layernorm_bwd_param_sum");
+        return IDIFF_OK;
+    }
     if (C <= 128)
         hipLaunchKernelGGL(chan_ln_bwd_dx_reg_kernel<32>, dim3((HW + 63) / 64, B), dim3(256), 0, ST, dy, (long long)dy_bstride, x, (long long)x_bstride,
                            gamma, mean_rstd, dx, (long long)dx_bstride, C, HW);

@@ -424,7 +424,7 @@ class ChanLayerNormFn(torch.autograd.Function):
         dx = torch.empty((B, Cc, H, W), device=x.device, dtype=torch.float32)
         dg = torch.empty((Cc,), device=x.device, dtype=torch.float32)
         db = torch.empty_like(dg)
-        ws = torch.empty((2 * B * Cc,), device=x.device, dtype=torch.float32)
+        ws = torch.empty((lib.idiff_chan_layernorm_bwd_ws_floats(B, Cc, H * W),), device=x.device, dtype=torch.float32)
         check(lib.idiff_chan_layernorm_bwd(_p(dy), _bs(dy), _p(x), _bs(x, "x"), _p(_c(gamma)), _p(mr), _p(dx), _bs(dx), _p(dg), _p(db), _p(ws), B,
                                            Cc, H * W, 0, _stream()), "chan_layernorm_bwd")
         return dx, dg, db, None
