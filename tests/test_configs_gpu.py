@@ -155,8 +155,8 @@ def _flat_grads(model):
     return torch.cat([g.reshape(-1) for g in model.drift_optimizer.flat_grads() + model.noise_optimizer.flat_grads()]).clone()
 
 
-def test_c3_train_step_256_vs_oracle_autograd():
-    B, H, T_ = 2, 256, 100
+def _train_step_vs_oracle(H, W, seed, what):
+    B, T_ = 2, 100
     model, sde = pipeline.build(phase="train", device=torch.device(DEV), T=T_, seed=0, score_map_dropout=0.0)
     model.set_train()
     with torch.no_grad():  # let the score-map branch carry gradient signal (gamma is 1e-4 at init)
@@ -166,8 +166,8 @@ def test_c3_train_step_256_vs_oracle_autograd():
     rd, rn = oracle_nets(model)
     rd.train(), rn.train()
     te = unet_ref.StubTextEncoder()
-    batch = make_batch(B, H, seed=31)
-    g = torch.Generator().manual_seed(32)
+    batch = make_batch(B, H, W, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
     t = torch.tensor([[[[7]]], [[[63]]]])
     eps = torch.randn(batch['input'].shape, generator=g)
     osde = sde_ref.DriftSDERef(T_, rd, rn, max_sigma=0.4)
@@ -180,7 +180,7 @@ def test_c3_train_step_256_vs_oracle_autograd():
     def pyr(sms, lab):  # drift_noise_model.py:234-240 with torchvision-0.14 tensor Resize semantics (bilinear, no antialias)
         tot = 0
         for i, sm in enumerate(sms):
-            lb = lab if i == 0 else F.interpolate(lab, size=(H >> i, H >> i), mode="bilinear", align_corners=False, antialias=False)
+            lb = lab if i == 0 else F.interpolate(lab, size=(H >> i, W >> i), mode="bilinear", align_corners=False, antialias=False)
             tot = tot + F.mse_loss(sm, lb)
         return tot / 2.0
     l0 = F.mse_loss(pd, tgt) + F.mse_loss(pn, std_noise) + pyr(dsm, tgt) + pyr(nsm, std_noise)
@@ -202,7 +202,24 @@ def test_c3_train_step_256_vs_oracle_autograd():
             e = float((p.grad.cpu() - rg).abs().max()) / scale
             worst = max(worst, e)
             assert e < 2e-3, (tag, k, e)
-    print(f"c3 256x256 B=2: loss {loss:.6f} (oracle {float(l0.detach()):.6f}), worst relative parameter-gradient error {worst:.2e}")
+    print(f"{what} B=2: loss {loss:.6f} (oracle {float(l0.detach()):.6f}), worst relative parameter-gradient error {worst:.2e}")
+
+
+def test_c3_train_step_256_vs_oracle_autograd():
+    _train_step_vs_oracle(256, 256, 31, "c3 256x256")
+
+
+def test_train_step_native_224_vs_oracle_autograd():
+    """The training step at the reference's native 224 x 224 (data/MedSpeckle.py:44-45): levels 224 / 112 / 56 / 28 -- partial 16x32
+    patches in the forward and data-gradient convs, the F(4x4,3x3) weight gradient on the two upper levels (224 = 14 x 16, 112 = 7 x
+    16), the F(2x2,3x3) / direct forms below (56 and 28 are not multiples of 16), GroupNorm backward on ragged partial grids; loss and
+    every parameter gradient against the oracle's autograd."""
+    _train_step_vs_oracle(224, 224, 41, "training step 224x224")
+
+
+def test_train_step_non_square_96x160_vs_oracle_autograd():
+    """H != W in the backward: 96 x 160 (48x80 / 24x40 / 12x20 below)."""
+    _train_step_vs_oracle(96, 160, 51, "training step 96x160")
 
 
 def test_c3_batch32_gradient_is_mean_of_microbatch_gradients():
