@@ -325,18 +325,105 @@ def log(msg):
 _T0 = time.time()
 
 
-def train_measure(args, world, rank, dev, batch_size, steps, warmup):
+def train_roofline(it, iters=2):
+    """Per-kernel-class roofline of the training iteration, measured live: `iters` more iterations on ONE stream with HIP events on the
+    launch stream around every library call of a matrix-core kernel class (ops.PROFILE hooks in ops.conv2d and train_ops), the FLOP
+    each call EXECUTES (F(4x4,3x3) forms: 36/144 of the direct 2*9*Cin*Cout*H*W*B, F(2x2,3x3): 16/36, the fused ScoreMapModule
+    attention with its query rows padded to the 32-row tile) / its time / the 157.3 TFLOP/s f32 matrix peak; then one iteration under
+    torch.profiler to count the device launches that are not this library's (ATen / runtime copies)."""
+    from instancediff_amd import ops, train_ops
+    two = train_ops.TRAIN_TWO_STREAMS
+    train_ops.TRAIN_TWO_STREAMS = False
+    try:
+        it()
+        torch.cuda.synchronize()
+        ops.PROFILE = []
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            it()
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - t0) / iters * 1e3
+        recs, ops.PROFILE = ops.PROFILE, None
+    finally:
+        ops.PROFILE = None
+        train_ops.TRAIN_TWO_STREAMS = two
+    CONV = {0: ("conv_igemm_kernel (direct form)", 1.0), 1: ("conv_wino_kernel F(2x2,3x3)", 16.0 / 36.0), 2: ("conv1x1 streaming f32", 1.0),
+            3: ("conv_wino4_kernel F(4x4,3x3) forward + data gradient", 0.25), 4: ("conv_wino4h_kernel F(4x4,3x3) forward + data gradient", 0.25),
+            5: ("conv1x1_x3_kernel (bf16x3 split; fp32-equivalent flops)", 1.0)}
+    WG = {0: ("conv_wgrad_kernel (direct form)", 1.0), 1: ("wino_wgrad_kernel F(2x2,3x3) weight gradient", 16.0 / 36.0),
+          2: ("wgrad1x1_kernel (streaming 1x1 weight gradient)", 1.0), 3: ("wino4_wgrad_kernel F(4x4,3x3) weight gradient", 0.25)}
+    groups = {}
+    for r in recs:
+        kind = r.get("kind", "conv")
+        if kind == "conv":
+            name, f = CONV.get(r["algo"], ("conv algo %d" % r["algo"], 1.0))
+        elif kind == "wgrad":
+            name, f = WG.get(r.get("algo", 0), ("wgrad algo %s" % r.get("algo"), 1.0))
+        else:
+            name, f = {"bgemm": "bgemm_kernel (token-side batched GEMMs)", "smm_xattn_fwd": "smm_xattn_kernel<64> (ScoreMapModule attention forward)",
+                       "smm_xattn_bwd": "smm_xattn_bwd_kernel (ScoreMapModule attention backward)"}[kind], 1.0
+        g = groups.setdefault(name, {"n": 0, "ms": 0.0, "fl": 0.0})
+        g["n"] += 1
+        g["ms"] += r["e0"].elapsed_time(r["e1"])
+        g["fl"] += r["flops"] * f
+    rows = []
+    for name, g in sorted(groups.items(), key=lambda kv: -kv[1]["ms"]):
+        tf = g["fl"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        rows.append({"kernel": name, "launches_per_it": g["n"] / iters, "ms_per_it_single_stream": round(g["ms"] / iters, 2),
+                     "executed_gflop_per_it": round(g["fl"] / iters / 1e9, 1), "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4)})
+    timed_ms = sum(g["ms"] for g in groups.values()) / iters
+    exec_fl = sum(g["fl"] for g in groups.values()) / iters
+    out = {"bound": "mfma", "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "kernels": rows[:5], "other_kernel_classes": rows[5:],
+           "ms_per_it_single_stream_wall": round(single_ms, 2), "matrix_kernel_ms_per_it_single_stream": round(timed_ms, 2),
+           "executed_gflop_per_it": round(exec_fl / 1e9, 1),
+           "how": "HIP events on the launch stream around each library call, %d single-stream iterations after the timed ones" % iters}
+    # launches outside the library: one iteration under torch.profiler (device activity only)
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            it()
+            torch.cuda.synchronize()
+        total, aten, names = 0, 0, {}
+        for ev in prof.events():
+            if ev.device_type is None or "cuda" not in str(ev.device_type).lower():
+                continue
+            total += 1
+            nm = ev.name
+            if any(k in nm for k in ("at::native", "at::cuda", "rocclr", "copyBuffer", "Memcpy", "memcpy", "Memset", "memset", "Cijk_", "rocblas", "fillBuffer")):
+                aten += 1
+                key = nm.split("<")[0].split("(")[0][-60:]
+                names[key] = names.get(key, 0) + 1
+        out["device_launches_per_it"] = total
+        out["aten_launches_per_it"] = aten
+        out["aten_kernels"] = dict(sorted(names.items(), key=lambda kv: -kv[1])[:8])
+    except Exception as e:  # a profiler that cannot attach (e.g. under rocprofv3) must not hide the line
+        out["aten_launches_per_it"] = None
+        out["aten_note"] = "torch.profiler unavailable: %r" % (e,)
+    return out
+
+
+def train_measure(args, world, rank, dev, batch_size, steps, warmup, wire=None, exchange=True, roofline=False):
     """feed_data (forward diffusion) + 2 UNet forwards + losses + backward + flat RCCL all-reduce + fused Adam, `steps` timed
-    iterations after `warmup`; returns (seconds, last loss) -- max over ranks."""
+    iterations after `warmup`; returns a dict: seconds (max over ranks), last loss, dropout and -- at world > 1 -- the data-parallel
+    exchange as the step saw it (GradSync.timings(): span / exposed ms per step, mean over the timed steps of rank 0), the bytes one
+    step puts on the wire per rank, and the same two all-reduces timed ALONE right after (nothing to overlap with).
+    exchange=False: the same ranks without the exchange (GradSync switched off; a timing reference, the ranks' weights drift apart)."""
     import torch.distributed as dist
     from instancediff_amd import pipeline
     from instancediff_amd.utils.synthetic import make_batch
     T = 100 if args.T == 1000 else args.T
+    os.environ["IDIFF_GRAD_WIRE"] = wire or args.grad_wire
     model, sde = pipeline.build(phase="train", device=dev, T=T, seed=0, dist=world > 1)
     model.set_train()
     sde.set_seed(1234 + rank)
     batch = make_batch(batch_size, args.size, seed=1234 + rank, mixed=True)
     torch.manual_seed(99 + rank)
+    sync = model.grad_sync
+    if sync is not None:
+        sync.timing = True
+        if not exchange:
+            sync.active = False
 
     def it():
         model.feed_data(batch)
@@ -352,22 +439,58 @@ def train_measure(args, world, rank, dev, batch_size, steps, warmup):
     for _ in range(warmup):
         loss = it()
     barrier()
+    if sync is not None:
+        sync.timings()  # drop the warm-up marks
+    lib = __import__("instancediff_amd.ops", fromlist=["_lib"])._lib.load()
+    n0 = lib.idiff_launch_count()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = it()
     barrier()
     el = time.perf_counter() - t0
+    launches = (lib.idiff_launch_count() - n0) / steps
     if world > 1:
         tmax = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         el = float(tmax.item())
-    return el, loss, float(getattr(model, "score_map_dropout", 0.1))
+    out = {"el": el, "loss": loss, "dropout": float(getattr(model, "score_map_dropout", 0.1)), "library_launches_per_it": launches,
+           "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+    if sync is not None and sync.active:
+        tm = sync.timings()
+        flats = model.drift_optimizer.flat_grads() + model.noise_optimizer.flat_grads()
+        nbytes = sum(f.numel() for f in flats) * (2 if sync.wire == "bf16" else 4)
+        out["exchange"] = {"wire": sync.wire, "bytes_per_step_per_rank": nbytes, "all_reduces_per_step": len(flats),
+                           "span_ms": round(sum(t["span_ms"] for t in tm) / max(len(tm), 1), 3),
+                           "exposed_ms": round(sum(t["exposed_ms"] for t in tm) / max(len(tm), 1), 3),
+                           "span_note": "first start() -> exchanges complete on the step's stream (overlaps the noise net's backward)",
+                           "exposed_note": "finish() entered (both backwards + gather done) -> exchanges complete: what the step waited for"}
+        # the same exchange alone: nothing on the GPU to hide behind
+        reps = 5
+        barrier()
+        sync.timing = False
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            sync.start(flats)
+            sync.finish()
+        barrier()
+        iso = (time.perf_counter() - t1) / reps
+        out["exchange"]["isolated_ms"] = round(iso * 1e3, 3)
+        out["exchange"]["isolated_busbw_GBps"] = round(2.0 * (world - 1) / world * nbytes / iso / 1e9, 1)
+    if roofline and rank == 0 and world == 1:
+        try:
+            out["roofline"] = train_roofline(it)
+        except Exception as e:  # a reported side measurement
+            out["roofline"] = {"error": repr(e)}
+    del model, sde
+    torch.cuda.empty_cache()
+    return out
 
 
 def train_bench(args, world, rank, dev):
     """Secondary line (BASELINE config c3): training iterations/sec of CLIPDriftModel.optimize_parameters."""
     import torch.distributed as dist
-    el, loss, _ = train_measure(args, world, rank, dev, args.batch, args.steps, args.warmup)
+    m = train_measure(args, world, rank, dev, args.batch, args.steps, args.warmup, roofline=not args.no_roofline)
+    el, loss = m["el"], m["loss"]
     if rank == 0:
         value = world * args.steps / el
         label = "training iterations/sec (%dx%d bs%d/GPU)" % (args.size, args.size, args.batch)
@@ -376,13 +499,60 @@ def train_bench(args, world, rank, dev):
         print(json.dumps({"metric": label, "value": round(value, 4), "grad_wire": args.grad_wire,
                           "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(el / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                          "dtype": "f32", "data": "synthetic", "last_loss": loss,
+                          "dtype": "f32", "data": "synthetic", "last_loss": loss, "exchange": m.get("exchange"),
+                          "library_launches_per_it": m["library_launches_per_it"], "roofline": m.get("roofline"),
                           "config": {"workload": "%dx%d synthetic, batch %d per GPU, drift+noise UNet fwd/bwd, pyramid losses, Adam"
                                                  % (args.size, args.size, args.batch), "global_batch": args.batch * world,
                                      "parallelism": "dp%d (flat RCCL all-reduce)" % world,
-                                     "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}}), flush=True)
+                                     "peak_mem_GB": m["peak_mem_GB"]}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def stored_n1_train():
+    """(it/s, source) of the newest N=1 training line kept under profiles/ (profiles/rNN/e_bench_train_b32.json), for the weak-scaling
+    efficiency of the N-rank training leg; (None, None) when there is none"""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "e_bench_train_b32.json")), reverse=True):
+        try:
+            with open(path) as f:
+                doc = json.loads(f.read().strip().splitlines()[-1])
+            if doc.get("n_gpus", 1) == 1 and doc.get("value"):
+                return float(doc["value"]), os.path.relpath(path, ROOT)
+        except (OSError, ValueError, IndexError):
+            continue
+    return None, None
+
+
+def train_leg_ranks(args, world, rank, dev):
+    """BASELINE c3 across the ranks of a multi-GPU run, inside the default line (every rank calls this; rank 0 gets the dict): 256x256,
+    batch 32 per GPU, fp32 compute, ONE flat RCCL all-reduce per optimizer per step started under the backward (parallel.GradSync) --
+    with the fp32 wire, then the same without the exchange (what the collective costs the step), then the bf16 wire as a labelled
+    variant.  The all-reduce is reported three ways: its span inside the step, the part the step waited for, and alone."""
+    steps, warmup, bs = 6, 2, 32
+    t0 = time.time()
+
+    def one(wire, exchange=True):
+        m = train_measure(args, world, rank, dev, bs, steps, warmup, wire=wire, exchange=exchange)
+        return {"it_per_s": round(world * steps / m["el"], 4), "ms_per_step": round(m["el"] / steps * 1e3, 2), "exchange": m.get("exchange"),
+                "last_loss": m["loss"], "peak_mem_GB": m["peak_mem_GB"]}
+    f32 = one("fp32")
+    none = one("fp32", exchange=False)
+    b16 = one("bf16")
+    n1, src = stored_n1_train()
+    out = {"n_gpus": world, "batch_per_gpu": bs, "global_batch": bs * world, "steps": steps, "warmup": warmup, "dtype": "f32",
+           "grad_wire": "fp32", "it_per_s": f32["it_per_s"], "ms_per_step": f32["ms_per_step"], "exchange": f32["exchange"],
+           "ms_per_step_without_exchange": none["ms_per_step"],
+           "exchange_cost_ms": round(f32["ms_per_step"] - none["ms_per_step"], 2),
+           "n1_it_per_s": n1, "n1_source": src,
+           "weak_scaling_efficiency_vs_n1": round(f32["it_per_s"] / (world * n1), 4) if n1 else None,
+           "bf16_wire_variant": {"label": "VARIANT: bf16 gradient wire format (fp32 compute and fp32 master gradients)", "it_per_s": b16["it_per_s"],
+                                 "ms_per_step": b16["ms_per_step"], "exchange": b16["exchange"],
+                                 "weak_scaling_efficiency_vs_n1": round(b16["it_per_s"] / (world * n1), 4) if n1 else None},
+           "last_loss": f32["last_loss"], "peak_mem_GB": f32["peak_mem_GB"], "leg_seconds": round(time.time() - t0, 1),
+           "workload": "%dx%d synthetic, batch %d per GPU, drift+noise UNet fwd/bwd, pyramid losses, flat RCCL all-reduce of both optimizers' "
+                       "gradient buffers, 2 fused Adam steps (BASELINE c3)" % (args.size, args.size, bs)}
+    return out if rank == 0 else None
 
 
 def train_leg(args, dev):
@@ -390,53 +560,73 @@ def train_leg(args, dev):
     iterations after the headline measurement (same process, the sampling model already freed by the caller)."""
     steps, warmup, bs = 6, 2, 32
     t0 = time.time()
-    el, loss, p_drop = train_measure(args, 1, 0, dev, bs, steps, warmup)
-    return {"it_per_s": round(steps / el, 4), "ms_per_step": round(el / steps * 1e3, 2), "batch": bs, "dropout": p_drop, "steps": steps,
-            "warmup": warmup, "dtype": "f32", "last_loss": loss, "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
-            "workload": "%dx%d synthetic, batch %d, drift+noise UNet fwd/bwd, pyramid losses, 2 fused Adam steps (BASELINE c3 at N=1, fp32)"
-                        % (args.size, args.size, bs), "leg_seconds": round(time.time() - t0, 1)}
+    m = train_measure(args, 1, 0, dev, bs, steps, warmup, roofline=not args.no_roofline)
+    el = m["el"]
+    out = {"it_per_s": round(steps / el, 4), "ms_per_step": round(el / steps * 1e3, 2), "batch": bs, "dropout": m["dropout"], "steps": steps,
+           "warmup": warmup, "dtype": "f32", "last_loss": m["loss"], "peak_mem_GB": m["peak_mem_GB"],
+           "library_launches_per_it": m["library_launches_per_it"],
+           "workload": "%dx%d synthetic, batch %d, drift+noise UNet fwd/bwd, pyramid losses, 2 fused Adam steps (BASELINE c3 at N=1, fp32)"
+                       % (args.size, args.size, bs), "leg_seconds": round(time.time() - t0, 1)}
+    out["roofline"] = m.get("roofline")
+    return out
 
 
 def train_dryrun(args, world, rank):
-    """IDIFF_BENCH_DRYRUN=1 on a box WITHOUT a GPU (tests/test_host_cpu.py): what `bench.py --gpus N --mode train` does around the HIP
-    compute -- rendezvous from the launcher's environment (gloo), train-phase model build with its GradSync, rank-0 parameter
-    broadcast, one start()/finish() exchange of the optimizers' flat gradient buffers in the train step's order -- with rank-valued
-    stand-in gradients.  No forward / backward runs (there is no CPU fallback for it) and no rate is reported."""
+    """IDIFF_BENCH_DRYRUN=1 on a box WITHOUT a GPU (tests/test_host_cpu.py): what `bench.py --gpus N` (default line: the training leg
+    across the ranks, key "train") and `bench.py --gpus N --mode train` do around the HIP compute -- rendezvous from the launcher's
+    environment (gloo), train-phase model build with its GradSync, rank-0 parameter broadcast, one start()/finish() exchange of the
+    optimizers' flat gradient buffers in the train step's order per wire format -- with rank-valued stand-in gradients and the
+    exchange's timing marks.  No forward / backward runs (there is no CPU fallback for it) and no rate is reported."""
     import torch.distributed as dist
     from instancediff_amd import pipeline
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-    os.environ["IDIFF_GRAD_WIRE"] = args.grad_wire
-    torch.manual_seed(1000 + rank)  # ranks start from DIFFERENT weights: the broadcast must make them equal
-    model, _ = pipeline.build(phase="train", device=torch.device("cpu"), T=4, seed=1000 + rank, dist=world > 1)
-    sync = model.grad_sync
-    assert (sync is not None and sync.active and sync.world == world) if world > 1 else sync is None
-    first = next(model.drift_net.parameters()).detach().reshape(-1)[:8].clone()
-    ok = True
-    scale = 1.0
-    if world > 1:
-        got = [torch.empty_like(first) for _ in range(world)]
-        dist.all_gather(got, first)
-        ok = all(torch.equal(g, got[0]) for g in got)
-        for opt in (model.drift_optimizer, model.noise_optimizer):  # the train step's order: drift first, then noise, one finish()
-            for f in opt.flat_grads():
-                f.fill_(float(rank + 1))
-            sync.start(opt.flat_grads())
-        scale = sync.finish()
-        want = float(world * (world + 1) // 2)
-        ok = ok and all(bool((f == want).all()) for opt in (model.drift_optimizer, model.noise_optimizer) for f in opt.flat_grads())
-        ok = ok and abs(scale - 1.0 / world) < 1e-12
-        dist.barrier()
-    if rank == 0:
+    ok_all, legs = True, {}
+    wires = [args.grad_wire] if args.mode == "train" else ["fp32", "bf16"]  # the default line's training leg reports both
+    for wire in wires:
+        os.environ["IDIFF_GRAD_WIRE"] = wire
+        torch.manual_seed(1000 + rank)  # ranks start from DIFFERENT weights: the broadcast must make them equal
+        model, _ = pipeline.build(phase="train", device=torch.device("cpu"), T=4, seed=1000 + rank, dist=world > 1)
+        sync = model.grad_sync
+        assert (sync is not None and sync.active and sync.world == world) if world > 1 else sync is None
+        first = next(model.drift_net.parameters()).detach().reshape(-1)[:8].clone()
+        ok, scale, tm = True, 1.0, []
+        if world > 1:
+            sync.timing = True
+            got = [torch.empty_like(first) for _ in range(world)]
+            dist.all_gather(got, first)
+            ok = all(torch.equal(g, got[0]) for g in got)
+            for opt in (model.drift_optimizer, model.noise_optimizer):  # the train step's order: drift first, then noise, one finish()
+                for f in opt.flat_grads():
+                    f.fill_(float(rank + 1))
+                sync.start(opt.flat_grads())
+            scale = sync.finish()
+            tm = sync.timings()
+            want = float(world * (world + 1) // 2)
+            ok = ok and all(bool((f == want).all()) for opt in (model.drift_optimizer, model.noise_optimizer) for f in opt.flat_grads())
+            ok = ok and abs(scale - 1.0 / world) < 1e-12 and len(tm) == 1 and tm[0]["span_ms"] >= tm[0]["exposed_ms"] >= 0.0
+            dist.barrier()
         nparam = sum(f.numel() for opt in (model.drift_optimizer, model.noise_optimizer) for f in opt.flat_grads())
-        print(json.dumps({"metric": "training iterations/sec (%dx%d bs%d/GPU)" % (args.size, args.size, args.batch), "value": None,
-                          "dryrun": "no GPU: rendezvous + model build + parameter broadcast + flat gradient all-reduce only",
-                          "n_gpus": world, "grad_wire": args.grad_wire, "grad_sync_ok": ok, "flat_gradient_floats": nparam,
-                          "scale": scale}), flush=True)
+        legs[wire] = {"grad_wire": wire, "grad_sync_ok": ok, "flat_gradient_floats": nparam, "scale": scale,
+                      "exchange": {"wire": wire, "span_ms": tm[0]["span_ms"] if tm else None, "exposed_ms": tm[0]["exposed_ms"] if tm else None}}
+        ok_all = ok_all and ok
+    if rank == 0:
+        note = "no GPU: rendezvous + model build + parameter broadcast + flat gradient all-reduce only"
+        if args.mode == "train":
+            leg = legs[args.grad_wire]
+            print(json.dumps({"metric": "training iterations/sec (%dx%d bs%d/GPU)" % (args.size, args.size, args.batch), "value": None,
+                              "dryrun": note, "n_gpus": world, "grad_wire": args.grad_wire, "grad_sync_ok": leg["grad_sync_ok"],
+                              "flat_gradient_floats": leg["flat_gradient_floats"], "scale": leg["scale"], "exchange": leg["exchange"]}), flush=True)
+        else:
+            n1, src = stored_n1_train()
+            train = dict(legs["fp32"], n_gpus=world, batch_per_gpu=32, it_per_s=None, n1_it_per_s=n1, n1_source=src,
+                         weak_scaling_efficiency_vs_n1=None, bf16_wire_variant=legs["bf16"])
+            print(json.dumps({"metric": "denoising steps/sec (%dx%d bs%d)" % (args.size, args.size, args.batch), "value": None, "dryrun": note,
+                              "n_gpus": world, "config": {"parallelism": "replicas x%d (no collective)" % world}, "train": train}), flush=True)
     if world > 1:
         dist.destroy_process_group()
-    sys.exit(0 if ok else 1)
+    sys.exit(0 if ok_all else 1)
 
 
 def irsde_bench(args, world, rank, dev):
@@ -509,8 +699,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
-        if os.environ.get("IDIFF_BENCH_DRYRUN") == "1" and args.mode == "train":
-            return train_dryrun(args, world, rank)  # CPU test hook: everything of the N>1 train line EXCEPT the HIP compute
+        if os.environ.get("IDIFF_BENCH_DRYRUN") == "1" and args.mode in ("train", "sample"):
+            return train_dryrun(args, world, rank)  # CPU test hook: everything of the N>1 training leg / line EXCEPT the HIP compute
         print("bench.py needs a GPU: the hot path has no CPU fallback", file=sys.stderr)
         sys.exit(2)
     # IDIFF_BENCH_REHEARSAL=1: several ranks share the one GPU of a development box over gloo -- exercises the N>1 code path
@@ -637,13 +827,27 @@ def main():
     if world > 1:
         barrier()
 
+    default_workload = args.size == 256 and args.batch == 16 and variant is None
+    train_ranks = None
+    if world > 1 and default_workload and not args.no_train_leg:
+        # BASELINE c3 -- the one configuration with an exchange step -- across the ranks of THIS run: every rank takes part (the RCCL
+        # all-reduce of the flat gradient buffers is collective); rank 0 reports it under "train"
+        log("train leg across %d ranks (BASELINE c3: flat RCCL all-reduce under the backward) ..." % world)
+        del run
+        torch.cuda.empty_cache()
+        try:
+            train_ranks = train_leg_ranks(args, world, rank, dev)
+        except Exception as e:
+            if rank != 0:
+                raise
+            train_ranks = {"error": repr(e)}
+
     if rank == 0:
         # the training leg runs BEFORE the CPU baseline: measured right behind the oracle's ~110 s of 16-thread host work (GPU idle)
         # it read 4-5 % low (3.75 against 3.91-3.98 it/s, profiles/r04/README.md)
         train = None
-        default_workload = args.size == 256 and args.batch == 16 and variant is None
         if world > 1:
-            train = "N=1 line only (bench.py --gpus N --mode train is the multi-GPU training line)"
+            train = train_ranks if train_ranks is not None else "skipped (%s)" % ("--no-train-leg" if args.no_train_leg else "not the default 256x256 batch-16 fp32 line")
         elif args.no_train_leg or not default_workload:
             train = "skipped (%s)" % ("--no-train-leg" if args.no_train_leg else "not the default 256x256 batch-16 fp32 line")
         else:

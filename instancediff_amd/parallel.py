@@ -53,6 +53,11 @@ class GradSync:
         the wire -- half the bytes per link -- and widened back into the fp32 master buffer (BASELINE config c3).  Default fp32.
       * single_rank_collectives: run the collectives at world size 1 too (a test hook: the RCCL path -- communicator, kernels,
         stream ordering -- is exercised on a one-GPU box).
+      * timing=True (bench.py): every step records three marks -- `start` (first start() of the step: the point behind which RCCL's
+        stream may begin), `wait0` (finish() entered: the backward of both nets and the gradient gather are complete on the current
+        stream) and `wait1` (the current stream has waited for every exchange, bf16 widening included) -- as HIP events on the current
+        stream (wall-clock stamps on the CPU / gloo path).  timings() turns them into per-step `span_ms` = start -> wait1 (the exchange
+        with whatever overlapped it) and `exposed_ms` = wait0 -> wait1 (what the step actually waited for: the non-overlapped part).
     """
 
     def __init__(self, group=None, wire=None, single_rank_collectives=False):
@@ -64,6 +69,31 @@ class GradSync:
         self.active = dist.is_initialized() and (self.world > 1 or single_rank_collectives)
         self._pending = []
         self._wirebufs = {}
+        self.timing = False
+        self._marks = []   # per finished step: (start, wait0, wait1)
+        self._mark0 = None
+
+    def _mark(self):
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
+        import time
+        return time.perf_counter()
+
+    def timings(self, reset=True):
+        """[{span_ms, exposed_ms}] of the steps finished since the last reset (synchronises the device)"""
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.synchronize()
+        out = []
+        for a, b, c in self._marks:
+            if isinstance(a, float):
+                out.append({"span_ms": (c - a) * 1e3, "exposed_ms": (c - b) * 1e3})
+            else:
+                out.append({"span_ms": a.elapsed_time(c), "exposed_ms": b.elapsed_time(c)})
+        if reset:
+            self._marks = []
+        return out
 
     @torch.no_grad()
     def broadcast_parameters(self, params, src=0):
@@ -81,6 +111,8 @@ class GradSync:
             # a previous step left between start() and finish() (an exception the caller caught): its stale handles must not be
             # waited on -- and, on the bf16 wire, widened over the fresh gradients -- by this step's finish()
             self.drain()
+        if self.timing and not self._pending:
+            self._mark0 = self._mark()
         for f in flats:
             if self.wire == "bf16" and f.is_cuda:
                 from . import ops
@@ -98,11 +130,15 @@ class GradSync:
         if not self.active:
             return 1.0
         pending, self._pending = self._pending, []  # cleared whatever happens below
+        w0 = self._mark() if (self.timing and pending) else None
         for work, f, wb in pending:
             work.wait()  # stream-ordered for RCCL (the current stream waits), blocking for gloo
             if wb is not None:
                 from . import ops
                 ops.bf16_to_f32(wb, out=f)
+        if w0 is not None:
+            self._marks.append((self._mark0 if self._mark0 is not None else w0, w0, self._mark()))
+            self._mark0 = None
         return 1.0 / self.world
 
     @torch.no_grad()
@@ -110,6 +146,7 @@ class GradSync:
         """wait for exchanges that were started and never finished, and discard their results (collectives are matched across
         ranks by order, so they are completed, not cancelled)"""
         pending, self._pending = self._pending, []
+        self._mark0 = None
         for work, _, _ in pending:
             work.wait()
 

@@ -17,6 +17,27 @@ from .ops import _bs, _c, _chk, _p, _stream
 WEIGHT_EPOCH = [0]
 
 
+class _prof:
+    """bench.py's training roofline pass (ops.PROFILE set to a list): HIP events on the launch stream around one library call of a
+    matrix-core kernel class, with the FLOP that call executes.  A no-op otherwise."""
+
+    def __init__(self, kind, flops, **extra):
+        self.on = ops.PROFILE is not None
+        if self.on:
+            self.rec = dict(kind=kind, flops=float(flops), e0=torch.cuda.Event(enable_timing=True), e1=torch.cuda.Event(enable_timing=True), **extra)
+
+    def __enter__(self):
+        if self.on:
+            self.rec["e0"].record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.rec["e1"].record()
+            ops.PROFILE.append(self.rec)
+        return False
+
+
 # =====================================================================================================
 # raw wrappers of the training kernels
 # =====================================================================================================
@@ -42,7 +63,12 @@ def conv2d_wgrad(src0, src1, mode, ks, dy, Cin, pro=None, dw=None, accumulate=Fa
     if dw is None:
         dw = torch.empty((Cout, Cin, ks, ks), device=dy.device, dtype=torch.float32)
         accumulate = False
-    check(lib.idiff_conv2d_wgrad(C.byref(d), _p(dy), _bs(dy, "dy"), _p(_c(dw)), 1 if accumulate else 0, _p(ws), _stream()), "conv2d_wgrad")
+    B, _, Hout, Wout = dy.shape
+    pr = _prof("wgrad", 2.0 * Cin * Cout * ks * ks * Hout * Wout * B, ks=ks)
+    with pr:
+        check(lib.idiff_conv2d_wgrad(C.byref(d), _p(dy), _bs(dy, "dy"), _p(_c(dw)), 1 if accumulate else 0, _p(ws), _stream()), "conv2d_wgrad")
+    if pr.on:
+        pr.rec["algo"] = lib.idiff_conv2d_wgrad_last_algo()
     return dw
 
 
@@ -120,8 +146,9 @@ def bgemm(A, B, M, N, K, lda, ldb, transA, transB, sA, sB, batch, out=None, alph
         out = torch.empty((batch, M, N), device=A.device, dtype=torch.float32)
     nws = lib.idiff_bgemm_ws_floats(M, N, K, batch)
     ws = torch.empty((nws,), device=A.device, dtype=torch.float32) if nws else None
-    check(lib.idiff_bgemm(_p(A), _p(B), _p(out), M, N, K, lda, ldb, N, 1 if transA else 0, 1 if transB else 0, sA, sB, M * N, batch, alpha, beta,
-                          _p(ws), _stream()), "bgemm")
+    with _prof("bgemm", 2.0 * M * N * K * batch):
+        check(lib.idiff_bgemm(_p(A), _p(B), _p(out), M, N, K, lda, ldb, N, 1 if transA else 0, 1 if transB else 0, sA, sB, M * N, batch, alpha, beta,
+                              _p(ws), _stream()), "bgemm")
     return out
 
 
@@ -290,7 +317,8 @@ class SmmXattnFn(torch.autograd.Function):
         o = torch.empty_like(qf)
         lse = torch.empty((B, R), device=qf.device, dtype=torch.float32)
         ws = torch.empty((lib.idiff_smm_xattn_ws_floats(B, R, 1, 256, N),), device=qf.device, dtype=torch.float32)
-        check(lib.idiff_smm_xattn_lse_fwd(_p(qf), _p(mem), _p(o), _p(lse), _p(ws), B, R, N, scale, _stream()), "smm_xattn_lse_fwd")
+        with _prof("smm_xattn_fwd", 2 * 2.0 * 32 * 256 * N * B):  # S = qf.mem, o = P.mem^T; query rows padded to the 32-row MFMA tile
+            check(lib.idiff_smm_xattn_lse_fwd(_p(qf), _p(mem), _p(o), _p(lse), _p(ws), B, R, N, scale, _stream()), "smm_xattn_lse_fwd")
         ctx.save_for_backward(qf, mem, o, lse)
         ctx.scale = scale
         return o
@@ -319,8 +347,9 @@ class SmmXattnFn(torch.autograd.Function):
                 raise RuntimeError("SmmXattnFn: more backward than forward calls on a shared memory gradient (retain_graph / double "
                                    "backward is not supported by the shared-gradient form; pass shared=None)")
         ws = torch.empty((lib.idiff_smm_xattn_ws_floats(B, R, 1, 256, N),), device=qf.device, dtype=torch.float32)
-        check(lib.idiff_smm_xattn_bwd(_p(qf), _p(mem), _p(o), _p(lse), _p(d_o), _p(dqf), _p(dmem), acc, _p(ws), B, R, N, ctx.scale, _stream()),
-              "smm_xattn_bwd")
+        with _prof("smm_xattn_bwd", 5 * 2.0 * 32 * 256 * N * B):  # S, dP, dqf, do^T P, qf^T G: five [32 x 256] products per key
+            check(lib.idiff_smm_xattn_bwd(_p(qf), _p(mem), _p(o), _p(lse), _p(d_o), _p(dqf), _p(dmem), acc, _p(ws), B, R, N, ctx.scale, _stream()),
+                  "smm_xattn_bwd")
         if sh is not None:
             if sh["pending"] > 0:
                 return dqf, None, None, None   # the sum is still growing: the last call to run returns it

@@ -414,6 +414,38 @@ def test_bench_train_mode_reaches_the_gradient_exchange_at_world_2(tmp_path):
     assert line["flat_gradient_floats"] > 60e6 and "dryrun" in line   # both nets' parameters in the flat buffers
 
 
+def test_bench_default_line_carries_the_training_exchange_at_world_2(tmp_path):
+    """`python bench.py --gpus 2` -- the command the driver's scaling run issues -- must put the collective into ITS line: the default
+    mode's N > 1 path runs BASELINE c3 across the ranks (train_leg_ranks) and reports it under "train" with the exchange measured for
+    the fp32 wire and the bf16 wire variant.  Without a GPU the dry run goes through the same rendezvous / GradSync / timing-mark code
+    for both wires and prints the line's shape (no rates)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(IDIFF_BENCH_DRYRUN="1", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    if torch.cuda.is_available():
+        pytest.skip("dry run is the no-GPU hook; on a GPU box the rehearsal (IDIFF_BENCH_REHEARSAL=1) runs the real step")
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    tr = line["train"]
+    assert line["n_gpus"] == 2 and line["metric"].startswith("denoising steps/sec") and tr["n_gpus"] == 2 and tr["batch_per_gpu"] == 32
+    for leg, wire in ((tr, "fp32"), (tr["bf16_wire_variant"], "bf16")):
+        assert leg["grad_sync_ok"] is True and leg["grad_wire"] == wire and leg["scale"] == 0.5 and leg["flat_gradient_floats"] > 60e6
+        ex = leg["exchange"]
+        assert ex["wire"] == wire and ex["span_ms"] >= ex["exposed_ms"] >= 0.0
+
+
+def test_grad_sync_timing_marks_cover_one_step_per_finish():
+    """GradSync(timing=True) on the CPU path without a process group is inactive and records nothing; the mark bookkeeping itself
+    (first start() of a step opens it, finish() closes it, drain() forgets it) is exercised at world 2 by the dry-run tests."""
+    from instancediff_amd.parallel import GradSync
+    g = GradSync()
+    g.timing = True
+    g.start([torch.zeros(4)])
+    assert g.finish() == 1.0 and g.timings() == []
+
+
 def test_hidden_register_loads_of_conv_wino4_are_only_touched_behind_a_wait(tmp_path):
     """conv_wino4.hip (SPEC 2: GroupNorm/FiLM + SiLU prologue) requests its input patch with inline-asm buffer loads that hipcc does
     not count: scripts/lint_asm_loads.py checks the generated ISA -- no instruction may name a destination register between the load
