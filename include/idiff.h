@@ -233,11 +233,29 @@ int idiff_smm_memproj_fwd(const float* feat, int64_t feat_bstride, const float* 
 int idiff_smm_memproj_compact_fwd(const float* feat, int64_t feat_bstride, const float* ln1_g, const float* ln1_b,
                                   const float* gram, const float* hvec, float evar, float* out, int B, int C, int N, int Cm,
                                   float eps1, float eps2, idiff_stream_t stream);
+/* Several idiff_smm_memproj_compact_fwd problems (the ScoreMapModules of a net's levels) in ONE launch; same arithmetic per problem,
+ * same bits.  The launch reserves the LDS of its widest problem: group levels of equal C. */
+#define IDIFF_MEMPROJ_MAX_GROUPS 4
+typedef struct idiff_memproj_group {
+    const float* feat;
+    int64_t feat_bstride;
+    const float *ln1_g, *ln1_b, *gram, *hvec;
+    float evar;
+    float* out;
+    int32_t C, N, Cm;
+} idiff_memproj_group;
+int idiff_smm_memproj_compact_grouped_fwd(const idiff_memproj_group* groups, int ngroups, int B, float eps1, float eps2,
+                                          idiff_stream_t stream);
 int idiff_layernorm_rows_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out,
                              int64_t ldo, int R, int C, float eps, float* mean_rstd, idiff_stream_t stream);
 /* sinusoidal embedding, [sin | cos] halves; freqs [dim/2] = host-built table exp(-ln(1e4) * i/(half-1))
  * (NULL = computed on device) */
 int idiff_time_embed_fwd(const float* t, const float* freqs, int B, int dim, float* out, idiff_stream_t stream);
+/* The UNet's time-embedding MLP (frozen spec, DESIGN.md section 2: temb = Linear(GELU(Linear(sinusoidal_dim(t))))) in ONE launch:
+ * out [B, nout] = w2 . GELU(w0 . [sin(t f) ; cos(t f)] + b0) + b2 with w0 [hid, dim], w2 [nout, hid] (torch layout), freqs [dim/2] or
+ * NULL.  Bit-identical to idiff_time_embed_fwd -> idiff_linear_fwd(act_out = GELU) -> idiff_linear_fwd. */
+int idiff_time_mlp_fwd(const float* t, const float* freqs, const float* w0, const float* b0, const float* w2, const float* b2, float* out,
+                       int B, int dim, int hid, int nout, idiff_stream_t stream);
 
 /* LayerNorm over the channel dim of an NCHW map (per pixel). Replaces the pre-norm of attention blocks. */
 int idiff_chan_layernorm_fwd(const float* x, int64_t x_bstride, const float* gamma, const float* beta, float* out,
@@ -265,6 +283,11 @@ int idiff_attn_ctx_fwd(const float* q, const float* k, const float* v, float* ou
  * (row stride ldkv) -- strides let q/k/v be slices of one packed qkv projection; out [B,Nq,C] dense; Nq,M <= 64 */
 int idiff_attn_tokens_fwd(const float* q, const float* k, const float* v, float* out, int B, int Nq, int M, int C,
                           int heads, float scale, int64_t ldq, int64_t ldkv, idiff_stream_t stream);
+/* Backward of idiff_attn_tokens_fwd for few tokens (Nq, M <= 8; head dim <= 64) -- the class-token self-attention of the ScoreMapModule
+ * decoder in the training step: P is recomputed, dq/dk/dv [rows, C] with row strides lddq / lddkv (packed q|k|v buffers allowed). */
+int idiff_attn_tokens_bwd(const float* q, const float* k, const float* v, const float* d_o, float* dq, float* dk, float* dv, int B, int Nq,
+                          int M, int C, int heads, float scale, int64_t ldq, int64_t ldkv, int64_t ldo, int64_t lddq, int64_t lddkv,
+                          idiff_stream_t stream);
 /* idiff_attn_tokens_fwd for ngroups (<= IDIFF_LINEAR_MAX_GROUPS) operand sets of one shape in ONE launch (host arrays of device pointers) */
 int idiff_attn_tokens_grouped_fwd(const float* const* q, const float* const* k, const float* const* v, float* const* out, int ngroups,
                                   int B, int Nq, int M, int C, int heads, float scale, int64_t ldq, int64_t ldkv, idiff_stream_t stream);
@@ -275,6 +298,19 @@ int idiff_attn_tokens_grouped_fwd(const float* const* q, const float* const* k, 
 int64_t idiff_smm_xattn_ws_floats(int B, int Nq, int heads, int Cm, int N);
 int idiff_smm_xattn_fwd(const float* qf, const float* mem, float* o, float* ws, int B, int Nq, int heads, int Cm,
                         int N, float scale, idiff_stream_t stream);
+/* Up to IDIFF_XATTN_MAX_GROUPS independent idiff_smm_xattn_fwd problems of one (B, Nq, heads, scale) -- the cross-attentions of a
+ * net's four ScoreMapModules in one decoder layer -- in ONE attention launch and ONE merge launch.  Each problem keeps the kernel,
+ * the key split and the merge order of its single launch: the results are the same bits.  ws per problem as for the single call. */
+#define IDIFF_XATTN_MAX_GROUPS 8
+typedef struct idiff_xattn_group {
+    const float* qf;   /* [B, Nq, heads, Cm] */
+    const float* mem;  /* [B, Cm, N] */
+    float* o;          /* [B, Nq, heads, Cm] */
+    float* ws;         /* idiff_smm_xattn_ws_floats(B, Nq, heads, Cm, N) floats */
+    int32_t Cm, N;
+} idiff_xattn_group;
+int idiff_smm_xattn_grouped_fwd(const idiff_xattn_group* groups, int ngroups, int B, int Nq, int heads, float scale,
+                                idiff_stream_t stream);
 /* Training path of the same attention over the full 256-row memory (Cm = 256, rows = Nq*heads <= 32, row-major qf / o [B, rows, 256]):
  * the forward also returns lse [B, rows] (log-sum-exp of the scaled scores); the backward makes ONE pass over the keys,
  *   dP = do mem, D = rowsum(do*o), G = scale * P * (dP - D), dqf = G mem^T, dmem = do^T P + qf^T G     (P = exp(scale*qf mem - lse)),
@@ -289,6 +325,17 @@ int idiff_smm_xattn_bwd(const float* qf, const float* mem, const float* o, const
  * sel (optional) [B, HW] = out[b, idx[b], :]  (idx int32 [B]) */
 int idiff_scoremap_fwd(const float* feat, int64_t feat_bstride, const float* tv, float* out, const int32_t* idx,
                        float* sel, int B, int C, int HW, int K, idiff_stream_t stream);
+/* The score maps of several levels in ONE launch (same K, idx); 16-byte form only (HW % 4 == 0, aligned operands). */
+#define IDIFF_SCOREMAP_MAX_GROUPS 4
+typedef struct idiff_scoremap_group {
+    const float* feat;
+    int64_t feat_bstride;
+    const float* tv;  /* [B, K, C] */
+    float* out;       /* [B, K, HW] */
+    float* sel;       /* [B, HW] or NULL (with idx) */
+    int32_t C, HW;
+} idiff_scoremap_group;
+int idiff_scoremap_grouped_fwd(const idiff_scoremap_group* groups, int ngroups, const int32_t* idx, int B, int K, idiff_stream_t stream);
 /* Output layer fused with the class gather (replaces the UNet's final 3x3 conv to out_nc channels followed by the
  * per-sample channel pick): out[b,0,y,x] = bias[idx[b]] + sum_{ci,ky,kx} w[idx[b],ci,ky,kx] * x[b,ci,y+ky-1,x+kx-1]
  * w [K,C,3,3] (torch layout), bias [K] or NULL, idx int32 [B] in [0,K), out [B,1,H,W]. */
@@ -360,6 +407,11 @@ int idiff_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, idiff_str
 int idiff_philox_raw(uint32_t* out, int64_t ncounters, uint64_t seed, uint64_t offset, idiff_stream_t stream);
 /* out = alpha*x + beta*y */
 int idiff_axpby(const float* x, const float* y, float* out, int64_t n, float alpha, float beta, idiff_stream_t stream);
+/* Gradient fan-in in one pass: out[b, :] = srcs[0][b, :] + srcs[1][b, :] (+ ..), 2..4 sources with their own batch strides (a source may
+ * be a channel slice of a bigger tensor), summed in argument order.  Replaces torch.autograd's pairwise accumulation (n - 1 passes
+ * plus a copy per non-contiguous operand) where a feature map has several consumers.  per_sample % 4 == 0, 16-byte aligned rows. */
+int idiff_sum_n(const float* const* srcs, const int64_t* src_bstrides, int nsrc, float* out, int64_t out_bstride, int B,
+                int64_t per_sample, idiff_stream_t stream);
 /* Many tensors -> one flat buffer in one launch (replaces the per-parameter gradient accumulate / copy launches of
  * torch.autograd's AccumulateGrad + optimizer packing; models/drift_noise_model.py:292-296 semantics unchanged).  segs_dev: device
  * array of nseg records {const float* src (NULL = zero fill); int64 dst_offset; int64 n; int64 first_block}, first_block = running

@@ -44,7 +44,22 @@ class LinearGroup(C.Structure):  # idiff_linear_group
                 ("ln_eps", C.c_float), ("R", C.c_int32), ("K", C.c_int32), ("N", C.c_int32), ("act_in", C.c_int32), ("act_out", C.c_int32)]
 
 
+class XattnGroup(C.Structure):  # idiff_xattn_group
+    _fields_ = [("qf", C.c_void_p), ("mem", C.c_void_p), ("o", C.c_void_p), ("ws", C.c_void_p), ("Cm", C.c_int32), ("N", C.c_int32)]
+
+
+class MemprojGroup(C.Structure):  # idiff_memproj_group
+    _fields_ = [("feat", C.c_void_p), ("feat_bstride", C.c_int64), ("ln1_g", C.c_void_p), ("ln1_b", C.c_void_p), ("gram", C.c_void_p),
+                ("hvec", C.c_void_p), ("evar", C.c_float), ("out", C.c_void_p), ("C", C.c_int32), ("N", C.c_int32), ("Cm", C.c_int32)]
+
+
+class ScoremapGroup(C.Structure):  # idiff_scoremap_group
+    _fields_ = [("feat", C.c_void_p), ("feat_bstride", C.c_int64), ("tv", C.c_void_p), ("out", C.c_void_p), ("sel", C.c_void_p),
+                ("C", C.c_int32), ("HW", C.c_int32)]
+
+
 LINEAR_MAX_GROUPS = 16
+XATTN_MAX_GROUPS, MEMPROJ_MAX_GROUPS, SCOREMAP_MAX_GROUPS = 8, 4, 4
 P, I, I64, F, U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 
 # name -> (restype, argtypes); must list every function declared in include/idiff.h
@@ -73,19 +88,24 @@ SIGNATURES = {
     "idiff_linear_t_heads_fwd": (I, [P, I64, I64, P, I64, I64, P, I64, P, I64, I64, I, I, I, I, c_stream]),
     "idiff_smm_memproj_fwd": (I, [P, I64, P, P, P, P, P, P, P, I, I, I, F, c_stream]),
     "idiff_smm_memproj_compact_fwd": (I, [P, I64, P, P, P, P, F, P, I, I, I, I, F, F, c_stream]),
+    "idiff_smm_memproj_compact_grouped_fwd": (I, [C.POINTER(MemprojGroup), I, I, F, F, c_stream]),
     "idiff_layernorm_rows_fwd": (I, [P, I64, P, P, P, I64, I, I, F, P, c_stream]),
     "idiff_time_embed_fwd": (I, [P, P, I, I, P, c_stream]),
+    "idiff_time_mlp_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, c_stream]),
     "idiff_chan_layernorm_fwd": (I, [P, I64, P, P, P, I64, I, I, I, F, P, c_stream]),
     "idiff_attn_self_fwd": (I, [P, P, P, I, I, I, I, F, c_stream]),
     "idiff_attn_self_bf16_fwd": (I, [P, P, I, I, I, I, F, c_stream]),
     "idiff_attn_self_f16_fwd": (I, [P, P, I, I, I, I, F, c_stream]),
     "idiff_attn_ctx_fwd": (I, [P, P, P, P, I, I, I, I, I, F, c_stream]),
     "idiff_attn_tokens_fwd": (I, [P, P, P, P, I, I, I, I, I, F, I64, I64, c_stream]),
+    "idiff_attn_tokens_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, F, I64, I64, I64, I64, I64, c_stream]),
     "idiff_smm_xattn_ws_floats": (I64, [I, I, I, I, I]),
     "idiff_smm_xattn_fwd": (I, [P, P, P, P, I, I, I, I, I, F, c_stream]),
+    "idiff_smm_xattn_grouped_fwd": (I, [C.POINTER(XattnGroup), I, I, I, I, F, c_stream]),
     "idiff_smm_xattn_lse_fwd": (I, [P, P, P, P, P, I, I, I, F, c_stream]),
     "idiff_smm_xattn_bwd": (I, [P, P, P, P, P, P, P, I, P, I, I, I, F, c_stream]),
     "idiff_scoremap_fwd": (I, [P, I64, P, P, P, P, I, I, I, I, c_stream]),
+    "idiff_scoremap_grouped_fwd": (I, [C.POINTER(ScoremapGroup), I, P, I, I, c_stream]),
     "idiff_gather_channel": (I, [P, P, P, I, I, I, c_stream]),
     "idiff_conv3x3_select_fwd": (I, [P, I64, P, P, P, P, I, I, I, I, I, c_stream]),
     "idiff_irsde_reverse_step": (I, [P, P, P, P, P, I64, F, F, F, F, F, I, U64, U64, c_stream]),
@@ -106,6 +126,7 @@ SIGNATURES = {
     "idiff_pixel_shuffle2": (I, [P, P, I, I, I, I, c_stream]),
     "idiff_plane_sum": (I, [P, I64, P, I, I, I, c_stream]),
     "idiff_batch_sum": (I, [P, P, I, I, I, c_stream]),
+    "idiff_sum_n": (I, [C.POINTER(P), C.POINTER(I64), I, P, I64, I, I64, c_stream]),
     "idiff_gather_segments": (I, [P, I, I64, P, c_stream]),
     "idiff_gn_silu_bwd_ws_floats": (I64, [I, I, I]),
     "idiff_gn_silu_bwd": (I, [P, I64, P, I64, P, P, P, P, P, P, I64, P, I64, P, P, P, I64, P, I, I, I, I, I, P, P, c_stream]),

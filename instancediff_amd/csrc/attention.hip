@@ -367,6 +367,75 @@ __global__ __launch_bounds__(64) void attn_tokens_kernel(const float* __restrict
     }
 }
 
+// Backward of attn_tokens for the few-token self-attention of the ScoreMapModule decoder (Nq, M <= 8: K = 5 class tokens), training path.
+// One wave per (b, head); lane = channel d of the head (dh <= 64).  With P = softmax_j(scale q_i.k_j) recomputed in registers:
+//   dP_ij = do_i . v_j ;  D_i = sum_j P_ij dP_ij ;  dS_ij = scale P_ij (dP_ij - D_i)
+//   dq_i = sum_j dS_ij k_j ;  dk_j = sum_i dS_ij q_i ;  dv_j = sum_i P_ij do_i
+// replaces two batched GEMMs + softmax forward and four + softmax backward (and the head permute copies around them) per layer.
+constexpr int ATB = 8;
+__global__ __launch_bounds__(64) void attn_tokens_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                             const float* __restrict__ d_o, float* __restrict__ dq, float* __restrict__ dk,
+                                                             float* __restrict__ dv, int Nq, int M, int C, int heads, float scale, long long ldq,
+                                                             long long ldkv, long long ldo, long long lddq, long long lddkv) {
+    const int dh = C / heads;
+    const int h = blockIdx.x % heads, b = blockIdx.x / heads;
+    const int d = threadIdx.x;
+    const bool on = d < dh;
+    float qr[ATB], kr[ATB], vr[ATB], gr[ATB];
+#pragma unroll
+    for (int i = 0; i < ATB; ++i) {
+        qr[i] = (on && i < Nq) ? q[((long long)b * Nq + i) * ldq + h * dh + d] : 0.f;
+        gr[i] = (on && i < Nq) ? d_o[((long long)b * Nq + i) * ldo + h * dh + d] : 0.f;
+        kr[i] = (on && i < M) ? k[((long long)b * M + i) * ldkv + h * dh + d] : 0.f;
+        vr[i] = (on && i < M) ? v[((long long)b * M + i) * ldkv + h * dh + d] : 0.f;
+    }
+    float dqa[ATB], dka[ATB], dva[ATB];
+#pragma unroll
+    for (int i = 0; i < ATB; ++i) dqa[i] = 0.f, dka[i] = 0.f, dva[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < ATB; ++i) {
+        if (i < Nq) {  // uniform
+            float sc[ATB], dp[ATB];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < ATB; ++j) {
+                sc[j] = j < M ? wave_sum(qr[i] * kr[j]) * scale : -INFINITY;
+                dp[j] = j < M ? wave_sum(gr[i] * vr[j]) : 0.f;
+                mx = fmaxf(mx, sc[j]);
+            }
+            float l = 0.f;
+#pragma unroll
+            for (int j = 0; j < ATB; ++j) {
+                sc[j] = j < M ? __expf(sc[j] - mx) : 0.f;
+                l += sc[j];
+            }
+            float D = 0.f;
+#pragma unroll
+            for (int j = 0; j < ATB; ++j) {
+                sc[j] = sc[j] / l;
+                D += sc[j] * dp[j];
+            }
+#pragma unroll
+            for (int j = 0; j < ATB; ++j) {
+                const float ds = scale * sc[j] * (dp[j] - D);
+                dqa[i] += ds * kr[j];
+                dka[j] += ds * qr[i];
+                dva[j] += sc[j] * gr[i];
+            }
+        }
+    }
+    if (on) {
+#pragma unroll
+        for (int i = 0; i < ATB; ++i) {
+            if (i < Nq) dq[((long long)b * Nq + i) * lddq + h * dh + d] = dqa[i];
+            if (i < M) {
+                dk[((long long)b * M + i) * lddkv + h * dh + d] = dka[i];
+                dv[((long long)b * M + i) * lddkv + h * dh + d] = dva[i];
+            }
+        }
+    }
+}
+
 // grouped form (idiff_attn_tokens_grouped_fwd): blockIdx.y picks one of up to IDIFF_LINEAR_MAX_GROUPS operand sets of the same shape
 struct AttnTokGroups {
     const float* q[IDIFF_LINEAR_MAX_GROUPS];
@@ -407,8 +476,8 @@ __global__ __launch_bounds__(64) void attn_tokens_grouped_kernel(const AttnTokGr
 // (even); the P.V product runs on whole 32-channel blocks, so a wave's LDS slice is padded to XCB*32 rows
 // (the padding rows produce accumulator rows that are never stored).
 template <int XCW>
-__global__ __launch_bounds__(256) void smm_xattn_kernel(const float* __restrict__ qf, const float* __restrict__ mem, float* __restrict__ ws,
-                                                        int rows, int N, int nsplit, int kps, float scale) {
+__device__ __forceinline__ void smm_xattn_body(const float* __restrict__ qf, const float* __restrict__ mem, float* __restrict__ ws, int rows, int N,
+                                               int nsplit, int kps, float scale, const int b, const int sp) {
     constexpr int XCM = 4 * XCW;
     constexpr int XCB = (XCW + 31) / 32;      // 32-channel blocks per wave in the P.V product
     constexpr int XTILE = XCB * 32 * 33;      // per-wave mem slice [XCB*32 c][33]
@@ -417,7 +486,6 @@ __global__ __launch_bounds__(256) void smm_xattn_kernel(const float* __restrict_
     float* tile = smem + (threadIdx.x >> 6) * XTILE;  // private per wave
     float* xch = smem + 4 * XTILE;                    // [4][16][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.y, sp = blockIdx.x;
     const int c0 = wave * XCW;
     const float* memb = mem + (long long)b * XCM * N + (long long)c0 * N;
 
@@ -526,6 +594,11 @@ __global__ __launch_bounds__(256) void smm_xattn_kernel(const float* __restrict_
         wp[(XCM + 1) * 32 + l31] = l;
     }
 }
+template <int XCW>
+__global__ __launch_bounds__(256) void smm_xattn_kernel(const float* __restrict__ qf, const float* __restrict__ mem, float* __restrict__ ws,
+                                                        int rows, int N, int nsplit, int kps, float scale) {
+    smm_xattn_body<XCW>(qf, mem, ws, rows, N, nsplit, kps, scale, blockIdx.y, blockIdx.x);
+}
 
 // Wave-per-key-block form for the narrow (compact) memories, CM = 72 / 136: every wave owns whole 32-key blocks (wave w of a workgroup takes
 // blocks w, w + 4, ...) with ALL CM channels, so S is complete inside the wave -- no partial tiles through LDS, no barrier per block --
@@ -533,15 +606,14 @@ __global__ __launch_bounds__(256) void smm_xattn_kernel(const float* __restrict_
 // a running max / sum / partial output each and merge them in LDS at the end (wave order): one partial per workgroup, as before.  profiles/r03: the channel-split
 // form streamed the 72-row memory at 1.85 TB/s (12 launches, 1.3 ms per step).
 template <int CM>
-__global__ __launch_bounds__(256) void smm_xattn_w_kernel(const float* __restrict__ qf, const float* __restrict__ mem, float* __restrict__ ws, int rows,
-                                                          int N, int nsplit, int kps, float scale) {
+__device__ __forceinline__ void smm_xattn_w_body(const float* __restrict__ qf, const float* __restrict__ mem, float* __restrict__ ws, int rows, int N,
+                                                 int nsplit, int kps, float scale, const int b, const int sp) {
     constexpr int CB = (CM + 31) / 32;           // 32-channel blocks of the P.V product
     constexpr int TILE = CB * 32 * 33;           // per-wave mem slice [CB*32 c][33]; rows >= CM stay zero
     constexpr int NF4 = (CM * 8 + 63) / 64;      // float4 loads per lane per 32-key block
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     float* tile = smem + wave * TILE;
-    const int b = blockIdx.y, sp = blockIdx.x;
     const float* memb = mem + (long long)b * CM * N;
     for (int i = lane; i < TILE; i += 64) tile[i] = 0.f;  // (wave-private; LDS is in order within a wave)
 
@@ -667,18 +739,22 @@ __global__ __launch_bounds__(256) void smm_xattn_w_kernel(const float* __restric
         wp[(CM + 1) * 32 + tid] = L;
     }
 }
+template <int CM>
+__global__ __launch_bounds__(256) void smm_xattn_w_kernel(const float* __restrict__ qf, const float* __restrict__ mem, float* __restrict__ ws, int rows,
+                                                          int N, int nsplit, int kps, float scale) {
+    smm_xattn_w_body<CM>(qf, mem, ws, rows, N, nsplit, kps, scale, blockIdx.y, blockIdx.x);
+}
 
 // Merge of the key splits' partial (max, sum, P.V) triples.  Workgroup = 2 channels x 32 rows x CSL split lanes: lane sl walks the
 // splits sl, sl + CSL, .. (max pass, then the weighted sums: every load of a pass independent of the others), the CSL lane results
 // are merged in lane order through LDS -- a fixed order that is a function of the split count (of N) alone.  (r04: one thread per
 // (channel, row) had walked all 64 splits twice: 15.6 us per launch of load latency, 24 launches per step.)
 constexpr int CSL = 4;
-__global__ __launch_bounds__(256) void smm_xattn_combine_kernel(const float* __restrict__ ws, float* __restrict__ o, int rows, int nsplit, int XCM,
-                                                                float* __restrict__ lse) {
+__device__ __forceinline__ void smm_xattn_combine_body(const float* __restrict__ ws, float* __restrict__ o, int rows, int nsplit, int XCM,
+                                                       float* __restrict__ lse, const int b, const int bx) {
     __shared__ float red[3][CSL][64];
-    const int b = blockIdx.y;
     const int io = threadIdx.x & 63, sl = threadIdx.x >> 6;  // output of the workgroup, split lane (= wave)
-    const int i = blockIdx.x * 64 + io;                      // over XCM * 32: the partials are laid out [c][32 rows]
+    const int i = bx * 64 + io;                              // over XCM * 32: the partials are laid out [c][32 rows]
     const int c = i >> 5, row = i & 31;
     const bool live = i < XCM * 32 && row < rows;
     const long long ss = (long long)(XCM + 2) * 32;  // floats per split
@@ -713,6 +789,39 @@ __global__ __launch_bounds__(256) void smm_xattn_combine_kernel(const float* __r
         o[((long long)b * rows + row) * XCM + c] = At / Lt;
         if (lse && c == 0) lse[(long long)b * rows + row] = Mt + __logf(Lt);  // log-sum-exp of the scaled scores (training: saved for the backward)
     }
+}
+__global__ __launch_bounds__(256) void smm_xattn_combine_kernel(const float* __restrict__ ws, float* __restrict__ o, int rows, int nsplit, int XCM,
+                                                                float* __restrict__ lse) {
+    smm_xattn_combine_body(ws, o, rows, nsplit, XCM, lse, blockIdx.y, blockIdx.x);
+}
+
+// Grouped launches (idiff_smm_xattn_grouped_fwd): the cross-attentions of SEVERAL ScoreMapModules (the four UNet levels of a net, which
+// advance their decoder chains in lock step) in ONE attention launch + ONE merge launch.  blockIdx.z picks the problem -- its own
+// operands, memory width and key count, descriptors in the kernel arguments as for the grouped token linears -- and the problem's
+// kernel body (the very code of the single launches: same per-sample arithmetic and order, so the results are the same bits); the grid
+// covers the largest split count, blocks beyond a smaller problem's exit.  The small levels (1 024 / 4 096 keys: a few dozen
+// workgroups) then run beside the 65 536-key level instead of in launches of their own.
+struct XattnGroups {
+    idiff_xattn_group g[IDIFF_XATTN_MAX_GROUPS];
+    int nsplit[IDIFF_XATTN_MAX_GROUPS], kps[IDIFF_XATTN_MAX_GROUPS], kind[IDIFF_XATTN_MAX_GROUPS];
+};
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void smm_xattn_grouped_kernel(const XattnGroups args, int rows, float scale) {
+    const int z = blockIdx.z;
+    const idiff_xattn_group& d = args.g[z];
+    const int ns = args.nsplit[z], kps = args.kps[z];
+    if ((int)blockIdx.x >= ns) return;  // uniform
+    switch (args.kind[z]) {             // uniform
+        case 0: smm_xattn_body<64>(d.qf, d.mem, d.ws, rows, d.N, ns, kps, scale, blockIdx.y, blockIdx.x); break;
+        case 1: smm_xattn_body<34>(d.qf, d.mem, d.ws, rows, d.N, ns, kps, scale, blockIdx.y, blockIdx.x); break;
+        case 2: smm_xattn_body<18>(d.qf, d.mem, d.ws, rows, d.N, ns, kps, scale, blockIdx.y, blockIdx.x); break;
+        default: smm_xattn_w_body<72>(d.qf, d.mem, d.ws, rows, d.N, ns, kps, scale, blockIdx.y, blockIdx.x); break;
+    }
+}
+__global__ __launch_bounds__(256) void smm_xattn_combine_grouped_kernel(const XattnGroups args, int rows) {
+    const int z = blockIdx.z;
+    const idiff_xattn_group& d = args.g[z];
+    if ((int)blockIdx.x * 64 >= d.Cm * 32) return;  // uniform
+    smm_xattn_combine_body(d.ws, d.o, rows, args.nsplit[z], d.Cm, nullptr, blockIdx.y, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -990,6 +1099,19 @@ extern "C" int idiff_attn_tokens_fwd(const float* q, const float* k, const float
     return IDIFF_OK;
 }
 
+extern "C" int idiff_attn_tokens_bwd(const float* q, const float* k, const float* v, const float* d_o, float* dq, float* dk, float* dv, int B, int Nq,
+                                     int M, int C, int heads, float scale, int64_t ldq, int64_t ldkv, int64_t ldo, int64_t lddq, int64_t lddkv,
+                                     idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(q && k && v && d_o && dq && dk && dv && B > 0 && C > 0 && heads > 0 && C % heads == 0, "attn_tokens_bwd: bad args");
+    IDIFF_CHECK_ARG(Nq >= 1 && Nq <= ATB && M >= 1 && M <= ATB, "attn_tokens_bwd: Nq and M must be in 1..%d (got %d, %d)", ATB, Nq, M);
+    IDIFF_CHECK_ARG(C / heads <= 64, "attn_tokens_bwd: head dim must be <= 64 (got %d)", C / heads);
+    IDIFF_CHECK_ARG(ldq >= C && ldkv >= C && ldo >= C && lddq >= C && lddkv >= C, "attn_tokens_bwd: row strides must be >= C");
+    hipLaunchKernelGGL(attn_tokens_bwd_kernel, dim3(B * heads), dim3(64), 0, (hipStream_t)stream, q, k, v, d_o, dq, dk, dv, Nq, M, C, heads, scale,
+                       (long long)ldq, (long long)ldkv, (long long)ldo, (long long)lddq, (long long)lddkv);
+    IDIFF_CHECK_LAUNCH("attn_tokens_bwd");
+    return IDIFF_OK;
+}
+
 extern "C" int idiff_attn_tokens_grouped_fwd(const float* const* q, const float* const* k, const float* const* v, float* const* out, int ngroups,
                                              int B, int Nq, int M, int C, int heads, float scale, int64_t ldq, int64_t ldkv, idiff_stream_t stream) {
     IDIFF_CHECK_ARG(q && k && v && out && ngroups >= 1 && ngroups <= IDIFF_LINEAR_MAX_GROUPS, "attn_tokens_grouped: 1..%d groups", IDIFF_LINEAR_MAX_GROUPS);
@@ -1049,6 +1171,38 @@ static int smm_xattn_fwd_impl(const float* qf, const float* mem, float* o, float
     IDIFF_CHECK_LAUNCH("smm_xattn_fwd");
     hipLaunchKernelGGL(smm_xattn_combine_kernel, dim3((32 * Cm + 63) / 64, B), dim3(256), 0, st, ws, o, rows, ns_eff, Cm, lse);
     IDIFF_CHECK_LAUNCH("smm_xattn_combine");
+    return IDIFF_OK;
+}
+
+extern "C" int idiff_smm_xattn_grouped_fwd(const idiff_xattn_group* groups, int ngroups, int B, int Nq, int heads, float scale, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(groups && ngroups >= 1 && ngroups <= IDIFF_XATTN_MAX_GROUPS, "smm_xattn_grouped: 1..%d groups", IDIFF_XATTN_MAX_GROUPS);
+    IDIFF_CHECK_ARG(B > 0 && Nq > 0 && heads > 0 && Nq * heads <= 32, "smm_xattn_grouped: Nq*heads must be in 1..32 (got %d)", Nq * heads);
+    XattnGroups args;
+    memset(&args, 0, sizeof(args));
+    int gx = 0, gc = 0;
+    size_t lds = 0;
+    for (int i = 0; i < ngroups; ++i) {
+        const idiff_xattn_group& d = groups[i];
+        IDIFF_CHECK_ARG(d.qf && d.mem && d.o && d.ws && d.N > 0 && d.N % 4 == 0, "smm_xattn_grouped: group %d: bad args", i);
+        IDIFF_CHECK_ARG(d.Cm == 256 || d.Cm == 136 || d.Cm == 72, "smm_xattn_grouped: group %d: Cm must be 72, 136 or 256 (got %d)", i, d.Cm);
+        args.g[i] = d;
+        smm_split(B, d.N, &args.nsplit[i], &args.kps[i]);
+        // the kernel each problem would get from idiff_smm_xattn_fwd (same choice, same bits)
+        const int xcb = (d.Cm / 4 + 31) / 32;
+        size_t l = (size_t)(4 * xcb * 32 * 33 + 4 * 16 * 64) * sizeof(float);
+        if (d.Cm == 256) args.kind[i] = 0;
+        else if (d.Cm == 136) args.kind[i] = 1;
+        else if (args.kps[i] >= 4) args.kind[i] = 3, l = (size_t)4 * 3 * 32 * 33 * sizeof(float);
+        else args.kind[i] = 2;
+        lds = max(lds, l);
+        gx = max(gx, args.nsplit[i]);
+        gc = max(gc, (32 * d.Cm + 63) / 64);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(smm_xattn_grouped_kernel, dim3(gx, B, ngroups), dim3(256), lds, st, args, Nq * heads, scale);
+    IDIFF_CHECK_LAUNCH("smm_xattn_grouped_fwd");
+    hipLaunchKernelGGL(smm_xattn_combine_grouped_kernel, dim3(gc, B, ngroups), dim3(256), 0, st, args, Nq * heads);
+    IDIFF_CHECK_LAUNCH("smm_xattn_grouped_combine");
     return IDIFF_OK;
 }
 

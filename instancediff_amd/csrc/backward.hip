@@ -872,3 +872,46 @@ extern "C" int idiff_adam_step(float* p, const float* g, float* m, float* v, int
     IDIFF_CHECK_LAUNCH("adam_step");
     return IDIFF_OK;
 }
+
+// ---- fan-in of gradients: out[b, :] = sum_i src_i[b, :] for 2..4 sources, each with its own batch stride (a gradient may be a channel
+// slice of a bigger tensor: one source of a virtual concat).  ONE pass (n reads + 1 write) where autograd's own accumulation makes
+// n - 1 passes of two reads + one write each, plus a copy for every non-contiguous operand; the order of the sum is the argument order.
+namespace {
+struct SumSrc {
+    const float* p[4];
+    long long bs[4];
+};
+template <int NS>
+__global__ __launch_bounds__(256) void sum_n_kernel(const SumSrc s, float* __restrict__ out, long long obs, long long per4) {
+    const int b = blockIdx.y;
+    for (long long v = blockIdx.x * (long long)blockDim.x + threadIdx.x; v < per4; v += (long long)gridDim.x * blockDim.x) {
+        floatx4 a = reinterpret_cast<const floatx4*>(s.p[0] + (long long)b * s.bs[0])[v];
+#pragma unroll
+        for (int i = 1; i < NS; ++i) {
+            const floatx4 x = reinterpret_cast<const floatx4*>(s.p[i] + (long long)b * s.bs[i])[v];
+            a.x += x.x, a.y += x.y, a.z += x.z, a.w += x.w;
+        }
+        reinterpret_cast<floatx4*>(out + (long long)b * obs)[v] = a;
+    }
+}
+}  // namespace
+extern "C" int idiff_sum_n(const float* const* srcs, const int64_t* src_bstrides, int nsrc, float* out, int64_t out_bstride, int B,
+                           int64_t per_sample, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(srcs && src_bstrides && out && nsrc >= 2 && nsrc <= 4 && B > 0 && per_sample > 0, "sum_n: 2..4 sources");
+    IDIFF_CHECK_ARG(per_sample % 4 == 0 && out_bstride % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0, "sum_n: 16-byte rows required");
+    SumSrc s;
+    memset(&s, 0, sizeof(s));
+    for (int i = 0; i < nsrc; ++i) {
+        IDIFF_CHECK_ARG(srcs[i] && src_bstrides[i] % 4 == 0 && (reinterpret_cast<uintptr_t>(srcs[i]) & 15) == 0, "sum_n: source %d: 16-byte rows required", i);
+        s.p[i] = srcs[i], s.bs[i] = src_bstrides[i];
+    }
+    const long long per4 = per_sample / 4;
+    long long gx = (per4 + 255) / 256;
+    if (gx > 2048) gx = 2048;
+    dim3 grid((unsigned)gx, B);
+    if (nsrc == 2) hipLaunchKernelGGL(sum_n_kernel<2>, grid, dim3(256), 0, ST, s, out, (long long)out_bstride, per4);
+    else if (nsrc == 3) hipLaunchKernelGGL(sum_n_kernel<3>, grid, dim3(256), 0, ST, s, out, (long long)out_bstride, per4);
+    else hipLaunchKernelGGL(sum_n_kernel<4>, grid, dim3(256), 0, ST, s, out, (long long)out_bstride, per4);
+    IDIFF_CHECK_LAUNCH("sum_n");
+    return IDIFF_OK;
+}

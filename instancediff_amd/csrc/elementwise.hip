@@ -321,11 +321,10 @@ __global__ __launch_bounds__(256) void scoremap_kernel(const float* __restrict__
 // Streaming form: 4 consecutive pixels per thread (16-byte loads, a 1-KB row segment per wave and channel), four channels of loads
 // in flight per thread.  The one-pixel-per-thread form above walked the channels with one dependent 4-byte load each and ran at
 // 1.25 TB/s (profiles/r03/pmc_kernels); it stays for shapes whose rows are not 16-byte aligned.
-__global__ __launch_bounds__(256) void scoremap4_kernel(const float* __restrict__ feat, long long fbs, const float* __restrict__ tv,
-                                                        float* __restrict__ out, const int* __restrict__ idx, float* __restrict__ sel, int C,
-                                                        int HW, int K) {
+__device__ __forceinline__ void scoremap4_body(const float* __restrict__ feat, long long fbs, const float* __restrict__ tv,
+                                               float* __restrict__ out, const int* __restrict__ idx, float* __restrict__ sel, int C, int HW, int K,
+                                               const int b, const int bx) {
     extern __shared__ float tvn[];  // [K][C]
-    const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int k = wave; k < K; k += 4) {
         const float* tr = tv + ((long long)b * K + k) * C;
@@ -335,7 +334,7 @@ __global__ __launch_bounds__(256) void scoremap4_kernel(const float* __restrict_
         for (int c = lane; c < C; c += 64) tvn[k * C + c] = tr[c] / nrm;
     }
     __syncthreads();
-    const int p = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int p = (bx * blockDim.x + threadIdx.x) * 4;
     if (p >= HW) return;  // HW % 4 == 0
     const float* fb = feat + (long long)b * fbs + p;
     floatx4 dot[SM_KMAX];
@@ -374,6 +373,75 @@ __global__ __launch_bounds__(256) void scoremap4_kernel(const float* __restrict_
             const floatx4 v = floatx4{dot[k].x / rn.x, dot[k].y / rn.y, dot[k].z / rn.z, dot[k].w / rn.w};
             *reinterpret_cast<floatx4*>(out + ((long long)b * K + k) * HW + p) = v;
             if (k == ksel) *reinterpret_cast<floatx4*>(sel + (long long)b * HW + p) = v;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void scoremap4_kernel(const float* __restrict__ feat, long long fbs, const float* __restrict__ tv,
+                                                        float* __restrict__ out, const int* __restrict__ idx, float* __restrict__ sel, int C,
+                                                        int HW, int K) {
+    scoremap4_body(feat, fbs, tv, out, idx, sel, C, HW, K, blockIdx.y, blockIdx.x);
+}
+// Grouped launch (idiff_scoremap_grouped_fwd): the score maps of a net's four ScoreMapModules in ONE launch; blockIdx.z picks the level
+// (own operands and shape, descriptors in the kernel arguments), blocks beyond a smaller level's pixels exit.  Same body, same bits.
+struct ScoremapGroups {
+    idiff_scoremap_group g[IDIFF_SCOREMAP_MAX_GROUPS];
+};
+__global__ __launch_bounds__(256) void scoremap4_grouped_kernel(const ScoremapGroups args, const int* __restrict__ idx, int K) {
+    const idiff_scoremap_group& d = args.g[blockIdx.z];
+    if ((long long)blockIdx.x * 1024 >= d.HW) return;  // uniform
+    scoremap4_body(d.feat, d.feat_bstride, d.tv, d.out, idx, d.sel, d.C, d.HW, K, blockIdx.y, blockIdx.x);
+}
+
+// The time-embedding MLP in ONE launch (idiff_time_mlp_fwd):  temb = W2 . GELU(W0 . [sin(t f) ; cos(t f)] + b0) + b2.
+// grid (4, B): every workgroup evaluates the sinusoidal embedding and the whole first layer of its sample (dim -> hid, cheap), then a
+// quarter of the second layer's outputs.  Per output the arithmetic is linear_kernel's (one wave per output, lanes split K in steps of 64,
+// wave_sum), so the result equals the time_embed -> linear -> linear chain it replaces bit for bit.
+__global__ __launch_bounds__(256) void time_mlp_kernel(const float* __restrict__ t, const float* __restrict__ freqs, const float* __restrict__ w0,
+                                                       const float* __restrict__ b0, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                       float* __restrict__ out, int dim, int hid, int nout) {
+    extern __shared__ float tm_smem[];  // [dim] embedding, [hid] hidden
+    float* e0 = tm_smem;
+    float* h1 = tm_smem + dim;
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = dim / 2;
+    for (int j = threadIdx.x; j < dim; j += 256) {
+        const int f = j < half ? j : j - half;
+        const float freq = freqs ? freqs[f] : expf((float)f * (-logf(10000.0f) / (float)(half - 1)));
+        const float arg = __fmul_rn(t[b], freq);
+        e0[j] = j < half ? sinf(arg) : cosf(arg);
+    }
+    __syncthreads();
+    for (int n0 = wave; n0 < hid; n0 += 4 * 8) {  // eight outputs of a wave in flight
+        float acc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc[u] = 0.f;
+            const int n = n0 + 4 * u;
+            if (n < hid)
+                for (int k = lane; k < dim; k += 64) acc[u] += e0[k] * w0[(long long)n * dim + k];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int n = n0 + 4 * u;
+            const float v = wave_sum(acc[u]);
+            if (n < hid && lane == 0) h1[n] = act_apply(1.f * (v + (b0 ? b0[n] : 0.f)), IDIFF_ACT_GELU);
+        }
+    }
+    __syncthreads();
+    const int per = (nout + 3) / 4, nb = blockIdx.x * per, ne = min(nout, nb + per);
+    for (int n0 = nb + wave; n0 < ne; n0 += 4 * 8) {
+        float acc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc[u] = 0.f;
+            const int n = n0 + 4 * u;
+            if (n < ne)
+                for (int k = lane; k < hid; k += 64) acc[u] += h1[k] * w2[(long long)n * hid + k];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int n = n0 + 4 * u;
+            const float v = wave_sum(acc[u]);
+            if (n < ne && lane == 0) out[(long long)b * nout + n] = 1.f * (v + (b2 ? b2[n] : 0.f));
         }
     }
 }
@@ -480,6 +548,38 @@ extern "C" int idiff_scoremap_fwd(const float* feat, int64_t feat_bstride, const
         hipLaunchKernelGGL(scoremap_kernel, dim3((HW + 255) / 256, B), dim3(256), (size_t)K * C * sizeof(float), (hipStream_t)stream, feat,
                            (long long)feat_bstride, tv, out, idx, sel, C, HW, K);
     IDIFF_CHECK_LAUNCH("scoremap");
+    return IDIFF_OK;
+}
+
+extern "C" int idiff_scoremap_grouped_fwd(const idiff_scoremap_group* groups, int ngroups, const int32_t* idx, int B, int K, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(groups && ngroups >= 1 && ngroups <= IDIFF_SCOREMAP_MAX_GROUPS, "scoremap_grouped: 1..%d groups", IDIFF_SCOREMAP_MAX_GROUPS);
+    IDIFF_CHECK_ARG(B > 0 && K > 0 && K <= SM_KMAX, "scoremap_grouped: K must be in 1..%d", SM_KMAX);
+    ScoremapGroups args;
+    memset(&args, 0, sizeof(args));
+    int gx = 0, cmax = 0;
+    for (int i = 0; i < ngroups; ++i) {
+        const idiff_scoremap_group& d = groups[i];
+        IDIFF_CHECK_ARG(d.feat && d.tv && d.out && d.C > 0 && d.HW > 0, "scoremap_grouped: group %d: bad args", i);
+        IDIFF_CHECK_ARG((idx == nullptr) == (d.sel == nullptr), "scoremap_grouped: group %d: idx/sel must both be set", i);
+        IDIFF_CHECK_ARG(d.HW % 4 == 0 && d.feat_bstride % 4 == 0 &&
+                            ((reinterpret_cast<uintptr_t>(d.feat) | reinterpret_cast<uintptr_t>(d.out) | reinterpret_cast<uintptr_t>(d.sel)) & 15) == 0,
+                        "scoremap_grouped: group %d: the grouped launch is the 16-byte form (HW %% 4 == 0, aligned operands)", i);
+        args.g[i] = d;
+        gx = max(gx, (d.HW / 4 + 255) / 256);
+        cmax = max(cmax, d.C);
+    }
+    hipLaunchKernelGGL(scoremap4_grouped_kernel, dim3(gx, B, ngroups), dim3(256), (size_t)K * cmax * sizeof(float), (hipStream_t)stream, args, idx, K);
+    IDIFF_CHECK_LAUNCH("scoremap_grouped");
+    return IDIFF_OK;
+}
+
+extern "C" int idiff_time_mlp_fwd(const float* t, const float* freqs, const float* w0, const float* b0, const float* w2, const float* b2, float* out,
+                                  int B, int dim, int hid, int nout, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(t && w0 && w2 && out && B > 0 && dim >= 4 && dim % 2 == 0 && hid > 0 && nout > 0, "time_mlp: bad args");
+    IDIFF_CHECK_ARG((size_t)(dim + hid) * sizeof(float) <= 48 * 1024, "time_mlp: dim + hid too large (%d)", dim + hid);
+    hipLaunchKernelGGL(time_mlp_kernel, dim3(4, B), dim3(256), (size_t)(dim + hid) * sizeof(float), (hipStream_t)stream, t, freqs, w0, b0, w2, b2, out,
+                       dim, hid, nout);
+    IDIFF_CHECK_LAUNCH("time_mlp");
     return IDIFF_OK;
 }
 

@@ -160,16 +160,15 @@ __global__ __launch_bounds__(256) void smm_memproj_kernel(const float* __restric
 // on the matrix cores instead of C -> 256 (4x fewer flops at C = 64), which leaves the kernel bandwidth-bound.
 // One workgroup = 64 pixels; 32 x 32 output tiles of y = G xhat are dealt to the 4 waves; sum_c' xhat[c'] (y[c'] + 2 h[c'])
 // is reduced over a lane's 16 rows, the two half-waves and the tiles through LDS.
-__global__ __launch_bounds__(256) void smm_memproj_gram_kernel(const float* __restrict__ feat, long long fbs, const float* __restrict__ g1,
-                                                               const float* __restrict__ b1, const float* __restrict__ gram,
-                                                               const float* __restrict__ hvec, float evar, float* __restrict__ out, int C,
-                                                               int N, int Cm, float eps1, float eps2) {
+__device__ __forceinline__ void smm_memproj_gram_body(const float* __restrict__ feat, long long fbs, const float* __restrict__ g1,
+                                                      const float* __restrict__ b1, const float* __restrict__ gram,
+                                                      const float* __restrict__ hvec, float evar, float* __restrict__ out, int C, int N, int Cm,
+                                                      float eps1, float eps2, const int b, const int bx) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xt = smem;                 // [C][64]
     float* part = smem + C * MP_PX;   // [8][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.y;
-    const int p0 = blockIdx.x * MP_PX;
+    const int p0 = bx * MP_PX;
     const float* fb = feat + (long long)b * fbs;
     const int nf4 = C * (MP_PX / 4);
     for (int f = tid; f < nf4; f += 256) {
@@ -247,6 +246,23 @@ __global__ __launch_bounds__(256) void smm_memproj_gram_kernel(const float* __re
             for (int e = 0; e < 4; ++e)
                 if (p0 + j4 + e < N) ob[(long long)c * N + p0 + j4 + e] = v[e];
     }
+}
+__global__ __launch_bounds__(256) void smm_memproj_gram_kernel(const float* __restrict__ feat, long long fbs, const float* __restrict__ g1,
+                                                               const float* __restrict__ b1, const float* __restrict__ gram,
+                                                               const float* __restrict__ hvec, float evar, float* __restrict__ out, int C,
+                                                               int N, int Cm, float eps1, float eps2) {
+    smm_memproj_gram_body(feat, fbs, g1, b1, gram, hvec, evar, out, C, N, Cm, eps1, eps2, blockIdx.y, blockIdx.x);
+}
+// Grouped launch (idiff_smm_memproj_compact_grouped_fwd): the compact memories of several ScoreMapModules in ONE launch; blockIdx.z
+// picks the level, blocks beyond a smaller level's pixels exit.  Same body, same bits.  The LDS of the launch is that of the widest
+// level, so callers group levels of equal channel count (the two 64-channel levels of the UNet).
+struct MemprojGroups {
+    idiff_memproj_group g[IDIFF_MEMPROJ_MAX_GROUPS];
+};
+__global__ __launch_bounds__(256) void smm_memproj_gram_grouped_kernel(const MemprojGroups args, float eps1, float eps2) {
+    const idiff_memproj_group& d = args.g[blockIdx.z];
+    if ((int)blockIdx.x * MP_PX >= d.N) return;  // uniform
+    smm_memproj_gram_body(d.feat, d.feat_bstride, d.ln1_g, d.ln1_b, d.gram, d.hvec, d.evar, d.out, d.C, d.N, d.Cm, eps1, eps2, blockIdx.y, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -531,6 +547,33 @@ extern "C" int idiff_smm_memproj_compact_fwd(const float* feat, int64_t feat_bst
     hipLaunchKernelGGL(smm_memproj_gram_kernel, dim3((N + MP_PX - 1) / MP_PX, B), dim3(256), lds, (hipStream_t)stream, feat, (long long)feat_bstride,
                        ln1_g, ln1_b, gram, hvec, evar, out, C, N, Cm, eps1, eps2);
     IDIFF_CHECK_LAUNCH("smm_memproj_compact_fwd");
+    return IDIFF_OK;
+}
+
+extern "C" int idiff_smm_memproj_compact_grouped_fwd(const idiff_memproj_group* groups, int ngroups, int B, float eps1, float eps2,
+                                                     idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(groups && ngroups >= 1 && ngroups <= IDIFF_MEMPROJ_MAX_GROUPS, "smm_memproj_compact_grouped: 1..%d groups", IDIFF_MEMPROJ_MAX_GROUPS);
+    MemprojGroups args;
+    memset(&args, 0, sizeof(args));
+    int gx = 0, cmax = 0;
+    for (int i = 0; i < ngroups; ++i) {
+        const idiff_memproj_group& d = groups[i];
+        IDIFF_CHECK_ARG(d.feat && d.ln1_g && d.ln1_b && d.gram && d.hvec && d.out, "smm_memproj_compact_grouped: group %d: null pointer", i);
+        IDIFF_CHECK_ARG(d.N > 0 && d.C >= 32 && d.C % 32 == 0 && d.C <= 512 && d.N % 4 == 0 && d.feat_bstride % 4 == 0 && d.Cm > d.C,
+                        "smm_memproj_compact_grouped: group %d: bad shape (C %d, N %d, Cm %d)", i, d.C, d.N, d.Cm);
+        args.g[i] = d;
+        gx = max(gx, (d.N + MP_PX - 1) / MP_PX);
+        cmax = max(cmax, d.C);
+    }
+    const size_t lds = (size_t)(cmax * MP_PX + 5 * MP_PX) * sizeof(float);
+    static size_t attr = 0;
+    if (lds > attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(smm_memproj_gram_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "smm_memproj_compact_grouped: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr = lds;
+    }
+    hipLaunchKernelGGL(smm_memproj_gram_grouped_kernel, dim3(gx, B, ngroups), dim3(256), lds, (hipStream_t)stream, args, eps1, eps2);
+    IDIFF_CHECK_LAUNCH("smm_memproj_compact_grouped_fwd");
     return IDIFF_OK;
 }
 

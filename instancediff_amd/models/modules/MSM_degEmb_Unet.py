@@ -13,6 +13,7 @@ include/idiff.h via instancediff_amd.ops.  There is no ATen fallback: on a machi
 library or without a GPU, forward() raises.
 """
 import math
+import os
 import weakref
 
 import torch
@@ -68,6 +69,15 @@ class _Prepared:
 
 
 _PREP = _Prepared()
+
+# IDIFF_SMM_SIDE=1 (experiment, off by default): each net's ScoreMapModule phase -- which only feeds the skip connections
+# the decoder reads later -- on a stream of its own beside the net's mid blocks.  Fork / join discipline under HIP-graph capture: the
+# side stream enters the capture by waiting on an event the net's stream records INSIDE the capture (side.wait_stream(cur)) and is
+# joined back (cur.wait_stream(side)) before the decoder's first ResBlock, i.e. before the net's stream is itself joined into the
+# capture's origin stream; tensors the side stream allocates and the net's stream consumes are record_stream()ed.
+SMM_SIDE = bool(int(os.environ.get("IDIFF_SMM_SIDE", "0")))
+# IDIFF_GROUPED_SMM=0 (A/B runs): the per-level launches of r04 for the memory projection, the cross-attention (+ merge) and the score map
+GROUPED_SMM = bool(int(os.environ.get("IDIFF_GROUPED_SMM", "1")))
 
 def packed(conv):
     return _PREP.get(("pk", conv), (conv.weight,), lambda: ops.pack_conv_weight(conv.weight.detach().contiguous()))
@@ -297,6 +307,7 @@ def decoder_tokens_grouped(smms, feats, texts, cache_prefix=True, plain_out=Fals
     R = B * K
 
     st = []  # per module: dict(dec, C, Cm, compact, mem, mp)
+    by_c = {}  # compact levels of equal channel count (and LayerNorm eps) share ONE memory-projection launch
     for m, feat, text in zip(smms, feats, texts):
         Bm, C, H, W = feat.shape
         assert Bm == B and text.shape[1] == K
@@ -307,14 +318,24 @@ def decoder_tokens_grouped(smms, feats, texts, cache_prefix=True, plain_out=Fals
         # g2.[Wc|bc] is folded into its query / value projections (b2 drops out of the softmax and returns as a bias).
         Cm = Wd if C + 1 > 136 else (72 if C + 1 <= 72 else 136)
         compact = Cm < Wd
+        mem = None
         if compact:
             gram, hvec, evar = _PREP.get(("mpvar", mp[1]), (mp[1].weight, mp[1].bias), lambda mp=mp: ops.memory_variance_form(mp[1].weight, mp[1].bias))
-            mem = ops.smm_memproj_compact(feat, mp[0].weight, mp[0].bias, gram, hvec, evar, Cm, eps1=mp[0].eps, eps2=mp[2].eps)
+            by_c.setdefault((C, mp[0].eps, mp[2].eps), []).append(
+                (len(st), dict(feat=feat, ln1_g=mp[0].weight, ln1_b=mp[0].bias, gram=gram, hvec=hvec, evar=evar, Cm=Cm)))
         else:
             wmp = _PREP.get(("mp", mp[1]), (mp[1].weight,),
                             lambda mp=mp, C=C: ops.pack_conv_weight(mp[1].weight.detach().reshape(Wd, C, 1, 1).contiguous()))
             mem = ops.smm_memproj(feat, mp[0].weight, mp[0].bias, wmp, mp[1].bias, mp[2].weight, mp[2].bias, eps=mp[0].eps)
         st.append(dict(m=m, dec=dec, C=C, Cm=Cm, compact=compact, mem=mem, mp=mp, t2d=text.reshape(R, m.text_dim)))
+    for (C, e1, e2), items in by_c.items():
+        if GROUPED_SMM and len(items) > 1:
+            mems = ops.smm_memproj_compact_grouped([it for _, it in items], eps1=e1, eps2=e2)
+        else:
+            mems = [ops.smm_memproj_compact(it["feat"], it["ln1_g"], it["ln1_b"], it["gram"], it["hvec"], it["evar"], it["Cm"], eps1=e1, eps2=e2)
+                    for _, it in items]
+        for (i, _), mem in zip(items, mems):
+            st[i]["mem"] = mem
 
     def fold_weights(s, ca):
         mp, Cm = s["mp"], s["Cm"]
@@ -388,10 +409,16 @@ def decoder_tokens_grouped(smms, feats, texts, cache_prefix=True, plain_out=Fals
         if li > 0:
             xs, qfs = self_attn_and_query(every, xs, li)
         avs, groups = [], []
-        for s, l, qf in zip(st, lay, qfs):
+        # the cross-attentions of all levels in ONE attention launch + ONE merge launch (one scale: the decoders share their geometry)
+        assert all(l.cross_attn.scale == lay[0].cross_attn.scale for l in lay)
+        if GROUPED_SMM and len(st) > 1:
+            os_ = ops.smm_xattn_grouped([qf.reshape(B, K, heads, s["Cm"]) for s, qf in zip(st, qfs)], [s["mem"] for s in st], lay[0].cross_attn.scale)
+        else:
+            os_ = [ops.smm_xattn(qf.reshape(B, K, heads, s["Cm"]), s["mem"], lay[0].cross_attn.scale) for s, qf in zip(st, qfs)]
+        for s, l, o in zip(st, lay, os_):
             Cm, ca = s["Cm"], l.cross_attn
             _, wvf, bvf = fold_weights(s, ca)
-            o = ops.smm_xattn(qf.reshape(B, K, heads, Cm), s["mem"], ca.scale).reshape(R, heads * Cm)
+            o = o.reshape(R, heads * Cm)
             # per head: av[:, h-block] = o[:, h-block] @ wvf[:, h column block] (+ bvf[h-block])  ([Cm, dh])
             av = torch.empty((R, Wd), device=dev, dtype=torch.float32)
             avs.append(av)
@@ -409,6 +436,14 @@ def decoder_tokens_grouped(smms, feats, texts, cache_prefix=True, plain_out=Fals
     # residual, per-column gain and LayerNorm fused into the last linear
     return ops.linear_t_grouped([dict(x=x, wT=wT(s["dec"].out_proj[1]), bias=s["dec"].out_proj[1].bias, res=t2v, gscale=s["m"].gamma,
                                       ln=(s["dec"].out_proj[0].weight, s["dec"].out_proj[0].bias, s["dec"].out_proj[0].eps)) for x, s, t2v in zip(xs, st, t2vs)])
+
+
+def _scoremaps(feats, tvs, idx):
+    """score maps of all levels: ONE grouped launch where every level has 16-byte rows (the streaming form), single launches otherwise"""
+    ok = all(f.shape[2] * f.shape[3] % 4 == 0 and f.data_ptr() % 16 == 0 and (f.stride(0) % 4 == 0 or f.shape[0] == 1) for f in feats)
+    if GROUPED_SMM and ok and 1 < len(feats) <= ops._lib.SCOREMAP_MAX_GROUPS and len({tv.shape[1] for tv in tvs}) == 1:
+        return ops.scoremap_grouped(feats, tvs, idx)
+    return [ops.scoremap(f, tv, idx) for f, tv in zip(feats, tvs)]
 
 
 def _grouped_chunks(groups):
@@ -702,9 +737,8 @@ class LearnableForwardUNet_MultiScoreMap(nn.Module):
         def ca_vec(ca_name, holder):
             return vecs[id(getattr(holder, ca_name))] if single else None
 
-        temb0 = ops.time_embed(t, self.nf, self.time_freqs)
-        temb = ops.linear(ops.linear(temb0, self.time_mlp[0].weight, self.time_mlp[0].bias, act_out=ops.ACT_GELU),
-                          self.time_mlp[2].weight, self.time_mlp[2].bias)
+        # sinusoidal embedding + both linears of the time MLP: one launch (the bits of time_embed -> linear(GELU) -> linear)
+        temb = ops.time_mlp(t, self.time_freqs, self.time_mlp[0].weight, self.time_mlp[0].bias, self.time_mlp[2].weight, self.time_mlp[2].bias)
         films = self._films(temb)
 
         x = ops.conv2d(x_a, packed(self.init_conv), self.init_conv.bias, 7, self.nf, src1=x_b)
@@ -734,23 +768,38 @@ class LearnableForwardUNet_MultiScoreMap(nn.Module):
             else:
                 hs.append(x)
             x = lv.down.run(x)
+        side = cur = None
         if use_sm:
             # A level's ScoreMapModule only feeds its skip connection (and the returned score maps), which the decoder reads much
             # later: the four modules run here, together -- every latency-bound token-side launch of their decoder chains serves all
             # four levels at once (decoder_tokens_grouped), 23 launches per net instead of 92.
-            smms = list(self.CLIP_ScoreMapModule)
-            texts = [m.text_embeddings(text_encoder, B) for m in smms]
-            tvs = decoder_tokens_grouped(smms, sm_feats, texts)
-            for i, (m, feat, tv, skip) in enumerate(zip(smms, sm_feats, tvs, sm_skips)):
-                din, dout, smc = self.level_dims[i]
-                score, sel = ops.scoremap(feat, tv.reshape(B, m.n_cls, feat.shape[1]), idx)
-                ops.conv2d(score, packed(self.sm_embed[i]), self.sm_embed[i].bias, 3, smc, out=skip[:, din:])
-                sms.append(sel)
+            def smm_phase():
+                smms = list(self.CLIP_ScoreMapModule)
+                texts = [m.text_embeddings(text_encoder, B) for m in smms]
+                tvs = decoder_tokens_grouped(smms, sm_feats, texts)
+                scores = _scoremaps(sm_feats, [tv.reshape(B, m.n_cls, feat.shape[1]) for m, feat, tv in zip(smms, sm_feats, tvs)], idx)
+                for i, ((score, sel), skip) in enumerate(zip(scores, sm_skips)):
+                    din, dout, smc = self.level_dims[i]
+                    ops.conv2d(score, packed(self.sm_embed[i]), self.sm_embed[i].bias, 3, smc, out=skip[:, din:])
+                    sms.append(sel)
+            if SMM_SIDE and x.is_cuda:
+                if getattr(self, "_side_stream", None) is None:
+                    self._side_stream = torch.cuda.Stream()
+                side, cur = self._side_stream, torch.cuda.current_stream()
+                side.wait_stream(cur)            # fork: the encoder's features are complete on the net's stream
+                with torch.cuda.stream(side):
+                    smm_phase()
+                for sel in sms:
+                    sel.record_stream(cur)
+            else:
+                smm_phase()
         x = self.mid_res1.run(x, None, films[id(self.mid_res1)])
         x = self.mid_attn.run(x, vec=ca_vec("mid_ca", self))
         if general:
             x = self.mid_ca.run(x, ctx)
         x = self.mid_res2.run(x, None, films[id(self.mid_res2)])
+        if side is not None:
+            cur.wait_stream(side)                # join: the skips carry the score-map embeddings from here on
         for up in self.ups:
             x = up.res1.run(x, hs.pop(), films[id(up.res1)], vec=ca_vec("ca1", up))
             if general:

@@ -6,8 +6,8 @@ import torch
 
 from ... import ops
 from .MSM_degEmb_Unet import branch_gains
-from ...train_ops import (ActFn, AddFn, AddVecFn, BgemmFn, ChanLayerNormFn, ChanNormalizeFn, ConvFn, GatherChannelFn, LayerNormRowsFn,
-                          LinearFn, ResBlockFn, ScaleColsFn, SmmXattnFn, SoftmaxRowsFn, dropout)
+from ...train_ops import (ActFn, AddFn, AddVecFn, BgemmFn, ChanLayerNormFn, ChanNormalizeFn, ConvFn, GatherChannelFn, HeadFoldFn, LayerNormRowsFn,
+                          Linear3Fn, LinearFn, ResBlockFn, ScaleColsFn, SkipCatFn, SmmXattnFn, SoftmaxRowsFn, TokenAttnFn, _Slot, dropout, fork)
 
 
 # IDIFF_FUSED_XATTN=0: the ScoreMapModule cross-attention of the training path as batched GEMMs + softmax (autograd-derived backward)
@@ -15,13 +15,14 @@ import os  # noqa: E402
 FUSED_XATTN = bool(int(os.environ.get("IDIFF_FUSED_XATTN", "1")))
 
 
-def _resblock(rb, src0, src1, temb_act, vec=None):
+def _resblock(rb, src0, src1, temb_act, vec=None, out=None):
+    """out: a preallocated destination (a channel slice of a skip buffer) the block's output is written into"""
     import torch.nn as nn
     film = LinearFn.apply(temb_act, rb.mlp.weight, rb.mlp.bias)
     ident = isinstance(rb.res_conv, nn.Identity)
     return ResBlockFn.apply(src0, src1, film, vec, rb.conv1.weight, rb.conv1.bias, rb.norm1.weight, rb.norm1.bias, rb.conv2.weight,
                             rb.conv2.bias, rb.norm2.weight, rb.norm2.bias, None if ident else rb.res_conv.weight,
-                            None if ident else rb.res_conv.bias, rb.groups, rb.norm1.eps)
+                            None if ident else rb.res_conv.bias, rb.groups, rb.norm1.eps, None if out is None else _Slot(out))
 
 
 def _heads_attention(q3, k3, v3, heads, scale):
@@ -71,6 +72,7 @@ def _self_attention(sa, x, vec=None):
     B, C, H, W = x.shape
     N, heads = H * W, sa.num_heads
     dh = C // heads
+    x, xr = fork(x, 2)
     xn = ChanLayerNormFn.apply(x, sa.norm.weight, sa.norm.bias, 1e-5)
     qkv = ConvFn.apply(xn, None, sa.qkv.weight, None, 1, ops.CONV_NORMAL).reshape(B, 3, heads, dh, N)
     q = qkv[:, 0].reshape(B * heads, dh, N)
@@ -80,12 +82,13 @@ def _self_attention(sa, x, vec=None):
     p = SoftmaxRowsFn.apply(s, sa.scale)            # [BH, N_q, N_k]
     o = BgemmFn.apply(v, p, False, True)            # [dh, N_k] . [N_k, N_q] -> channel-major [BH, dh, N_q]
     o = o.reshape(B, C, H, W)
-    y = AddFn.apply(x, ConvFn.apply(o, None, sa.proj.weight, sa.proj.bias, 1, ops.CONV_NORMAL), 1.0)
+    y = AddFn.apply(xr, ConvFn.apply(o, None, sa.proj.weight, sa.proj.bias, 1, ops.CONV_NORMAL), 1.0)
     return AddVecFn.apply(y, vec) if vec is not None else y
 
 
-def _smm(smm, feat, text_encoder, idx):
-    """ScoreMapModule forward in Function form -> (score [B,K,h,w], sel [B,1,h,w])"""
+def _smm(smm, feat, text_encoder, idx, feat_n=None):
+    """ScoreMapModule forward in Function form -> (score [B,K,h,w], sel [B,1,h,w]).  feat_n: a second handle on the same feature map
+    for the score map's normalisation (the caller's fork: the module reads the map twice)"""
     B, C, H, W = feat.shape
     K, N = smm.n_cls, H * W
     dec = smm.context_decoder
@@ -93,7 +96,10 @@ def _smm(smm, feat, text_encoder, idx):
     dh = Wd // heads
     text = smm.text_embeddings(text_encoder, B)
     t2d = text.reshape(B * K, smm.text_dim)
+    t2d, t2d_v = fork(t2d, 2)  # text projection and text_to_visual
     mp = dec.memory_proj
+    if feat_n is None:
+        feat, feat_n = fork(feat, 2)  # consumed by the memory projection and by the score map's normalisation
     fn = ChanLayerNormFn.apply(feat, mp[0].weight, mp[0].bias, mp[0].eps)
     m1 = ConvFn.apply(fn, None, mp[1].weight.reshape(Wd, C, 1, 1), mp[1].bias, 1, ops.CONV_NORMAL)
     mem = ChanLayerNormFn.apply(m1, mp[2].weight, mp[2].bias, mp[2].eps).reshape(B, Wd, N)
@@ -104,46 +110,54 @@ def _smm(smm, feat, text_encoder, idx):
     # MLP's inner Dropout and the block's output Dropout, models/_modified_BiomedCLIP.py:448-478,520-549); identity in eval()
     pd, tr = dec.dropout, smm.training
     mem_grad = {}  # the layers' gradients w.r.t. the shared memory are summed inside the fused backward kernel (SmmXattnFn)
+    fused_x = FUSED_XATTN and heads * K <= 32 and Wd == 256 and N % 4 == 0
+    fused_t = K <= 8 and dh <= 64  # few-token self-attention: one fused forward / backward launch each
 
     def branch(y, g):  # TransformerDecoderLayer_scaled's per-channel gain on a residual branch (:586-589); plain layers: none
         return y if g is None else ScaleColsFn.apply(y, g)
 
+    # Token rows r = (sample, class token).  No tensor is permuted or copied between the launches: the head dimension of the folded k / v
+    # projections lives in the strides of the batched GEMMs (HeadFoldFn: rows of a sample ordered (token, head) -- the attention over
+    # the memory treats its query rows independently), the three self-attention projections share one packed buffer, and a state
+    # with two consumers (residual + LayerNorm) is forked, so its two gradients meet in one library launch.
     for layer in dec.decoder:
         sa, ca = layer.self_attn, layer.cross_attn
         g_sa, g_ca, g_mlp = branch_gains(layer)
+        x, xr = fork(x, 2)
         n1 = LayerNormRowsFn.apply(x, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
-        q = LinearFn.apply(n1, sa.q_proj.weight, None).reshape(B, K, Wd)
-        k = LinearFn.apply(n1, sa.k_proj.weight, None).reshape(B, K, Wd)
-        v = LinearFn.apply(n1, sa.v_proj.weight, None).reshape(B, K, Wd)
-        a = _heads_attention(q, k, v, heads, sa.scale).reshape(R, Wd)
-        x = AddFn.apply(x, branch(dropout(LinearFn.apply(a, sa.proj.weight, sa.proj.bias), pd, tr), g_sa), 1.0)
+        if fused_t:
+            a = TokenAttnFn.apply(Linear3Fn.apply(n1, sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight), B, K, heads, sa.scale)
+        else:
+            n1a, n1b, n1c = fork(n1, 3)
+            q = LinearFn.apply(n1a, sa.q_proj.weight, None).reshape(B, K, Wd)
+            k = LinearFn.apply(n1b, sa.k_proj.weight, None).reshape(B, K, Wd)
+            v = LinearFn.apply(n1c, sa.v_proj.weight, None).reshape(B, K, Wd)
+            a = _heads_attention(q, k, v, heads, sa.scale).reshape(R, Wd)
+        x = AddFn.apply(xr, branch(dropout(LinearFn.apply(a, sa.proj.weight, sa.proj.bias), pd, tr), g_sa), 1.0)
+        x, xr = fork(x, 2)
         n2 = LayerNormRowsFn.apply(x, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
         qc = LinearFn.apply(n2, ca.q_proj.weight, None)  # [R, Wd]
         # k/v projections folded onto the queries: qf_h = q_h Wk_h ; S = qf mem ; o = P mem^T ; av_h = o_h Wv_h^T.
-        # All heads' query rows are stacked ([B, heads*K, Wd]) so `mem` is read once per product, not once per head.
-        # (every head in one batched GEMM: batch = heads, through permutes -- no per-head slices, see _heads_attention)
-        qh = qc.reshape(R, heads, dh).permute(1, 0, 2)                                   # [heads, R, dh]
-        qf = BgemmFn.apply(qh, ca.k_proj.weight.reshape(heads, dh, Wd), False, False)    # [heads, R, Wd]
-        qf = qf.reshape(heads, B, K, Wd).permute(1, 0, 2, 3).reshape(B, heads * K, Wd)   # row = h*K + k
-        if FUSED_XATTN and heads * K <= 32 and Wd == 256 and N % 4 == 0:
+        # All heads' query rows are stacked ([B, K*heads, Wd]) so `mem` is read once per product, not once per head.
+        qf = HeadFoldFn.apply(qc, ca.k_proj.weight, heads, "in").reshape(B, K * heads, Wd)   # row = k*heads + h
+        if fused_x:
             o = SmmXattnFn.apply(qf, mem, ca.scale, mem_grad)        # one fused forward, one fused backward pass over the keys
         else:
-            s = BgemmFn.apply(qf, mem, False, False)                 # [B, heads*K, N]
-            p = SoftmaxRowsFn.apply(s, ca.scale)
-            o = BgemmFn.apply(p, mem, False, True)                   # [B, heads*K, Wd]
-        oh = o.reshape(B, heads, K, Wd).permute(1, 0, 2, 3).reshape(heads, R, Wd)        # [heads, R, Wd]
-        av = BgemmFn.apply(oh, ca.v_proj.weight.reshape(heads, dh, Wd), False, True)     # [heads, R, dh]
-        av = av.permute(1, 0, 2).reshape(R, Wd)
-        x = AddFn.apply(x, branch(dropout(LinearFn.apply(av, ca.proj.weight, ca.proj.bias), pd, tr), g_ca), 1.0)
+            s_ = BgemmFn.apply(qf, mem, False, False)                # [B, K*heads, N]
+            p = SoftmaxRowsFn.apply(s_, ca.scale)
+            o = BgemmFn.apply(p, mem, False, True)                   # [B, K*heads, Wd]
+        av = HeadFoldFn.apply(o.reshape(R, heads, Wd), ca.v_proj.weight, heads, "out")       # [R, Wd]
+        x = AddFn.apply(xr, branch(dropout(LinearFn.apply(av, ca.proj.weight, ca.proj.bias), pd, tr), g_ca), 1.0)
+        x, xr = fork(x, 2)
         n3 = LayerNormRowsFn.apply(x, layer.norm3.weight, layer.norm3.bias, layer.norm3.eps)
         hm = dropout(ActFn.apply(LinearFn.apply(n3, layer.mlp[0].weight, layer.mlp[0].bias), ops.ACT_GELU), pd, tr)
-        x = AddFn.apply(x, branch(dropout(LinearFn.apply(hm, layer.mlp[3].weight, layer.mlp[3].bias), pd, tr), g_mlp), 1.0)
+        x = AddFn.apply(xr, branch(dropout(LinearFn.apply(hm, layer.mlp[3].weight, layer.mlp[3].bias), pd, tr), g_mlp), 1.0)
     op = dec.out_proj
     diff = LinearFn.apply(LayerNormRowsFn.apply(x, op[0].weight, op[0].bias, op[0].eps), op[1].weight, op[1].bias)  # [R, C]
-    t2v = LinearFn.apply(t2d, smm.text_to_visual.weight, smm.text_to_visual.bias)
+    t2v = LinearFn.apply(t2d_v, smm.text_to_visual.weight, smm.text_to_visual.bias)
     tv = AddFn.apply(t2v, ScaleColsFn.apply(diff, smm.gamma), 1.0)
     tvn = ChanNormalizeFn.apply(tv.reshape(R, C, 1)).reshape(B, K, C)
-    fnm = ChanNormalizeFn.apply(feat).reshape(B, C, N)
+    fnm = ChanNormalizeFn.apply(feat_n).reshape(B, C, N)
     score = BgemmFn.apply(tvn, fnm, False, False).reshape(B, K, H, W)
     sel = GatherChannelFn.apply(score, idx)
     return score, sel
@@ -170,47 +184,63 @@ def forward_train(net, x_a, x_b, t, names, text_encoder, image_context=None):
     hmid = ActFn.apply(LinearFn.apply(temb0, net.time_mlp[0].weight, net.time_mlp[0].bias), ops.ACT_GELU)
     temb = LinearFn.apply(hmid, net.time_mlp[2].weight, net.time_mlp[2].bias)
     tact = ActFn.apply(temb, ops.ACT_SILU)
+    tacts = list(fork(tact, len(net.resblocks())))  # one handle per ResBlock's time projection: their gradients meet in library launches
 
+    # A feature map with several consumers is handed out through fork(): the consumers' gradients then meet in ONE library launch
+    # (idiff_sum_n) instead of autograd's pairwise ATen adds.  A level's skip cat(x, score-map embedding) is never copied together: both
+    # producers write into the channel slices of one buffer (SkipCatFn), as in the sampling path.
     x = ConvFn.apply(x_a.contiguous(), x_b.contiguous(), net.init_conv.weight, net.init_conv.bias, 7, ops.CONV_NORMAL)
-    x_ = x
+    x, x_ = fork(x, 2)
     hs, sms = [], []
     use_sm = net.CLIP_ScoreMapModule is not None
     for i, lv in enumerate(net.downs):
-        x = _resblock(lv.res1, x, None, tact, vec_of(lv, "ca1"))
+        x = _resblock(lv.res1, x, None, tacts.pop(), vec_of(lv, "ca1"))
         if general:
             x = _ca_general(lv.ca1, x, ctx)
-        hs.append(x)
-        x = _resblock(lv.res2, x, None, tact, vec_of(lv, "ca2"))
+        x, xs = fork(x, 2)
+        hs.append(xs)
+        din, dout, smc = net.level_dims[i]
+        skipbuf = None
+        if use_sm and not general:
+            with torch.no_grad():
+                skipbuf = torch.empty((B, din + smc, x.shape[2], x.shape[3]), device=dev, dtype=torch.float32)
+        x = _resblock(lv.res2, x, None, tacts.pop(), vec_of(lv, "ca2"), out=None if skipbuf is None else skipbuf[:, :din].detach())
         if general:
             x = _ca_general(lv.ca2, x, ctx)
         if use_sm:
-            score, sel = _smm(net.CLIP_ScoreMapModule[i], x, text_encoder, idx)
+            x, x_smm, x_smm2, x_skip = fork(x, 4)  # down conv, memory projection, score-map normalisation, skip
+            score, sel = _smm(net.CLIP_ScoreMapModule[i], x_smm, text_encoder, idx, feat_n=x_smm2)
             sms.append(sel)
-            emb = ConvFn.apply(score, None, net.sm_embed[i].weight, net.sm_embed[i].bias, 3, ops.CONV_NORMAL)
-            hs.append(("cat", x, emb))
+            if skipbuf is not None:
+                emb = ConvFn.apply(score, None, net.sm_embed[i].weight, net.sm_embed[i].bias, 3, ops.CONV_NORMAL, _Slot(skipbuf[:, din:].detach()))
+                hs.append(SkipCatFn.apply(x_skip, emb, _Slot(skipbuf)))
+            else:
+                emb = ConvFn.apply(score, None, net.sm_embed[i].weight, net.sm_embed[i].bias, 3, ops.CONV_NORMAL)
+                hs.append(("cat", x_skip, emb))
         else:
-            hs.append(x)
+            x, xs = fork(x, 2)
+            hs.append(xs)
         down = lv.down
         mode = ops.CONV_UNSHUFFLE2 if type(down).__name__ == "Downsample" else ops.CONV_NORMAL
         x = ConvFn.apply(x, None, down.conv.weight, down.conv.bias, 1 if mode == ops.CONV_UNSHUFFLE2 else 3, mode)
-    x = _resblock(net.mid_res1, x, None, tact)
+    x = _resblock(net.mid_res1, x, None, tacts.pop())
     x = _self_attention(net.mid_attn, x, vec_of(net, "mid_ca"))
     if general:
         x = _ca_general(net.mid_ca, x, ctx)
-    x = _resblock(net.mid_res2, x, None, tact)
+    x = _resblock(net.mid_res2, x, None, tacts.pop())
     for up in net.ups:
         skip = hs.pop()
         skip = torch.cat([skip[1], skip[2]], dim=1) if isinstance(skip, tuple) else skip
-        x = _resblock(up.res1, x, skip, tact, vec_of(up, "ca1"))
+        x = _resblock(up.res1, x, skip, tacts.pop(), vec_of(up, "ca1"))
         if general:
             x = _ca_general(up.ca1, x, ctx)
-        x = _resblock(up.res2, x, hs.pop(), tact, vec_of(up, "ca2"))
+        x = _resblock(up.res2, x, hs.pop(), tacts.pop(), vec_of(up, "ca2"))
         if general:
             x = _ca_general(up.ca2, x, ctx)
         u = up.up
         mode = ops.CONV_UPSAMPLE2 if type(u).__name__ == "Upsample" else ops.CONV_NORMAL
         x = ConvFn.apply(x, None, u.conv.weight, u.conv.bias, 3, mode)
-    x = _resblock(net.final_res, x, x_, tact)
+    x = _resblock(net.final_res, x, x_, tacts.pop())
     out = ConvFn.apply(x, None, net.final_conv.weight, net.final_conv.bias, 3, ops.CONV_NORMAL)
     pred = GatherChannelFn.apply(out, idx)
     if net.text_module == "scoremap":

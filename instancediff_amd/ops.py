@@ -523,6 +523,87 @@ def smm_xattn(qf, mem, scale):
     return o
 
 
+def smm_xattn_grouped(qfs, mems, scale):
+    """smm_xattn for several (qf [B,Nq,heads,Cm_i], mem [B,Cm_i,N_i]) pairs of one (B, Nq, heads) in ONE attention launch + ONE merge
+    launch (idiff_smm_xattn_grouped_fwd) -> list of o; the same bits as the single calls."""
+    lib = _lib.load()
+    n = len(qfs)
+    assert 1 <= n <= _lib.XATTN_MAX_GROUPS and len(mems) == n
+    B, Nq, heads, _ = qfs[0].shape
+    arr = (_lib.XattnGroup * n)()
+    outs, keep = [], []
+    for d, qf, mem in zip(arr, qfs, mems):
+        _c(qf, "qf"), _c(mem, "mem")
+        Cm, N = qf.shape[3], mem.shape[2]
+        assert tuple(qf.shape[:3]) == (B, Nq, heads) and tuple(mem.shape[:2]) == (B, Cm)
+        ws = torch.empty((lib.idiff_smm_xattn_ws_floats(B, Nq, heads, Cm, N),), device=qf.device, dtype=torch.float32)
+        o = torch.empty_like(qf)
+        d.qf, d.mem, d.o, d.ws, d.Cm, d.N = qf.data_ptr(), mem.data_ptr(), o.data_ptr(), ws.data_ptr(), Cm, N
+        outs.append(o)
+        keep.append(ws)
+    check(lib.idiff_smm_xattn_grouped_fwd(arr, n, B, Nq, heads, scale, _stream()), "smm_xattn_grouped_fwd")
+    return outs
+
+
+def smm_memproj_compact_grouped(items, eps1=1e-5, eps2=1e-5):
+    """smm_memproj_compact for several levels in ONE launch; items: dicts feat, ln1_g, ln1_b, gram, hvec, evar, Cm -> list of [B,Cm,H*W]"""
+    lib = _lib.load()
+    n = len(items)
+    assert 1 <= n <= _lib.MEMPROJ_MAX_GROUPS
+    B = items[0]["feat"].shape[0]
+    arr = (_lib.MemprojGroup * n)()
+    outs = []
+    for d, it in zip(arr, items):
+        feat = it["feat"]
+        Bf, Cc, H, W = feat.shape
+        assert Bf == B
+        out = torch.empty((B, it["Cm"], H * W), device=feat.device, dtype=torch.float32)
+        d.feat, d.feat_bstride = feat.data_ptr(), _bs(feat, "feat")
+        d.ln1_g, d.ln1_b = _c(it["ln1_g"]).data_ptr(), _c(it["ln1_b"]).data_ptr()
+        d.gram, d.hvec, d.evar = _c(it["gram"]).data_ptr(), _c(it["hvec"]).data_ptr(), float(it["evar"])
+        d.out, d.C, d.N, d.Cm = out.data_ptr(), Cc, H * W, it["Cm"]
+        outs.append(out)
+    check(lib.idiff_smm_memproj_compact_grouped_fwd(arr, n, B, eps1, eps2, _stream()), "smm_memproj_compact_grouped_fwd")
+    return outs
+
+
+def scoremap_grouped(feats, tvs, idx):
+    """scoremap for several levels in ONE launch -> list of (score [B,K,H,W], sel [B,1,H,W] or None)"""
+    lib = _lib.load()
+    n = len(feats)
+    assert 1 <= n <= _lib.SCOREMAP_MAX_GROUPS and len(tvs) == n
+    B = feats[0].shape[0]
+    K = tvs[0].shape[1]
+    if idx is not None:
+        _c(idx, "idx", torch.int32)
+    arr = (_lib.ScoremapGroup * n)()
+    outs = []
+    for d, feat, tv in zip(arr, feats, tvs):
+        Bf, Cc, H, W = feat.shape
+        _c(tv, "tv")
+        assert Bf == B and tuple(tv.shape) == (B, K, Cc)
+        out = torch.empty((B, K, H, W), device=feat.device, dtype=torch.float32)
+        sel = torch.empty((B, 1, H, W), device=feat.device, dtype=torch.float32) if idx is not None else None
+        d.feat, d.feat_bstride, d.tv, d.out, d.sel, d.C, d.HW = feat.data_ptr(), _bs(feat, "feat"), tv.data_ptr(), out.data_ptr(), \
+            (sel.data_ptr() if sel is not None else None), Cc, H * W
+        outs.append((out, sel))
+    check(lib.idiff_scoremap_grouped_fwd(arr, n, _p(idx), B, K, _stream()), "scoremap_grouped_fwd")
+    return outs
+
+
+def time_mlp(t, freqs, w0, b0, w2, b2):
+    """temb [B, nout] = w2 . GELU(w0 . sinusoidal(t) + b0) + b2 in one launch (idiff_time_mlp_fwd)"""
+    lib = _lib.load()
+    _c(t, "t"), _c(freqs, "freqs"), _c(w0, "w0"), _c(b0, "b0"), _c(w2, "w2"), _c(b2, "b2")
+    B = t.numel()
+    hid, dim = w0.shape
+    nout = w2.shape[0]
+    assert w2.shape[1] == hid
+    out = torch.empty((B, nout), device=t.device, dtype=torch.float32)
+    check(lib.idiff_time_mlp_fwd(_p(t), _p(freqs), _p(w0), _p(b0), _p(w2), _p(b2), _p(out), B, dim, hid, nout, _stream()), "time_mlp")
+    return out
+
+
 def conv3x3_select(x, weight, bias, idx):
     """final 3x3 conv + class gather in one pass: x [B,C,H,W], weight [K,C,3,3] (torch layout), idx int32 [B] -> [B,1,H,W]."""
     lib = _lib.load()

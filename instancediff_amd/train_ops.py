@@ -139,7 +139,9 @@ def batch_sum(bc):
     return out
 
 
-def bgemm(A, B, M, N, K, lda, ldb, transA, transB, sA, sB, batch, out=None, alpha=1.0, beta=0.0):
+def bgemm(A, B, M, N, K, lda, ldb, transA, transB, sA, sB, batch, out=None, alpha=1.0, beta=0.0, ldc=None, sC=None):
+    """ldc / sC: row and batch stride of C inside `out` (default: a dense [batch, M, N]); A, B, out are base pointers (tensors whose
+    data_ptr() is the first element of batch 0)"""
     lib = _lib.load()
     _chk(A), _chk(B)
     if out is None:
@@ -147,8 +149,8 @@ def bgemm(A, B, M, N, K, lda, ldb, transA, transB, sA, sB, batch, out=None, alph
     nws = lib.idiff_bgemm_ws_floats(M, N, K, batch)
     ws = torch.empty((nws,), device=A.device, dtype=torch.float32) if nws else None
     with _prof("bgemm", 2.0 * M * N * K * batch):
-        check(lib.idiff_bgemm(_p(A), _p(B), _p(out), M, N, K, lda, ldb, N, 1 if transA else 0, 1 if transB else 0, sA, sB, M * N, batch, alpha, beta,
-                              _p(ws), _stream()), "bgemm")
+        check(lib.idiff_bgemm(_p(A), _p(B), _p(out), M, N, K, lda, ldb, N if ldc is None else ldc, 1 if transA else 0, 1 if transB else 0, sA, sB,
+                              M * N if sC is None else sC, batch, alpha, beta, _p(ws), _stream()), "bgemm")
     return out
 
 
@@ -179,9 +181,9 @@ class ConvFn(torch.autograd.Function):
     """plain conv (virtual concat / upsample / unshuffle gather modes), bias; no fused prologue/epilogue."""
 
     @staticmethod
-    def forward(ctx, src0, src1, weight, bias, ks, mode):
+    def forward(ctx, src0, src1, weight, bias, ks, mode, slot=None):
         Cout = weight.shape[0]
-        out = ops.conv2d(src0, _packed(weight), bias, ks, Cout, src1=src1, mode=mode)
+        out = ops.conv2d(src0, _packed(weight), bias, ks, Cout, src1=src1, mode=mode, out=None if slot is None else slot.t)
         ctx.save_for_backward(src0, src1, weight)
         ctx.ks, ctx.mode, ctx.has_bias = ks, mode, bias is not None
         return out
@@ -204,7 +206,7 @@ class ConvFn(torch.autograd.Function):
             d1 = dxv[:, C0:] if src1 is not None else None
         dw = conv2d_wgrad(src0, src1, mode, ks, dout, Cin) if ctx.needs_input_grad[2] else None
         db = channel_sums(dout) if ctx.has_bias and ctx.needs_input_grad[3] else None
-        return d0, d1, dw, db, None, None
+        return d0, d1, dw, db, None, None, None
 
 
 class ResBlockFn(torch.autograd.Function):
@@ -212,17 +214,18 @@ class ResBlockFn(torch.autograd.Function):
     inference path (GN statistics in the conv epilogue, normalise+SiLU in the next conv's gather)."""
 
     @staticmethod
-    def forward(ctx, src0, src1, film, vec, w1, b1, g1, be1, w2, b2, g2, be2, wr, br, groups, eps):
+    def forward(ctx, src0, src1, film, vec, w1, b1, g1, be1, w2, b2, g2, be2, wr, br, groups, eps, slot=None):
         B, _, H, W = src0.shape
+        dst = None if slot is None else slot.t
         Co, HW = w1.shape[0], H * W
         h1, st1 = ops.conv2d(src0, _packed(w1), b1, 3, Co, src1=src1, want_stats=True)
         a1, c1, mr1 = ops.gn_finalize(st1, groups, HW, g1, be1, film=film, eps=eps, want_mean_rstd=True)
         h2, st2 = ops.conv2d(h1, _packed(w2), b2, 3, Co, pro=(a1, c1), want_stats=True)
         a2, c2, mr2 = ops.gn_finalize(st2, groups, HW, g2, be2, eps=eps, want_mean_rstd=True)
         if wr is None:
-            out = ops.affine_silu_add(h2, (a2, c2), res=src0, vec=vec)
+            out = ops.affine_silu_add(h2, (a2, c2), res=src0, vec=vec, out=dst)
         else:
-            out = ops.conv2d(src0, _packed(wr), br, 1, Co, src1=src1, aux=(h2, a2, c2), vec=vec)
+            out = ops.conv2d(src0, _packed(wr), br, 1, Co, src1=src1, aux=(h2, a2, c2), vec=vec, out=dst)
         ctx.save_for_backward(src0, src1, film, w1, g1, be1, w2, g2, be2, wr, h1, h2, a1, c1, mr1, a2, c2, mr2)
         ctx.groups, ctx.has_vec = groups, vec is not None
         return out
@@ -254,7 +257,7 @@ class ResBlockFn(torch.autograd.Function):
         dx = conv2d_dgrad(dh1, w1, 3, ops.CONV_NORMAL, Cin, res=dres)
         d0 = dx[:, :C0] if src1 is not None else dx
         d1 = dx[:, C0:] if src1 is not None else None
-        return d0, d1, dfilm, dvec, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, dwr, dbr, None, None
+        return d0, d1, dfilm, dvec, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, dwr, dbr, None, None, None
 
 
 class BgemmFn(torch.autograd.Function):
@@ -290,6 +293,125 @@ class BgemmFn(torch.autograd.Function):
             else:       # dB stored [N,K] = dC^T [N,M] . op(A) [M,K]
                 dB = bgemm(dC, A, N, K, M, N, A.stride(1), True, tA, M * N, A.stride(0), batch)
         return dA, dB, None, None
+
+
+class HeadFoldFn(torch.autograd.Function):
+    """Per-head product between token rows and a weight's head blocks, with the head dimension living in the STRIDES of the batched GEMM
+    (no permute / reshape copies, whose autograd backward is an ATen copy or a zero-fill + add per head):
+      fold = "in":   y[r, h, :] = x[r, h*dh:(h+1)*dh] @ w[h*dh:(h+1)*dh, :]          x [R, heads*dh], w [heads*dh, Wd] -> y [R, heads, Wd]
+      fold = "out":  y[r, h*dh:(h+1)*dh] = x[r, h, :] @ w[h*dh:(h+1)*dh, :]^T        x [R, heads, Wd], w [heads*dh, Wd] -> y [R, heads*dh]
+    (the cross-attention's k / v projections folded onto the class-token queries / outputs; row r = (sample, class token), so
+    y.reshape(B, K*heads, Wd) is the per-sample row block the fused attention kernel takes, rows ordered (token, head))."""
+
+    @staticmethod
+    def forward(ctx, x, w, heads, fold):
+        x, w = x.contiguous(), w.contiguous()
+        R = x.shape[0]
+        Wd = w.shape[1]
+        dh = w.shape[0] // heads
+        ctx.save_for_backward(x, w)
+        ctx.geom = (R, Wd, dh, heads, fold)
+        if fold == "in":
+            y = torch.empty((R, heads, Wd), device=x.device, dtype=torch.float32)
+            bgemm(x, w, R, Wd, dh, heads * dh, Wd, False, False, dh, dh * Wd, heads, out=y, ldc=heads * Wd, sC=Wd)
+        else:
+            y = torch.empty((R, heads * dh), device=x.device, dtype=torch.float32)
+            bgemm(x, w, R, dh, Wd, heads * Wd, Wd, False, True, Wd, dh * Wd, heads, out=y, ldc=heads * dh, sC=dh)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        R, Wd, dh, heads, fold = ctx.geom
+        dy = dy.contiguous()
+        dx = dw = None
+        if fold == "in":  # y_h = x_h w_h
+            if ctx.needs_input_grad[0]:   # dx_h [R, dh] = dy_h [R, Wd] w_h^T
+                dx = torch.empty_like(x)
+                bgemm(dy, w, R, dh, Wd, heads * Wd, Wd, False, True, Wd, dh * Wd, heads, out=dx, ldc=heads * dh, sC=dh)
+            if ctx.needs_input_grad[1]:   # dw_h [dh, Wd] = x_h^T [dh, R] dy_h [R, Wd]
+                dw = torch.empty_like(w)
+                bgemm(x, dy, dh, Wd, R, heads * dh, heads * Wd, True, False, dh, Wd, heads, out=dw, ldc=Wd, sC=dh * Wd)
+        else:             # y_h = x_h w_h^T
+            if ctx.needs_input_grad[0]:   # dx_h [R, Wd] = dy_h [R, dh] w_h [dh, Wd]
+                dx = torch.empty_like(x)
+                bgemm(dy, w, R, Wd, dh, heads * dh, Wd, False, False, dh, dh * Wd, heads, out=dx, ldc=heads * Wd, sC=Wd)
+            if ctx.needs_input_grad[1]:   # dw_h [dh, Wd] = dy_h^T [dh, R] x_h [R, Wd]
+                dw = torch.empty_like(w)
+                bgemm(dy, x, dh, Wd, R, heads * dh, heads * Wd, True, False, dh, Wd, heads, out=dw, ldc=Wd, sC=dh * Wd)
+        return dx, dw, None, None
+
+
+class Linear3Fn(torch.autograd.Function):
+    """[x Wq^T | x Wk^T | x Wv^T] as ONE packed [R, 3N] output (bias-free projections of one input): three matrix-core launches into the
+    column blocks of one buffer; the backward accumulates dx through the residual input of the transposed-weight linear instead of
+    leaving two fan-in adds to autograd."""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv):
+        _chk(x, "x")
+        lib = _lib.load()
+        assert x.dim() == 2 and x.stride(1) == 1
+        R, K = x.shape
+        N = wq.shape[0]
+        y = torch.empty((R, 3 * N), device=x.device, dtype=torch.float32)
+        for i, w in enumerate((wq, wk, wv)):
+            assert tuple(w.shape) == (N, K) and w.stride(1) == 1
+            check(lib.idiff_linear_mfma_fwd(_p(x), x.stride(0), _p(w), w.stride(0), None, C.c_void_p(y.data_ptr() + 4 * i * N), 3 * N, R, K, N,
+                                            _stream()), "linear_mfma_fwd")
+        ctx.save_for_backward(x, wq, wk, wv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wq, wk, wv = ctx.saved_tensors
+        dy = dy.contiguous()
+        R, K = x.shape
+        N = wq.shape[0]
+        dx = None
+        dws = [None, None, None]
+        for i, w in enumerate((wq, wk, wv)):
+            dyi = dy[:, i * N:(i + 1) * N]
+            if ctx.needs_input_grad[0]:
+                dx = ops.linear_t(dyi, w, res=dx)   # dx += dy_i W_i (w [N,K] is the transposed-weight form of dy -> dx)
+            if ctx.needs_input_grad[1 + i]:
+                dws[i] = bgemm(dyi, x, N, K, R, dy.stride(0), x.stride(0), True, False, 0, 0, 1).reshape(N, K)
+        return dx, dws[0], dws[1], dws[2]
+
+
+class TokenAttnFn(torch.autograd.Function):
+    """self-attention among the few class tokens on a packed projection qkv [B*Nt, 3C] (q | k | v): forward = the sampling path's
+    attn_tokens kernel, backward = ONE launch (idiff_attn_tokens_bwd) that recomputes P -- instead of two batched GEMMs + softmax
+    forward, four + softmax backward and six head-permute copies per layer."""
+
+    @staticmethod
+    def forward(ctx, qkv, B, Nt, heads, scale):
+        lib = _lib.load()
+        _c(qkv, "qkv")
+        C3 = qkv.shape[1]
+        Cc = C3 // 3
+        out = torch.empty((B * Nt, Cc), device=qkv.device, dtype=torch.float32)
+        base = qkv.data_ptr()
+        check(lib.idiff_attn_tokens_fwd(C.c_void_p(base), C.c_void_p(base + 4 * Cc), C.c_void_p(base + 8 * Cc), _p(out), B, Nt, Nt, Cc, heads, scale,
+                                        C3, C3, _stream()), "attn_tokens_fwd")
+        ctx.save_for_backward(qkv)
+        ctx.geom = (B, Nt, heads, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_o):
+        lib = _lib.load()
+        (qkv,) = ctx.saved_tensors
+        B, Nt, heads, scale = ctx.geom
+        d_o = d_o.contiguous()
+        C3 = qkv.shape[1]
+        Cc = C3 // 3
+        dqkv = torch.empty_like(qkv)
+        base, dbase = qkv.data_ptr(), dqkv.data_ptr()
+        check(lib.idiff_attn_tokens_bwd(C.c_void_p(base), C.c_void_p(base + 4 * Cc), C.c_void_p(base + 8 * Cc), _p(d_o), C.c_void_p(dbase),
+                                        C.c_void_p(dbase + 4 * Cc), C.c_void_p(dbase + 8 * Cc), B, Nt, Nt, Cc, heads, scale, C3, C3, Cc, C3, C3,
+                                        _stream()), "attn_tokens_bwd")
+        return dqkv, None, None, None, None
 
 
 class SmmXattnFn(torch.autograd.Function):
@@ -561,6 +683,75 @@ class AddFn(torch.autograd.Function):
         d = d.contiguous()
         db = d if ctx.alpha == 1.0 else ops.axpby(d, d, ctx.alpha, 0.0)
         return d, db, None
+
+
+def sum_n(ts):
+    """sum of 2..4 same-shaped [B, ...] tensors whose samples are contiguous (batch-strided operands allowed) in ONE launch"""
+    lib = _lib.load()
+    n = len(ts)
+    assert 2 <= n <= 4
+    ts = [_samples_contiguous(t) for t in ts]
+    B = ts[0].shape[0]
+    per = ts[0].numel() // B
+    out = torch.empty(ts[0].shape, device=ts[0].device, dtype=torch.float32)
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    bss = (C.c_int64 * n)(*[(t.stride(0) if B > 1 else per) for t in ts])
+    check(lib.idiff_sum_n(ptrs, bss, n, _p(out), per, B, per, _stream()), "sum_n")
+    return out
+
+
+class ForkFn(torch.autograd.Function):
+    """x -> n aliases of x for n consumers.  The backward receives the consumers' gradients together and sums them in ONE library
+    launch (idiff_sum_n; batch-strided operands are taken as they are) -- autograd's own fan-in would add them pairwise in ATen
+    (n - 1 passes over the tensor, plus a copy whenever a gradient is a channel slice of a bigger tensor)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n = n
+        return tuple(x.detach() for _ in range(n))  # plain aliases (no view bookkeeping: the kernels write through raw pointers)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        live = [g for g in gs if g is not None]
+        if not live:
+            return None, None
+        if len(live) == 1:
+            return live[0], None
+        while len(live) > 4:   # (not reached by the UNet: at most four consumers)
+            live = [sum_n(live[:4])] + live[4:]
+        return sum_n(live), None
+
+
+def fork(x, n):
+    """n handles on x for n consumers (see ForkFn); needs 16-byte rows, else the plain tensor n times (autograd sums)"""
+    per = x.numel() // x.shape[0]
+    if n < 2 or not x.requires_grad or per % 4 != 0:
+        return (x,) * n
+    return ForkFn.apply(x, n)
+
+
+class _Slot:
+    """a plain (non-tensor) holder: hands a preallocated output buffer into an autograd Function without autograd seeing an input"""
+
+    def __init__(self, t):
+        self.t = t
+
+
+class SkipCatFn(torch.autograd.Function):
+    """cat(x, emb) along channels WITHOUT a copy: x and emb were written by their producers straight into the two channel slices of
+    one buffer (the inference path's virtual concat); forward hands out that buffer, backward hands each producer its slice of the
+    gradient (views; the consumers take batch-strided gradients)."""
+
+    @staticmethod
+    def forward(ctx, x, emb, slot):
+        buf = slot.t
+        assert x.data_ptr() == buf.data_ptr() and emb.data_ptr() == buf[:, x.shape[1]:].data_ptr() and buf.shape[1] == x.shape[1] + emb.shape[1]
+        ctx.c0 = x.shape[1]
+        return buf.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :ctx.c0], g[:, ctx.c0:], None
 
 
 class AddVecFn(torch.autograd.Function):

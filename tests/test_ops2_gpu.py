@@ -268,3 +268,55 @@ def test_attn_tokens_grouped_equals_single_launches():
     outs = ops.attn_tokens_packed_grouped(qkvs, heads, 0.125)
     for q, o in zip(qkvs, outs):
         assert torch.equal(o, ops.attn_tokens_packed(q, heads, 0.125))
+
+
+def test_smm_xattn_grouped_equals_single_launches():
+    """idiff_smm_xattn_grouped_fwd: the four levels of a net (72-row compact memories at two key counts -- the wave-per-key-block form
+    and, below 4 key blocks per split, the channel-split form --, a 136-row and a 256-row memory) in one attention + one merge launch
+    give the bits of the four single calls."""
+    torch.manual_seed(3)
+    B, K, heads = 3, 5, 4
+    shapes = [(72, 16384), (72, 1024), (136, 1024), (256, 256), (72, 96)]
+    qfs = [torch.randn(B, K, heads, Cm, device=DEV) * 0.3 for Cm, _ in shapes]
+    mems = [torch.randn(B, Cm, N, device=DEV) for Cm, N in shapes]
+    single = [ops.smm_xattn(q, m, 0.125) for q, m in zip(qfs, mems)]
+    grouped = ops.smm_xattn_grouped(qfs, mems, 0.125)
+    for s, g in zip(single, grouped):
+        assert torch.equal(s, g)
+
+
+def test_scoremap_and_memproj_grouped_equal_single_launches():
+    torch.manual_seed(4)
+    B, K = 2, 5
+    feats = [torch.randn(B, 64, 32, 32, device=DEV), torch.randn(B, 64, 16, 16, device=DEV), torch.randn(B, 128, 8, 8, device=DEV)]
+    feats[1] = torch.randn(B, 80, 16, 16, device=DEV)[:, :64]  # a channel slice of a bigger buffer (the skip buffer)
+    tvs = [torch.randn(B, K, f.shape[1], device=DEV) for f in feats]
+    idx = torch.tensor([3, 0], dtype=torch.int32, device=DEV)
+    single = [ops.scoremap(f, tv, idx) for f, tv in zip(feats, tvs)]
+    grouped = ops.scoremap_grouped(feats, tvs, idx)
+    for (s0, s1), (g0, g1) in zip(single, grouped):
+        assert torch.equal(s0, g0) and torch.equal(s1, g1)
+    items = []
+    for f in feats[:2]:
+        C = f.shape[1]
+        W = torch.randn(256, C, device=DEV) * 0.1
+        bvec = torch.randn(256, device=DEV) * 0.1
+        gram, hvec, evar = ops.memory_variance_form(W, bvec)
+        items.append(dict(feat=f, ln1_g=torch.rand(C, device=DEV) + 0.5, ln1_b=torch.randn(C, device=DEV) * 0.1, gram=gram, hvec=hvec, evar=evar, Cm=72))
+    single = [ops.smm_memproj_compact(it["feat"], it["ln1_g"], it["ln1_b"], it["gram"], it["hvec"], it["evar"], it["Cm"]) for it in items]
+    grouped = ops.smm_memproj_compact_grouped(items)
+    for s, g in zip(single, grouped):
+        assert torch.equal(s, g)
+
+
+def test_time_mlp_equals_the_three_launch_chain():
+    torch.manual_seed(5)
+    B, dim, hid = 5, 64, 256
+    t = torch.tensor([1000., 3., 517., 1., 64.], device=DEV)
+    half = dim // 2
+    freqs = torch.exp(torch.arange(half, dtype=torch.float32, device=DEV) * (-math.log(10000.0) / (half - 1)))
+    w0, b0 = torch.randn(hid, dim, device=DEV) * 0.1, torch.randn(hid, device=DEV) * 0.1
+    w2, b2 = torch.randn(hid, hid, device=DEV) * 0.1, torch.randn(hid, device=DEV) * 0.1
+    chain = ops.linear(ops.linear(ops.time_embed(t, dim, freqs), w0, b0, act_out=ops.ACT_GELU), w2, b2)
+    fused = ops.time_mlp(t, freqs, w0, b0, w2, b2)
+    assert torch.equal(chain, fused), float((chain - fused).abs().max())

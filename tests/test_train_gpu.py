@@ -655,3 +655,84 @@ def test_scaled_decoder_scoremap_module_gradients_vs_fp64_oracle(C, H):
         assert e < 1e-3, (k, e)
         seen += "gamma_" in k
     assert seen == 6
+
+
+def test_fork_sums_the_consumers_gradients_in_one_launch_and_skipcat_shares_a_buffer():
+    """train_ops.fork / SkipCatFn (r05): a feature map with several consumers hands out aliases, the consumers' gradients -- one of them
+    a channel slice of a bigger tensor -- meet in idiff_sum_n; a skip cat(x, emb) whose two producers wrote into one buffer is handed
+    out without a copy and routes the gradient slices back.  Against torch autograd of the same graph on the CPU."""
+    g = _g(31)
+    B, C, Ce, H, W = 3, 8, 4, 8, 12
+    a = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(B, C + Ce, H, W, generator=g)
+    ad = _leaf(a)
+    buf = torch.empty(B, C + Ce, H, W, device=DEV)
+    x = T.AddFn.apply(ad, ad, 1.0)                       # 2a (a library Function output)
+    buf[:, :C].copy_(x.detach())
+    xs = T.ForkFn.apply(x, 3)
+    e = T.AddFn.apply(xs[1][:, :Ce].contiguous(), xs[1][:, :Ce].contiguous(), 0.5)   # 1.5 * x[:, :Ce]
+    buf[:, C:].copy_(e.detach())
+
+    class _Alias(torch.autograd.Function):               # stands in for a producer that wrote into its slice of buf
+        @staticmethod
+        def forward(ctx, t, slot):
+            return slot.t
+
+        @staticmethod
+        def backward(ctx, gr):
+            return gr, None
+    skip = T.SkipCatFn.apply(_Alias.apply(xs[2], T._Slot(buf[:, :C].detach())), _Alias.apply(e, T._Slot(buf[:, C:].detach())), T._Slot(buf))
+    wd = w.to(DEV)
+    loss = (skip * wd).sum() + (xs[0] * xs[0]).sum()
+    loss.backward()
+    ar = a.clone().requires_grad_(True)
+    xr = 2 * ar
+    er = 1.5 * xr[:, :Ce]
+    ((torch.cat([xr, er], 1) * w).sum() + (xr * xr).sum()).backward()
+    assert _rel(ad.grad, ar.grad) < 1e-6
+    # sum_n: 2..4 operands, one of them batch-strided
+    ts = [torch.randn(B, C, H, W, generator=g).to(DEV) for _ in range(3)] + [torch.randn(B, C + 4, H, W, generator=g).to(DEV)[:, 4:]]
+    for n in (2, 3, 4):
+        ref = ts[-1].clone()
+        for t in ts[:n - 1]:
+            ref = ref + t
+        assert _rel(T.sum_n([ts[-1]] + ts[:n - 1]), ref) < 1e-6
+
+
+def test_token_side_fused_functions_vs_torch_autograd():
+    """HeadFoldFn (per-head k / v folds with the head dimension in the GEMM strides), Linear3Fn (packed q | k | v projection) and
+    TokenAttnFn (few-token self-attention, one fused backward launch) against torch autograd of the plain formulas in fp64."""
+    g = _g(41)
+    B, K, heads, Wd = 3, 5, 4, 256
+    dh, R = Wd // heads, B * K
+    # HeadFoldFn
+    for fold in ("in", "out"):
+        x = torch.randn(R, Wd if fold == "in" else heads * Wd, generator=g) * 0.5
+        w = torch.randn(Wd, Wd, generator=g) * 0.1
+        xd, wd = _leaf(x), _leaf(w)
+        y = T.HeadFoldFn.apply(xd if fold == "in" else xd.reshape(R, heads, Wd), wd, heads, fold)
+        up = torch.randn(y.shape, generator=g)
+        (y * up.to(DEV)).sum().backward()
+        xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+        if fold == "in":
+            yr = torch.einsum("rhd,hdn->rhn", xr.reshape(R, heads, dh), wr.reshape(heads, dh, Wd))
+        else:
+            yr = torch.einsum("rhn,hdn->rhd", xr.reshape(R, heads, Wd), wr.reshape(heads, dh, Wd)).reshape(R, Wd)
+        (yr * up.double()).sum().backward()
+        assert _rel(y, yr) < 2e-6 and _rel(xd.grad, xr.grad.reshape(x.shape)) < 2e-6 and _rel(wd.grad, wr.grad) < 2e-6, fold
+    # Linear3Fn + TokenAttnFn
+    x = torch.randn(R, Wd, generator=g)
+    ws = [torch.randn(Wd, Wd, generator=g) * 0.08 for _ in range(3)]
+    xd, wds = _leaf(x), [_leaf(w) for w in ws]
+    qkv = T.Linear3Fn.apply(xd, *wds)
+    a = T.TokenAttnFn.apply(qkv, B, K, heads, dh ** -0.5)
+    up = torch.randn(R, Wd, generator=g)
+    (a * up.to(DEV)).sum().backward()
+    xr, wrs = x.double().requires_grad_(True), [w.double().requires_grad_(True) for w in ws]
+    q, k, v = [(xr @ w.t()).reshape(B, K, heads, dh).permute(0, 2, 1, 3) for w in wrs]
+    p = torch.softmax(q @ k.transpose(-1, -2) * dh ** -0.5, dim=-1)
+    ar = (p @ v).permute(0, 2, 1, 3).reshape(R, Wd)
+    (ar * up.double()).sum().backward()
+    assert _rel(a, ar) < 3e-6 and _rel(xd.grad, xr.grad) < 1e-5
+    for wd_, wr_ in zip(wds, wrs):
+        assert _rel(wd_.grad, wr_.grad) < 1e-5
