@@ -229,7 +229,7 @@ int idiff_smm_memproj_fwd(const float* feat, int64_t feat_bstride, const float* 
  * idiff_smm_xattn_fwd streams (C+1)/256 of the bytes.  The variance itself is evaluated as the quadratic form
  * var = xhat^T G xhat + 2 h.xhat + e with  gram = Wc^T Wc / 256  [C][C],  hvec = Wc^T bc / 256  [C],  evar = |bc|^2 / 256
  * (host-prepared in fp64): a C -> C product instead of C -> 256.  Same arithmetic as idiff_smm_memproj_fwd up to fp32
- * rounding.  C % 32 == 0. */
+ * rounding.  C = 64 or 128 (a thread holds C / 4 channels of its pixel in registers). */
 int idiff_smm_memproj_compact_fwd(const float* feat, int64_t feat_bstride, const float* ln1_g, const float* ln1_b,
                                   const float* gram, const float* hvec, float evar, float* out, int B, int C, int N, int Cm,
                                   float eps1, float eps2, idiff_stream_t stream);

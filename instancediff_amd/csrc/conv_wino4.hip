@@ -892,6 +892,9 @@ long long conv_wino4_items(const ConvArgs& a, int ks, int mode, bool requested) 
     if (mode != IDIFF_CONV_NORMAL && mode != IDIFF_CONV_UPSAMPLE2) return 0;
     if (a.Cout % 16 || a.Cin % 8 || a.C0v % CK || (a.Hout & 3) || (a.Wout & 3) || a.Wout < 24) return 0;
     if ((long long)a.Cin * a.Hin * a.Win * 4 >= (1ll << 31)) return 0;  // 32-bit byte offsets inside a sample
+    // ... and inside the weight image: both F(4x4,3x3) kernels address a chunk of it as chunk * ncob * U_FLOATS * 4 (+ up to 36 KB) in
+    // 32-bit scalar offsets (dma_u / dma_u_piece here, the rolling A-operand window of conv_wino4h.hip): 144 bytes per (ci, co) pair
+    if (144ll * a.Cin * a.ncob * 64 + U_FLOATS * 4 >= (1ll << 31)) return 0;
     if (mode == IDIFF_CONV_UPSAMPLE2 && (a.pro_a || a.src1)) return 0;
     if (a.pro_a && a.src1) return 0;
     if (a.pro_a && ((a.C0r & 3) || (reinterpret_cast<uintptr_t>(a.pro_a) & 15) || (reinterpret_cast<uintptr_t>(a.pro_b) & 15))) return 0;  // s_load_dwordx4

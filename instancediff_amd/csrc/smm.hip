@@ -160,57 +160,78 @@ __global__ __launch_bounds__(256) void smm_memproj_kernel(const float* __restric
 // on the matrix cores instead of C -> 256 (4x fewer flops at C = 64), which leaves the kernel bandwidth-bound.
 // One workgroup = 64 pixels; 32 x 32 output tiles of y = G xhat are dealt to the 4 waves; sum_c' xhat[c'] (y[c'] + 2 h[c'])
 // is reduced over a lane's 16 rows, the two half-waves and the tiles through LDS.
+// r05 form: the pixel's channels of a wave live in REGISTERS (thread = pixel x channel quarter: channels wave, wave + 4, ..): the tile
+// is requested with all its loads in flight at the top of the kernel and never staged raw -- LDS only carries the 4-way partial sums
+// of the two LayerNorm passes, the normalised tile (the B operand of the quadratic form) and the per-pixel rstd; the output rows
+// leave from the same registers.  The Gram operand of a wave's first 32 x 32 tile is requested before the tile itself (it depends on
+// nothing).  Same operations in the same order per pixel as the r01-r04 form (LDS-staged tile, three walks over it): the same bits.
+template <int CJ>  // channels per thread = C / 4 (16: C = 64, 32: C = 128)
 __device__ __forceinline__ void smm_memproj_gram_body(const float* __restrict__ feat, long long fbs, const float* __restrict__ g1,
                                                       const float* __restrict__ b1, const float* __restrict__ gram,
-                                                      const float* __restrict__ hvec, float evar, float* __restrict__ out, int C, int N, int Cm,
+                                                      const float* __restrict__ hvec, float evar, float* __restrict__ out, int N, int Cm,
                                                       float eps1, float eps2, const int b, const int bx) {
+    constexpr int C = 4 * CJ;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xt = smem;                 // [C][64]
-    float* part = smem + C * MP_PX;   // [8][64]
+    float* xt = smem;                 // [C][64] normalised tile
+    float* part = smem + C * MP_PX;   // [5][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int p0 = bx * MP_PX;
-    const float* fb = feat + (long long)b * fbs;
-    const int nf4 = C * (MP_PX / 4);
-    for (int f = tid; f < nf4; f += 256) {
-        const int c = f >> 4, j4 = (f & 15) * 4;
-        floatx4 v = {0.f, 0.f, 0.f, 0.f};
-        if (p0 + j4 + 3 < N)
-            v = *reinterpret_cast<const floatx4*>(fb + (long long)c * N + p0 + j4);
-        else
-            for (int e = 0; e < 4; ++e)
-                if (p0 + j4 + e < N) v[e] = fb[(long long)c * N + p0 + j4 + e];
-        *reinterpret_cast<floatx4*>(xt + c * MP_PX + j4) = v;
+    const int p = p0 + lane;
+    const bool ok = p < N;
+    const float* fb = feat + (long long)b * fbs + (ok ? p : 0);
+    // the wave's first tile of y = G xhat: (m, n) = (wave % mt, wave / mt); its A operand (Gram rows) travels in registers
+    constexpr int mt = C / 32, ntiles = mt * 2;
+    constexpr bool PRE = CJ == 16;  // (C = 128: 64 more registers would halve the occupancy of a bandwidth-bound kernel)
+    float ga[PRE ? C / 2 : 1];
+    if (PRE) {
+        const int m = wave % mt;
+        const float* wl = gram + (long long)half * C + m * 32 + l31;
+#pragma unroll
+        for (int st = 0; st < C / 2; ++st) ga[st] = wl[(long long)(2 * st) * C];
     }
-    __syncthreads();
+    float x[CJ];
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) x[j] = ok ? fb[(long long)(wave + 4 * j) * N] : 0.f;
     // ---- LayerNorm over C per pixel (two-pass; wave q covers channels q, q+4, ...; lane = pixel) ------------------
     float s = 0.f;
-    for (int c = wave; c < C; c += 4) s += xt[c * MP_PX + lane];
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) s += x[j];
     part[wave * MP_PX + lane] = s;
     __syncthreads();
     const float mean1 = (part[lane] + part[MP_PX + lane] + part[2 * MP_PX + lane] + part[3 * MP_PX + lane]) / (float)C;
     __syncthreads();
     float q = 0.f;
-    for (int c = wave; c < C; c += 4) {
-        const float d = xt[c * MP_PX + lane] - mean1;
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) {
+        const float d = x[j] - mean1;
         q += d * d;
     }
     part[wave * MP_PX + lane] = q;
     __syncthreads();
     const float rstd1 = rsqrtf((part[lane] + part[MP_PX + lane] + part[2 * MP_PX + lane] + part[3 * MP_PX + lane]) / (float)C + eps1);
-    __syncthreads();
-    for (int c = wave; c < C; c += 4) xt[c * MP_PX + lane] = (xt[c * MP_PX + lane] - mean1) * rstd1 * g1[c] + b1[c];
-    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) {
+        const int c = wave + 4 * j;
+        x[j] = (x[j] - mean1) * rstd1 * g1[c] + b1[c];
+        xt[c * MP_PX + lane] = x[j];
+    }
+    __syncthreads();  // (also: every wave has read the second-pass partials before they are overwritten below)
     // ---- quadratic form: tiles (m: 32 rows c', n: 32 pixels) of y = G xhat, folded with xhat on the spot -----------
-    const int mt = C / 32, ntiles = mt * 2;
     float pv[2] = {0.f, 0.f};  // per pixel block n
     for (int t = wave; t < ntiles; t += 4) {
         const int m = t % mt, n = t / mt;
         floatx16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float* wl = gram + (long long)half * C + m * 32 + l31;
         const float* xl = xt + half * MP_PX + n * 32 + l31;
-        for (int st = 0; st < C / 2; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(long long)(2 * st) * C], xl[2 * st * MP_PX], acc, 0, 0, 0);
+        if (PRE && t == wave) {
+#pragma unroll
+            for (int st = 0; st < C / 2; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[PRE ? st : 0], xl[2 * st * MP_PX], acc, 0, 0, 0);
+        } else {
+            const float* wl = gram + (long long)half * C + m * 32 + l31;
+#pragma unroll 8
+            for (int st = 0; st < C / 2; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[(long long)(2 * st) * C], xl[2 * st * MP_PX], acc, 0, 0, 0);
+        }
         float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -225,33 +246,20 @@ __device__ __forceinline__ void smm_memproj_gram_body(const float* __restrict__ 
         if (half == 0) part[wave * MP_PX + n * 32 + l31] = pv[n];
     }
     __syncthreads();
-    float* rs = part + 4 * MP_PX;  // [64] rstd per pixel
-    if (tid < MP_PX) rs[tid] = rsqrtf(part[tid] + part[MP_PX + tid] + part[2 * MP_PX + tid] + part[3 * MP_PX + tid] + evar + eps2);
-    __syncthreads();
-    float* ob = out + (long long)b * Cm * N;
-    const int nf = Cm * (MP_PX / 4);
-    for (int f = tid; f < nf; f += 256) {
-        const int c = f >> 4, j4 = (f & 15) * 4;
-        floatx4 v = {0.f, 0.f, 0.f, 0.f};
-        const floatx4 r4 = *reinterpret_cast<const floatx4*>(rs + j4);
-        if (c < C) {
-            const floatx4 x4 = *reinterpret_cast<const floatx4*>(xt + c * MP_PX + j4);
-            v = floatx4{x4.x * r4.x, x4.y * r4.y, x4.z * r4.z, x4.w * r4.w};
-        } else if (c == C) {
-            v = r4;
-        }
-        if (p0 + j4 + 3 < N)
-            *reinterpret_cast<floatx4*>(ob + (long long)c * N + p0 + j4) = v;
-        else
-            for (int e = 0; e < 4; ++e)
-                if (p0 + j4 + e < N) ob[(long long)c * N + p0 + j4 + e] = v[e];
+    const float r2 = rsqrtf(part[lane] + part[MP_PX + lane] + part[2 * MP_PX + lane] + part[3 * MP_PX + lane] + evar + eps2);
+    if (ok) {
+        float* ob = out + (long long)b * Cm * N + p;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) ob[(long long)(wave + 4 * j) * N] = x[j] * r2;
+        for (int c = C + wave; c < Cm; c += 4) ob[(long long)c * N] = c == C ? r2 : 0.f;
     }
 }
+template <int CJ>
 __global__ __launch_bounds__(256) void smm_memproj_gram_kernel(const float* __restrict__ feat, long long fbs, const float* __restrict__ g1,
                                                                const float* __restrict__ b1, const float* __restrict__ gram,
-                                                               const float* __restrict__ hvec, float evar, float* __restrict__ out, int C,
+                                                               const float* __restrict__ hvec, float evar, float* __restrict__ out,
                                                                int N, int Cm, float eps1, float eps2) {
-    smm_memproj_gram_body(feat, fbs, g1, b1, gram, hvec, evar, out, C, N, Cm, eps1, eps2, blockIdx.y, blockIdx.x);
+    smm_memproj_gram_body<CJ>(feat, fbs, g1, b1, gram, hvec, evar, out, N, Cm, eps1, eps2, blockIdx.y, blockIdx.x);
 }
 // Grouped launch (idiff_smm_memproj_compact_grouped_fwd): the compact memories of several ScoreMapModules in ONE launch; blockIdx.z
 // picks the level, blocks beyond a smaller level's pixels exit.  Same body, same bits.  The LDS of the launch is that of the widest
@@ -259,10 +267,11 @@ __global__ __launch_bounds__(256) void smm_memproj_gram_kernel(const float* __re
 struct MemprojGroups {
     idiff_memproj_group g[IDIFF_MEMPROJ_MAX_GROUPS];
 };
+template <int CJ>
 __global__ __launch_bounds__(256) void smm_memproj_gram_grouped_kernel(const MemprojGroups args, float eps1, float eps2) {
     const idiff_memproj_group& d = args.g[blockIdx.z];
     if ((int)blockIdx.x * MP_PX >= d.N) return;  // uniform
-    smm_memproj_gram_body(d.feat, d.feat_bstride, d.ln1_g, d.ln1_b, d.gram, d.hvec, d.evar, d.out, d.C, d.N, d.Cm, eps1, eps2, blockIdx.y, blockIdx.x);
+    smm_memproj_gram_body<CJ>(d.feat, d.feat_bstride, d.ln1_g, d.ln1_b, d.gram, d.hvec, d.evar, d.out, d.N, d.Cm, eps1, eps2, blockIdx.y, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -534,18 +543,17 @@ extern "C" int idiff_smm_memproj_compact_fwd(const float* feat, int64_t feat_bst
                                              const float* hvec, float evar, float* out, int B, int C, int N, int Cm, float eps1, float eps2,
                                              idiff_stream_t stream) {
     IDIFF_CHECK_ARG(feat && ln1_g && ln1_b && gram && hvec && out, "smm_memproj_compact: null pointer");
-    IDIFF_CHECK_ARG(B > 0 && N > 0 && C >= 32 && C % 32 == 0 && C <= 512, "smm_memproj_compact: C must be a multiple of 32, <= 512 (got %d)", C);
+    IDIFF_CHECK_ARG(B > 0 && N > 0 && (C == 64 || C == 128), "smm_memproj_compact: C must be 64 or 128 (got %d)", C);
     IDIFF_CHECK_ARG(N % 4 == 0 && feat_bstride % 4 == 0, "smm_memproj_compact: N and feat_bstride must be multiples of 4");
     IDIFF_CHECK_ARG(Cm > C, "smm_memproj_compact: Cm must exceed C (got %d, C = %d)", Cm, C);
-    const size_t lds = (size_t)(C * MP_PX + 5 * MP_PX) * sizeof(float);
-    static size_t attr = 0;
-    if (lds > attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(smm_memproj_gram_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "smm_memproj_compact: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr = lds;
-    }
-    hipLaunchKernelGGL(smm_memproj_gram_kernel, dim3((N + MP_PX - 1) / MP_PX, B), dim3(256), lds, (hipStream_t)stream, feat, (long long)feat_bstride,
-                       ln1_g, ln1_b, gram, hvec, evar, out, C, N, Cm, eps1, eps2);
+    const size_t lds = (size_t)(C * MP_PX + 5 * MP_PX) * sizeof(float);  // <= 34 KB: no attribute needed
+    const dim3 grid((N + MP_PX - 1) / MP_PX, B);
+    if (C == 64)
+        hipLaunchKernelGGL(smm_memproj_gram_kernel<16>, grid, dim3(256), lds, (hipStream_t)stream, feat, (long long)feat_bstride, ln1_g, ln1_b, gram,
+                           hvec, evar, out, N, Cm, eps1, eps2);
+    else
+        hipLaunchKernelGGL(smm_memproj_gram_kernel<32>, grid, dim3(256), lds, (hipStream_t)stream, feat, (long long)feat_bstride, ln1_g, ln1_b, gram,
+                           hvec, evar, out, N, Cm, eps1, eps2);
     IDIFF_CHECK_LAUNCH("smm_memproj_compact_fwd");
     return IDIFF_OK;
 }
@@ -559,20 +567,16 @@ extern "C" int idiff_smm_memproj_compact_grouped_fwd(const idiff_memproj_group* 
     for (int i = 0; i < ngroups; ++i) {
         const idiff_memproj_group& d = groups[i];
         IDIFF_CHECK_ARG(d.feat && d.ln1_g && d.ln1_b && d.gram && d.hvec && d.out, "smm_memproj_compact_grouped: group %d: null pointer", i);
-        IDIFF_CHECK_ARG(d.N > 0 && d.C >= 32 && d.C % 32 == 0 && d.C <= 512 && d.N % 4 == 0 && d.feat_bstride % 4 == 0 && d.Cm > d.C,
+        IDIFF_CHECK_ARG(d.N > 0 && (d.C == 64 || d.C == 128) && d.N % 4 == 0 && d.feat_bstride % 4 == 0 && d.Cm > d.C,
                         "smm_memproj_compact_grouped: group %d: bad shape (C %d, N %d, Cm %d)", i, d.C, d.N, d.Cm);
         args.g[i] = d;
         gx = max(gx, (d.N + MP_PX - 1) / MP_PX);
         cmax = max(cmax, d.C);
     }
-    const size_t lds = (size_t)(cmax * MP_PX + 5 * MP_PX) * sizeof(float);
-    static size_t attr = 0;
-    if (lds > attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(smm_memproj_gram_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "smm_memproj_compact_grouped: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr = lds;
-    }
-    hipLaunchKernelGGL(smm_memproj_gram_grouped_kernel, dim3(gx, B, ngroups), dim3(256), lds, (hipStream_t)stream, args, eps1, eps2);
+    for (int i = 0; i < ngroups; ++i) IDIFF_CHECK_ARG(groups[i].C == cmax, "smm_memproj_compact_grouped: the groups of a launch share their channel count (%d vs %d)", groups[i].C, cmax);
+    const size_t lds = (size_t)(cmax * MP_PX + 5 * MP_PX) * sizeof(float);  // <= 34 KB: no attribute needed
+    if (cmax == 64) hipLaunchKernelGGL(smm_memproj_gram_grouped_kernel<16>, dim3(gx, B, ngroups), dim3(256), lds, (hipStream_t)stream, args, eps1, eps2);
+    else hipLaunchKernelGGL(smm_memproj_gram_grouped_kernel<32>, dim3(gx, B, ngroups), dim3(256), lds, (hipStream_t)stream, args, eps1, eps2);
     IDIFF_CHECK_LAUNCH("smm_memproj_compact_grouped_fwd");
     return IDIFF_OK;
 }

@@ -135,23 +135,16 @@ class driftSDE:
         s1.wait_stream(main)
         s2.wait_stream(main)
         from ..modules import MSM_degEmb_Unet as _U
-        if _U.SMM_SIDE:
-            # (experiment) each net's ScoreMapModule side stream enters here, as a FIRST-level fork of the origin stream: a stream that
-            # joins a HIP-graph capture by waiting on an event of an already forked stream (a fork of a fork) crashed
-            # hipStreamEndCapture on ROCm 7.2 (profiles/r05/x_side_stream_capture.txt)
-            for net in (self.drift_net, self.noise_net):
-                if getattr(net, "_side_stream", None) is None:
-                    net._side_stream = torch.cuda.Stream()
-                net._side_stream.wait_stream(main)
         with torch.cuda.stream(s1):
             r_hat = self._pred(self.drift_net, xa, cond, tdev, names, text_encoder, image_context)
         with torch.cuda.stream(s2):
             e_hat = self._pred(self.noise_net, xa, x, tdev, names, text_encoder, image_context)
         main.wait_stream(s1)
         main.wait_stream(s2)
-        if _U.SMM_SIDE:
+        if _U.SMM_SIDE:  # (experiment) a net's decoder ran on its side stream, which only the origin may join (MSM_degEmb_Unet.SMM_SIDE)
             for net in (self.drift_net, self.noise_net):
-                main.wait_stream(net._side_stream)  # (already joined into s1 / s2 by the net; this makes the origin's join explicit)
+                if getattr(net, "_side_stream", None) is not None:
+                    main.wait_stream(net._side_stream)
         r_hat.record_stream(main)
         e_hat.record_stream(main)
         return r_hat, e_hat

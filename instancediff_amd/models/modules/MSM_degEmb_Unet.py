@@ -71,10 +71,12 @@ class _Prepared:
 _PREP = _Prepared()
 
 # IDIFF_SMM_SIDE=1 (experiment, off by default): each net's ScoreMapModule phase -- which only feeds the skip connections
-# the decoder reads later -- on a stream of its own beside the net's mid blocks.  Fork / join discipline under HIP-graph capture: the
-# side stream enters the capture by waiting on an event the net's stream records INSIDE the capture (side.wait_stream(cur)) and is
-# joined back (cur.wait_stream(side)) before the decoder's first ResBlock, i.e. before the net's stream is itself joined into the
-# capture's origin stream; tensors the side stream allocates and the net's stream consumes are record_stream()ed.
+# the decoder reads later -- on a stream of its own beside the net's mid blocks.  Capture rule found in r05
+# (scripts/proto/capture_fork_probe.py, profiles/r05/x_capture_fork_probe.txt): under HIP-graph capture on ROCm 7.2 a forked stream may
+# WAIT on another forked stream, but must itself be joined by the capture's ORIGIN stream -- a forked stream that waits on a stream
+# forked later than itself (the "join the side stream back into the net's stream" shape) crashes hipStreamEndCapture.  So the side
+# stream is never joined back: it waits for the net's mid blocks and the DECODER continues on it; driftSDE.predict() joins both the
+# net's stream and its side stream into the origin.
 SMM_SIDE = bool(int(os.environ.get("IDIFF_SMM_SIDE", "0")))
 # IDIFF_GROUPED_SMM=0 (A/B runs): the per-level launches of r04 for the memory projection, the cross-attention (+ merge) and the score map
 GROUPED_SMM = bool(int(os.environ.get("IDIFF_GROUPED_SMM", "1")))
@@ -316,7 +318,7 @@ def decoder_tokens_grouped(smms, feats, texts, cache_prefix=True, plain_out=Fals
         # Narrow feature maps: LN_256(W.xhat + b) = g2 * ((Wc.xhat + bc) * rstd) + b2 is an affine image of the (C+1)-vector
         # m = [xhat*rstd ; rstd], so the cross-attention streams m (Cm = 72 / 136 rows) instead of the 256-row memory and
         # g2.[Wc|bc] is folded into its query / value projections (b2 drops out of the softmax and returns as a bias).
-        Cm = Wd if C + 1 > 136 else (72 if C + 1 <= 72 else 136)
+        Cm = Wd if (C + 1 > 136 or C not in (64, 128)) else (72 if C + 1 <= 72 else 136)  # the compact kernel holds C / 4 channels per thread
         compact = Cm < Wd
         mem = None
         if compact:
@@ -799,7 +801,18 @@ class LearnableForwardUNet_MultiScoreMap(nn.Module):
             x = self.mid_ca.run(x, ctx)
         x = self.mid_res2.run(x, None, films[id(self.mid_res2)])
         if side is not None:
-            cur.wait_stream(side)                # join: the skips carry the score-map embeddings from here on
+            side.wait_stream(cur)                # the side stream (skips filled) waits for the mid blocks and carries on with the decoder
+            for t in [x, x_] + hs:
+                t.record_stream(side)
+            with torch.cuda.stream(side):
+                pred = self._decode(x, x_, hs, films, vecs if single else None, general, ctx, idx)
+            pred.record_stream(cur)
+            return (pred, sms) if self.text_module == "scoremap" else pred
+        return self._decode(x, x_, hs, films, vecs if single else None, general, ctx, idx, sms if self.text_module == "scoremap" else None)
+
+    def _decode(self, x, x_, hs, films, vecs, general, ctx, idx, sms=None):
+        def ca_vec(ca_name, holder):
+            return vecs[id(getattr(holder, ca_name))] if vecs is not None else None
         for up in self.ups:
             x = up.res1.run(x, hs.pop(), films[id(up.res1)], vec=ca_vec("ca1", up))
             if general:
@@ -811,6 +824,6 @@ class LearnableForwardUNet_MultiScoreMap(nn.Module):
         x = self.final_res.run(x, x_, films[id(self.final_res)])
         # final 3x3 conv to out_nc channels + per-sample class pick, computed as ONE channel per sample
         pred = ops.conv3x3_select(x, self.final_conv.weight.detach(), self.final_conv.bias, idx)
-        if self.text_module == "scoremap":
+        if self.text_module == "scoremap" and sms is not None:
             return pred, sms
         return pred

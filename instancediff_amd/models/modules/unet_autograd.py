@@ -159,7 +159,8 @@ def _smm(smm, feat, text_encoder, idx, feat_n=None):
     tvn = ChanNormalizeFn.apply(tv.reshape(R, C, 1)).reshape(B, K, C)
     fnm = ChanNormalizeFn.apply(feat_n).reshape(B, C, N)
     score = BgemmFn.apply(tvn, fnm, False, False).reshape(B, K, H, W)
-    sel = GatherChannelFn.apply(score, idx)
+    score, score_g = fork(score, 2)  # the embedding conv of the skip and the class pick of the pyramid loss
+    sel = GatherChannelFn.apply(score_g, idx)
     return score, sel
 
 

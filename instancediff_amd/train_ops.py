@@ -868,14 +868,24 @@ class FusedAdam(torch.optim.Optimizer):
         return [f['g'] for f in self._flat if f is not None]
 
     def zero_grad(self, set_to_none=True):
-        """p.grad = None for every parameter: autograd's AccumulateGrad then TAKES the gradient tensor a backward produces (no
-        `grad += g` launch per parameter, no zero-fill of the flat buffer); _collect() moves them into the flat buffer in ONE launch
-        (a parameter that received no gradient gets zeros) and re-binds p.grad to its view of the flat buffer."""
+        """set_to_none=True (default): p.grad = None for every parameter: autograd's AccumulateGrad then TAKES the gradient tensor a
+        backward produces (no `grad += g` launch per parameter, no zero-fill of the flat buffer); _collect() moves them into the flat
+        buffer in ONE launch (a parameter that received no gradient gets zeros) and re-binds p.grad to its view of the flat buffer.
+        set_to_none=False: torch.optim semantics -- the flat buffer is zero-filled and every p.grad is (re-)bound to its view of it, so
+        a backward ACCUMULATES into it."""
         for f in self._flat:
             if f is None:
                 continue
-            for p in f['params']:
-                p.grad = None
+            if set_to_none:
+                for p in f['params']:
+                    p.grad = None
+            else:
+                f['g'].zero_()
+                o = 0
+                for p in f['params']:
+                    n = p.numel()
+                    p.grad = f['g'][o:o + n].view_as(p)
+                    o += n
 
     @torch.no_grad()
     def _collect(self):
@@ -910,13 +920,26 @@ class FusedAdam(torch.optim.Optimizer):
                         f['g'][o:o + n].copy_(p.grad.reshape(-1))
                     o += n
             else:
-                tab = np.zeros((len(recs), 4), dtype=np.int64)
+                # The segment table goes up from a persistent PINNED staging buffer with a non-blocking copy: a pageable-memory copy
+                # is synchronous for the host, and this point sits right behind the waits on both backward streams -- the host would
+                # stall until the whole backward has drained, once per optimizer per iteration (r04 ADVICE).  The staging buffer may
+                # be overwritten by the next collect only after this copy has run: an event guards it.
+                nrec = len(recs)
+                st = f.get('_stage')
+                if st is None or st[0].shape[0] < nrec:
+                    st = f['_stage'] = (torch.empty((nrec, 4), dtype=torch.int64, pin_memory=True),
+                                        torch.empty((nrec, 4), dtype=torch.int64, device=f['g'].device), torch.cuda.Event())
+                else:
+                    st[2].synchronize()  # (long past: one iteration ago)
+                tab = st[0].numpy()[:nrec]
                 tab[:, :3] = np.asarray(recs, dtype=np.int64)
                 nb = (tab[:, 2] + 4095) // 4096
                 tab[:, 3] = np.cumsum(nb) - nb
-                dev_tab = torch.from_numpy(tab).to(f['g'].device)
-                check(_lib.load().idiff_gather_segments(dev_tab.data_ptr(), len(recs), int(nb.sum()), _p(f['g']), _stream()), "gather_segments")
-                f['_keep'] = (dev_tab, [p.grad for p in f['params']])  # alive until the next collect: the launch is asynchronous
+                dev_tab = st[1][:nrec]
+                dev_tab.copy_(st[0][:nrec], non_blocking=True)
+                st[2].record()
+                check(_lib.load().idiff_gather_segments(dev_tab.data_ptr(), nrec, int(nb.sum()), _p(f['g']), _stream()), "gather_segments")
+                f['_keep'] = [p.grad for p in f['params']]  # the gathered tensors stay alive until the next collect: the launch is asynchronous
             o = 0
             for p in f['params']:
                 n = p.numel()

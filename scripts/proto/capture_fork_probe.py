@@ -6,12 +6,16 @@ take the others down -- and captures a few trivial kernels on streams forked fro
   cross_join_back  : + s1 then waits on s3 (s3 joins INTO s1, s1 joins the origin)               (the side-stream experiment's shape)
   nested           : s3 enters the capture only by waiting on s1 (a fork of a fork), joins s1
   nested_join_origin: s3 enters by waiting on s1, joins the origin directly
+  join_back_only   : s3 forks from the origin (no wait on s1); s1 waits on s3; the origin joins s1, s2 AND s3
+  cross_join_back_origin : cross_join_back + the origin also joins s3 directly
+  continue_on_side : s3 enters by waiting on s1, s1 works on, s3 waits on s1 AGAIN and carries on; the origin joins s1, s2, s3
+                     (the shape the side-stream experiment was rebuilt on)
     python scripts/proto/capture_fork_probe.py            # runs every case, prints one line each
     python scripts/proto/capture_fork_probe.py CASE       # one case in this process"""
 import subprocess
 import sys
 
-CASES = ["two_forks", "cross_one_way", "cross_join_back", "nested", "nested_join_origin"]
+CASES = ["two_forks", "cross_one_way", "cross_join_back", "nested", "nested_join_origin", "join_back_only", "cross_join_back_origin", "continue_on_side"]
 
 
 def run(case):
@@ -25,21 +29,26 @@ def run(case):
         with torch.cuda.graph(g, stream=origin, capture_error_mode="thread_local"):
             s1.wait_stream(origin)
             s2.wait_stream(origin)
-            if case in ("cross_one_way", "cross_join_back"):
+            if case in ("cross_one_way", "cross_join_back", "join_back_only", "cross_join_back_origin"):
                 s3.wait_stream(origin)
             with torch.cuda.stream(s1):
                 a.add_(1.0)
             with torch.cuda.stream(s2):
                 b.add_(1.0)
             if case != "two_forks":
-                s3.wait_stream(s1)
+                if case != "join_back_only":
+                    s3.wait_stream(s1)
                 with torch.cuda.stream(s3):
-                    c.add_(a)
+                    c.add_(a if case != "join_back_only" else 1.0)
                 with torch.cuda.stream(s1):
                     a.mul_(2.0)
-                if case in ("cross_join_back", "nested"):
+                if case in ("cross_join_back", "nested", "join_back_only", "cross_join_back_origin"):
                     s1.wait_stream(s3)
-                else:
+                if case == "continue_on_side":
+                    s3.wait_stream(s1)
+                    with torch.cuda.stream(s3):
+                        c.add_(a)
+                if case not in ("cross_join_back", "nested"):
                     origin.wait_stream(s3)
             origin.wait_stream(s1)
             origin.wait_stream(s2)

@@ -4,7 +4,7 @@ set -u
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=${1:-gpurun_out/train_prof}; B=${2:-32}; mkdir -p $O
 python3 bench.py --mode train --batch $B --steps 4 --warmup 2 > $O/bench_train.json 2> $O/bench_train.err; cat $O/bench_train.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --mode train --batch $B --steps 3 --warmup 2 > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --mode train --batch $B --steps 3 --warmup 2 --no-roofline > $O/stats.log 2>&1
 f=$(find $O/stats -name "*kernel_stats.csv" | head -1); cp "$f" $O/train_kernel_stats.csv; rm -rf $O/stats
 python3 - "$O/train_kernel_stats.csv" <<'PY'
 import csv, sys, re

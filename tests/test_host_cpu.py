@@ -414,6 +414,29 @@ def test_bench_train_mode_reaches_the_gradient_exchange_at_world_2(tmp_path):
     assert line["flat_gradient_floats"] > 60e6 and "dryrun" in line   # both nets' parameters in the flat buffers
 
 
+def test_fused_adam_zero_grad_honours_set_to_none():
+    """FusedAdam.zero_grad: set_to_none=True drops the per-parameter gradients (the backward's tensors are then taken as they are and
+    gathered in one launch); set_to_none=False is torch.optim's meaning -- zero-filled gradients that a backward accumulates into,
+    bound to the flat buffer.  (CPU: the host logic only.)"""
+    from instancediff_amd.train_ops import FusedAdam
+    net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    opt = FusedAdam(net.parameters(), lr=1e-3)
+    x = torch.randn(5, 4)
+    net(x).sum().backward()
+    g1 = [p.grad.clone() for p in net.parameters()]
+    opt.zero_grad()
+    assert all(p.grad is None for p in net.parameters())
+    opt.zero_grad(set_to_none=False)
+    flat = opt.flat_grads()[0]
+    assert all(p.grad is not None and float(p.grad.abs().sum()) == 0.0 for p in net.parameters())
+    assert next(net.parameters()).grad.data_ptr() == flat.data_ptr()
+    net(x).sum().backward()
+    net(x).sum().backward()          # accumulates
+    for p, g in zip(net.parameters(), g1):
+        assert torch.allclose(p.grad, 2 * g)
+    assert torch.allclose(opt.flat_grads()[0], torch.cat([2 * g.reshape(-1) for g in g1]))
+
+
 def test_bench_default_line_carries_the_training_exchange_at_world_2(tmp_path):
     """`python bench.py --gpus 2` -- the command the driver's scaling run issues -- must put the collective into ITS line: the default
     mode's N > 1 path runs BASELINE c3 across the ranks (train_leg_ranks) and reports it under "train" with the exchange measured for
