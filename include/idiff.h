@@ -233,6 +233,17 @@ int idiff_smm_memproj_fwd(const float* feat, int64_t feat_bstride, const float* 
 int idiff_smm_memproj_compact_fwd(const float* feat, int64_t feat_bstride, const float* ln1_g, const float* ln1_b,
                                   const float* gram, const float* hvec, float evar, float* out, int B, int C, int N, int Cm,
                                   float eps1, float eps2, idiff_stream_t stream);
+/* Training step (r05): the same projection with the quadratic form's constant read from device memory (it is a function of the
+ * weights, evaluated on the device every step), C = 64, and its backward.  Given dm [B, Cm, N] (rows 0..C carry gradient):
+ *   dfeat [B, C, N] (dfeat_bstride) and dparams [C*C + 3C + 1] = d gram (row-major) | d ln1_g | d ln1_b | d hvec | d evar.
+ * ws: idiff_smm_memproj_compact_bwd_ws_floats(B, C, N) floats (per-workgroup partial rows, reduced in a fixed order). */
+int idiff_smm_memproj_compact_train_fwd(const float* feat, int64_t feat_bstride, const float* ln1_g, const float* ln1_b, const float* gram,
+                                        const float* hvec, const float* evar_dev, float* out, int B, int C, int N, int Cm, float eps1,
+                                        float eps2, idiff_stream_t stream);
+int64_t idiff_smm_memproj_compact_bwd_ws_floats(int B, int C, int N);
+int idiff_smm_memproj_compact_bwd(const float* feat, int64_t feat_bstride, const float* ln1_g, const float* ln1_b, const float* gram,
+                                  const float* hvec, const float* evar_dev, const float* dm, float* dfeat, int64_t dfeat_bstride,
+                                  float* dparams, float* ws, int B, int C, int N, int Cm, float eps1, float eps2, idiff_stream_t stream);
 /* Several idiff_smm_memproj_compact_fwd problems (the ScoreMapModules of a net's levels) in ONE launch; same arithmetic per problem,
  * same bits.  The launch reserves the LDS of its widest problem: group levels of equal C. */
 #define IDIFF_MEMPROJ_MAX_GROUPS 4
@@ -253,7 +264,8 @@ int idiff_layernorm_rows_fwd(const float* x, int64_t ldx, const float* gamma, co
 int idiff_time_embed_fwd(const float* t, const float* freqs, int B, int dim, float* out, idiff_stream_t stream);
 /* The UNet's time-embedding MLP (frozen spec, DESIGN.md section 2: temb = Linear(GELU(Linear(sinusoidal_dim(t))))) in ONE launch:
  * out [B, nout] = w2 . GELU(w0 . [sin(t f) ; cos(t f)] + b0) + b2 with w0 [hid, dim], w2 [nout, hid] (torch layout), freqs [dim/2] or
- * NULL.  Bit-identical to idiff_time_embed_fwd -> idiff_linear_fwd(act_out = GELU) -> idiff_linear_fwd. */
+ * NULL; dim = 64, hid = 256, nout <= 256 (the UNet's nf = 64).  The sums run in a different order than the
+ * idiff_time_embed_fwd -> idiff_linear_fwd(act_out = GELU) -> idiff_linear_fwd chain it replaces (fp32 rounding differences only). */
 int idiff_time_mlp_fwd(const float* t, const float* freqs, const float* w0, const float* b0, const float* w2, const float* b2, float* out,
                        int B, int dim, int hid, int nout, idiff_stream_t stream);
 
@@ -321,6 +333,13 @@ int idiff_smm_xattn_lse_fwd(const float* qf, const float* mem, float* o, float* 
                             idiff_stream_t stream);
 int idiff_smm_xattn_bwd(const float* qf, const float* mem, const float* o, const float* lse, const float* d_o, float* dqf, float* dmem,
                         int accumulate, float* ws, int B, int rows, int N, float scale, idiff_stream_t stream);
+/* The same pair over a memory of Cm rows (row-major qf / o / dqf [B, rows, Cm], mem / dmem [B, Cm, N]): Cm = 256, or 72 for the compact
+ * (C + 1)-row memory of the 64-channel levels (r05: the training step attends to the compact memory too; its padding rows carry no
+ * gradient).  ws: idiff_smm_xattn_ws_floats(B, rows, 1, Cm, N) floats. */
+int idiff_smm_xattn_cm_lse_fwd(const float* qf, const float* mem, float* o, float* lse, float* ws, int B, int rows, int Cm, int N,
+                               float scale, idiff_stream_t stream);
+int idiff_smm_xattn_cm_bwd(const float* qf, const float* mem, const float* o, const float* lse, const float* d_o, float* dqf, float* dmem,
+                           int accumulate, float* ws, int B, int rows, int Cm, int N, float scale, idiff_stream_t stream);
 /* score map: out[b,k,p] = <feat[b,:,p]/max(|feat[b,:,p]|,eps), tv[b,k,:]/max(|tv[b,k,:]|,eps)>; K <= 8
  * sel (optional) [B, HW] = out[b, idx[b], :]  (idx int32 [B]) */
 int idiff_scoremap_fwd(const float* feat, int64_t feat_bstride, const float* tv, float* out, const int32_t* idx,

@@ -88,6 +88,9 @@ SIGNATURES = {
     "idiff_linear_t_heads_fwd": (I, [P, I64, I64, P, I64, I64, P, I64, P, I64, I64, I, I, I, I, c_stream]),
     "idiff_smm_memproj_fwd": (I, [P, I64, P, P, P, P, P, P, P, I, I, I, F, c_stream]),
     "idiff_smm_memproj_compact_fwd": (I, [P, I64, P, P, P, P, F, P, I, I, I, I, F, F, c_stream]),
+    "idiff_smm_memproj_compact_train_fwd": (I, [P, I64, P, P, P, P, P, P, I, I, I, I, F, F, c_stream]),
+    "idiff_smm_memproj_compact_bwd_ws_floats": (I64, [I, I, I]),
+    "idiff_smm_memproj_compact_bwd": (I, [P, I64, P, P, P, P, P, P, P, I64, P, P, I, I, I, I, F, F, c_stream]),
     "idiff_smm_memproj_compact_grouped_fwd": (I, [C.POINTER(MemprojGroup), I, I, F, F, c_stream]),
     "idiff_layernorm_rows_fwd": (I, [P, I64, P, P, P, I64, I, I, F, P, c_stream]),
     "idiff_time_embed_fwd": (I, [P, P, I, I, P, c_stream]),
@@ -104,6 +107,8 @@ SIGNATURES = {
     "idiff_smm_xattn_grouped_fwd": (I, [C.POINTER(XattnGroup), I, I, I, I, F, c_stream]),
     "idiff_smm_xattn_lse_fwd": (I, [P, P, P, P, P, I, I, I, F, c_stream]),
     "idiff_smm_xattn_bwd": (I, [P, P, P, P, P, P, P, I, P, I, I, I, F, c_stream]),
+    "idiff_smm_xattn_cm_lse_fwd": (I, [P, P, P, P, P, I, I, I, I, F, c_stream]),
+    "idiff_smm_xattn_cm_bwd": (I, [P, P, P, P, P, P, P, I, P, I, I, I, I, F, c_stream]),
     "idiff_scoremap_fwd": (I, [P, I64, P, P, P, P, I, I, I, I, c_stream]),
     "idiff_scoremap_grouped_fwd": (I, [C.POINTER(ScoremapGroup), I, P, I, I, c_stream]),
     "idiff_gather_channel": (I, [P, P, P, I, I, I, c_stream]),

@@ -835,11 +835,16 @@ __global__ __launch_bounds__(256) void smm_xattn_combine_grouped_kernel(const Xa
 // split the 256 channels (partial S / dP tiles meet in LDS), 32-key blocks, f32 MFMA 32x32x2 throughout; P and G are taken straight
 // from the accumulators as B operands for dqf, and through a 32x32 LDS transpose (keys onto the lanes) for dmem.
 //   LDS: mem tile 4 x [64][33]; qf and do as [32 rows][257]; exchange / transpose area 4 x 2304; row constants.
+// XCW = channels per wave: 64 (the 256-row memory) or 18 (the compact 72-row memory of the narrow levels, r05: rows >= C + 1 of it are
+// padding -- their dmem rows are written and never read).  The 18-channel form pads a wave's P.V-shaped products to one 32-channel
+// block (as the forward kernel does) and needs 72 KB of LDS instead of 137: two workgroups per CU.
+template <int XCW>
 __global__ __launch_bounds__(256) void smm_xattn_bwd_kernel(const float* __restrict__ qf, const float* __restrict__ mem, const float* __restrict__ o,
                                                             const float* __restrict__ lse, const float* __restrict__ d_o, float* __restrict__ ws,
                                                             float* __restrict__ dmem, int rows, int N, int nsplit, int kps, float scale,
                                                             int accumulate) {
-    constexpr int XCW = 64, XCM = 256, XTILE = 64 * 33, XP = 257, XREG = 2304;
+    constexpr int XCM = 4 * XCW, XCB = (XCW + 31) / 32, XTILE = XCB * 32 * 33, XP = XCM + 1, XREG = 2304;
+    constexpr int NF4 = (XCW * 8 + 63) / 64;  // float4 loads per lane per 32-key block
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tile = smem + (threadIdx.x >> 6) * XTILE;  // private per wave: [64 c][33]
     float* qL = smem + 4 * XTILE;                     // [32][257]
@@ -852,9 +857,11 @@ __global__ __launch_bounds__(256) void smm_xattn_bwd_kernel(const float* __restr
     const float* memb = mem + (long long)b * XCM * N + (long long)c0 * N;
     float* dmemb = dmem + (long long)b * XCM * N + (long long)c0 * N;
 
-    // qf, do -> LDS (rows beyond `rows` are zero); D = rowsum(do * o): 8 threads per row, 32 channels each
+    // qf, do -> LDS (rows beyond `rows` are zero); D = rowsum(do * o): 8 threads per row, XCM / 8 channels each
+    if (XCW % 32 != 0)
+        for (int i = lane; i < XTILE; i += 64) tile[i] = 0.f;  // the padding rows of the wave's slice feed MFMA rows that are never stored
     for (int i = tid; i < 32 * XCM; i += 256) {
-        const int r = i >> 8, c = i & 255;
+        const int r = i / XCM, c = i - r * XCM;
         const bool v = r < rows;
         qL[r * XP + c] = v ? qf[((long long)b * rows + r) * XCM + c] : 0.f;
         dL[r * XP + c] = v ? d_o[((long long)b * rows + r) * XCM + c] : 0.f;
@@ -863,7 +870,7 @@ __global__ __launch_bounds__(256) void smm_xattn_bwd_kernel(const float* __restr
         const int r = tid >> 3, part = tid & 7;
         float acc = 0.f;
         if (r < rows)
-            for (int c = part * 32; c < part * 32 + 32; ++c) acc += d_o[((long long)b * rows + r) * XCM + c] * o[((long long)b * rows + r) * XCM + c];
+            for (int c = part * (XCM / 8); c < (part + 1) * (XCM / 8); ++c) acc += d_o[((long long)b * rows + r) * XCM + c] * o[((long long)b * rows + r) * XCM + c];
         acc += __shfl_xor(acc, 1, 64);
         acc += __shfl_xor(acc, 2, 64);
         acc += __shfl_xor(acc, 4, 64);
@@ -875,24 +882,25 @@ __global__ __launch_bounds__(256) void smm_xattn_bwd_kernel(const float* __restr
     __syncthreads();
     const float my_lse = rowc[l31], my_D = rowc[32 + l31];
 
-    floatx16 Oq[2];
+    floatx16 Oq[XCB];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < XCB; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) Oq[m][r] = 0.f;
 
     const int nkb = (N + 31) / 32;
     const int kb_begin = sp * kps;
     const int kb_end = min(nkb, kb_begin + kps);
-    floatx4 rt[8];  // 64 c x 32 keys / 64 lanes
+    floatx4 rt[NF4];  // XCW c x 32 keys / 64 lanes
     auto load_tile = [&](int kbi) {
         const int key0 = kbi * 32;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int f = lane + i * 64;  // float4 index in [64][8]
+        for (int i = 0; i < NF4; ++i) {
+            const int f = lane + i * 64;  // float4 index in [XCW][8]
             const int c = f >> 3, j4 = (f & 7) * 4;
             floatx4 z = {0.f, 0.f, 0.f, 0.f};
-            if (key0 + j4 + 3 < N)
+            if (XCW % 8 != 0 && f >= XCW * 8) {
+            } else if (key0 + j4 + 3 < N)
                 z = *reinterpret_cast<const floatx4*>(memb + (long long)c * N + key0 + j4);
             else
                 for (int e = 0; e < 4; ++e)
@@ -902,9 +910,10 @@ __global__ __launch_bounds__(256) void smm_xattn_bwd_kernel(const float* __restr
     };
     auto write_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NF4; ++i) {
             const int f = lane + i * 64;
             const int c = f >> 3, j4 = (f & 7) * 4;
+            if (XCW % 8 != 0 && f >= XCW * 8) continue;
 #pragma unroll
             for (int e = 0; e < 4; ++e) tile[c * 33 + j4 + e] = rt[i][e];
         }
@@ -949,7 +958,7 @@ __global__ __launch_bounds__(256) void smm_xattn_bwd_kernel(const float* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r)
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < XCB; ++m)
                 Oq[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(tile[(m * 32 + l31) * 33 + KAPPA(r) + 4 * half], G[r], Oq[m], 0, 0, 0);
         // ---- dmem[c][key] = sum_row do[row][c] P[key][row] + qf[row][c] G[key][row]: P, G with the keys on the lanes ----
         float* pt = xch + wave * XREG;   // [32 rows][33]
@@ -960,33 +969,42 @@ __global__ __launch_bounds__(256) void smm_xattn_bwd_kernel(const float* __restr
             gt[l31 * 33 + KAPPA(r) + 4 * half] = G[r];
         }
         // (wave-private area: the reads below follow the writes in program order; LDS is in order within a wave)
-        floatx16 Dm[2];
+        floatx16 Dm[XCB];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < XCB; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) Dm[m][r] = 0.f;
+        // (a wave's last channel block may reach past its XCW channels: lanes beyond read a neighbour's / the next row's values -- finite
+        // numbers that only enter accumulator rows no store ever reads; the clamp keeps the address inside the row arrays)
 #pragma unroll
         for (int sidx = 0; sidx < 16; ++sidx) {
             const int row = 2 * sidx + half;
             const float pb = pt[row * 33 + l31], gb = gt[row * 33 + l31];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                Dm[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(dL[row * XP + c0 + m * 32 + l31], pb, Dm[m], 0, 0, 0);
-                Dm[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(qL[row * XP + c0 + m * 32 + l31], gb, Dm[m], 0, 0, 0);
+            for (int m = 0; m < XCB; ++m) {
+                const int cc = XCW % 32 == 0 ? c0 + m * 32 + l31 : min(c0 + m * 32 + l31, XCM - 1);
+                Dm[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(dL[row * XP + cc], pb, Dm[m], 0, 0, 0);
+                Dm[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(qL[row * XP + cc], gb, Dm[m], 0, 0, 0);
             }
         }
         const int key = kbi * 32 + l31;
         if (key < N) {
             if (accumulate) {  // uniform: dmem += (the gradients of the decoder layers that share this memory meet here, in a fixed order)
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < XCB; ++m)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) Dm[m][r] += dmemb[(long long)(m * 32 + KAPPA(r) + 4 * half) * N + key];
+                    for (int r = 0; r < 16; ++r) {
+                        const int cl = m * 32 + KAPPA(r) + 4 * half;
+                        if (cl < XCW) Dm[m][r] += dmemb[(long long)cl * N + key];
+                    }
             }
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < XCB; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dmemb[(long long)(m * 32 + KAPPA(r) + 4 * half) * N + key] = Dm[m][r];
+                for (int r = 0; r < 16; ++r) {
+                    const int cl = m * 32 + KAPPA(r) + 4 * half;
+                    if (cl < XCW) dmemb[(long long)cl * N + key] = Dm[m][r];
+                }
         }
         if (kbi + 1 < kb_end) write_tile();
         __syncthreads();  // the tile and the exchange area are rewritten by the next block
@@ -994,22 +1012,25 @@ __global__ __launch_bounds__(256) void smm_xattn_bwd_kernel(const float* __restr
     // partial dqf: ws[b][sp][c][row]
     float* wp = ws + ((long long)b * nsplit + sp) * XCM * 32;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < XCB; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) wp[(c0 + m * 32 + KAPPA(r) + 4 * half) * 32 + l31] = Oq[m][r];
+        for (int r = 0; r < 16; ++r) {
+            const int cl = m * 32 + KAPPA(r) + 4 * half;
+            if (cl < XCW) wp[(c0 + cl) * 32 + l31] = Oq[m][r];
+        }
 }
 
 // dqf[b][row][c] = sum over the key splits, in order
-__global__ __launch_bounds__(256) void smm_xattn_bwd_combine_kernel(const float* __restrict__ ws, float* __restrict__ dqf, int rows, int nsplit) {
+__global__ __launch_bounds__(256) void smm_xattn_bwd_combine_kernel(const float* __restrict__ ws, float* __restrict__ dqf, int rows, int nsplit, int XCM) {
     const int b = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 256 * 32
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over XCM * 32
     const int c = i >> 5, row = i & 31;
-    if (c >= 256 || row >= rows) return;
-    const float* wb = ws + (long long)b * nsplit * 256 * 32;
+    if (c >= XCM || row >= rows) return;
+    const float* wb = ws + (long long)b * nsplit * XCM * 32;
     float acc = 0.f;
 #pragma unroll 8
-    for (int s = 0; s < nsplit; ++s) acc += wb[(long long)s * 256 * 32 + c * 32 + row];
-    dqf[((long long)b * rows + row) * 256 + c] = acc;
+    for (int s = 0; s < nsplit; ++s) acc += wb[(long long)s * XCM * 32 + c * 32 + row];
+    dqf[((long long)b * rows + row) * XCM + c] = acc;
 }
 
 inline void smm_split(int B, int N, int* nsplit, int* kps) {
@@ -1217,24 +1238,47 @@ extern "C" int idiff_smm_xattn_lse_fwd(const float* qf, const float* mem, float*
     return smm_xattn_fwd_impl(qf, mem, o, lse, ws, B, rows, 1, 256, N, scale, stream);
 }
 
-extern "C" int idiff_smm_xattn_bwd(const float* qf, const float* mem, const float* o, const float* lse, const float* d_o, float* dqf, float* dmem,
-                                   int accumulate, float* ws, int B, int rows, int N, float scale, idiff_stream_t stream) {
+extern "C" int idiff_smm_xattn_cm_lse_fwd(const float* qf, const float* mem, float* o, float* lse, float* ws, int B, int rows, int Cm, int N,
+                                          float scale, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(lse, "smm_xattn_cm_lse_fwd: null lse");
+    return smm_xattn_fwd_impl(qf, mem, o, lse, ws, B, rows, 1, Cm, N, scale, stream);
+}
+
+static int smm_xattn_bwd_impl(const float* qf, const float* mem, const float* o, const float* lse, const float* d_o, float* dqf, float* dmem,
+                              int accumulate, float* ws, int B, int rows, int Cm, int N, float scale, idiff_stream_t stream) {
     IDIFF_CHECK_ARG(qf && mem && o && lse && d_o && dqf && dmem && ws && B > 0 && N > 0, "smm_xattn_bwd: bad args");
     IDIFF_CHECK_ARG(rows >= 1 && rows <= 32, "smm_xattn_bwd: rows must be in 1..32 (got %d)", rows);
+    IDIFF_CHECK_ARG(Cm == 256 || Cm == 72, "smm_xattn_bwd: Cm must be 72 or 256 (got %d)", Cm);
     IDIFF_CHECK_ARG(N % 4 == 0, "smm_xattn_bwd: N must be a multiple of 4");
     int ns, kps;
     smm_split(B, N, &ns, &kps);
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)(4 * 64 * 33 + 2 * 32 * 257 + 4 * 2304 + 64) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(smm_xattn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int xcb = (Cm / 4 + 31) / 32;
+    const size_t lds = (size_t)(4 * xcb * 32 * 33 + 2 * 32 * (Cm + 1) + 4 * 2304 + 64) * sizeof(float);
+    static bool attr[2] = {false, false};
+    const int which = Cm == 256 ? 0 : 1;
+    if (!attr[which]) {
+        hipError_t e = Cm == 256 ? hipFuncSetAttribute(reinterpret_cast<const void*>(smm_xattn_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                 : hipFuncSetAttribute(reinterpret_cast<const void*>(smm_xattn_bwd_kernel<18>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "smm_xattn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr = true;
+        attr[which] = true;
     }
-    hipLaunchKernelGGL(smm_xattn_bwd_kernel, dim3(ns, B), dim3(256), lds, st, qf, mem, o, lse, d_o, ws, dmem, rows, N, ns, kps, scale, accumulate);
+    if (Cm == 256)
+        hipLaunchKernelGGL(smm_xattn_bwd_kernel<64>, dim3(ns, B), dim3(256), lds, st, qf, mem, o, lse, d_o, ws, dmem, rows, N, ns, kps, scale, accumulate);
+    else
+        hipLaunchKernelGGL(smm_xattn_bwd_kernel<18>, dim3(ns, B), dim3(256), lds, st, qf, mem, o, lse, d_o, ws, dmem, rows, N, ns, kps, scale, accumulate);
     IDIFF_CHECK_LAUNCH("smm_xattn_bwd");
-    hipLaunchKernelGGL(smm_xattn_bwd_combine_kernel, dim3(32, B), dim3(256), 0, st, ws, dqf, rows, ns);
+    hipLaunchKernelGGL(smm_xattn_bwd_combine_kernel, dim3((Cm * 32 + 255) / 256, B), dim3(256), 0, st, ws, dqf, rows, ns, Cm);
     IDIFF_CHECK_LAUNCH("smm_xattn_bwd_combine");
     return IDIFF_OK;
+}
+
+extern "C" int idiff_smm_xattn_bwd(const float* qf, const float* mem, const float* o, const float* lse, const float* d_o, float* dqf, float* dmem,
+                                   int accumulate, float* ws, int B, int rows, int N, float scale, idiff_stream_t stream) {
+    return smm_xattn_bwd_impl(qf, mem, o, lse, d_o, dqf, dmem, accumulate, ws, B, rows, 256, N, scale, stream);
+}
+
+extern "C" int idiff_smm_xattn_cm_bwd(const float* qf, const float* mem, const float* o, const float* lse, const float* d_o, float* dqf, float* dmem,
+                                      int accumulate, float* ws, int B, int rows, int Cm, int N, float scale, idiff_stream_t stream) {
+    return smm_xattn_bwd_impl(qf, mem, o, lse, d_o, dqf, dmem, accumulate, ws, B, rows, Cm, N, scale, stream);
 }

@@ -393,57 +393,52 @@ __global__ __launch_bounds__(256) void scoremap4_grouped_kernel(const ScoremapGr
 }
 
 // The time-embedding MLP in ONE launch (idiff_time_mlp_fwd):  temb = W2 . GELU(W0 . [sin(t f) ; cos(t f)] + b0) + b2.
-// grid (4, B): every workgroup evaluates the sinusoidal embedding and the whole first layer of its sample (dim -> hid, cheap), then a
-// quarter of the second layer's outputs.  Per output the arithmetic is linear_kernel's (one wave per output, lanes split K in steps of 64,
-// wave_sum), so the result equals the time_embed -> linear -> linear chain it replaces bit for bit.
+// grid (8, B): every workgroup evaluates the sinusoidal embedding and the whole first layer of its sample (thread = hidden unit: its
+// weight row of `dim` floats in 16-byte loads, all in flight at once), then an eighth of the second layer's outputs (eight threads per
+// output, 32 consecutive weights each, summed over the eight lanes by shuffles).  Every load of a layer is issued before the first
+// use: the r05 first version (a wave per output, eight outputs in flight) took 71 us -- twice the three launches it replaced.
 __global__ __launch_bounds__(256) void time_mlp_kernel(const float* __restrict__ t, const float* __restrict__ freqs, const float* __restrict__ w0,
                                                        const float* __restrict__ b0, const float* __restrict__ w2, const float* __restrict__ b2,
-                                                       float* __restrict__ out, int dim, int hid, int nout) {
-    extern __shared__ float tm_smem[];  // [dim] embedding, [hid] hidden
-    float* e0 = tm_smem;
-    float* h1 = tm_smem + dim;
-    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = dim / 2;
-    for (int j = threadIdx.x; j < dim; j += 256) {
-        const int f = j < half ? j : j - half;
+                                                       float* __restrict__ out, int nout) {
+    constexpr int DIM = 64, HID = 256;
+    __shared__ __attribute__((aligned(16))) float e0[DIM];
+    __shared__ __attribute__((aligned(16))) float h1[HID];
+    const int b = blockIdx.y, tid = threadIdx.x, half = DIM / 2;
+    // this thread's first-layer row: requested before anything else
+    floatx4 wr[DIM / 4];
+#pragma unroll
+    for (int i = 0; i < DIM / 4; ++i) wr[i] = reinterpret_cast<const floatx4*>(w0 + (long long)tid * DIM)[i];
+    if (tid < DIM) {
+        const int f = tid < half ? tid : tid - half;
         const float freq = freqs ? freqs[f] : expf((float)f * (-logf(10000.0f) / (float)(half - 1)));
         const float arg = __fmul_rn(t[b], freq);
-        e0[j] = j < half ? sinf(arg) : cosf(arg);
+        e0[tid] = tid < half ? sinf(arg) : cosf(arg);
     }
+    // second layer: output n = 32 * blockIdx.x + tid / 8, K range 32 * (tid & 7) .. + 31
+    const int n = 32 * blockIdx.x + (tid >> 3), kq = tid & 7;
+    floatx4 w2r[8];
+    const bool live = n < nout;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w2r[i] = live ? reinterpret_cast<const floatx4*>(w2 + (long long)n * HID + kq * 32)[i] : floatx4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
-    for (int n0 = wave; n0 < hid; n0 += 4 * 8) {  // eight outputs of a wave in flight
-        float acc[8];
+    float acc = 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            acc[u] = 0.f;
-            const int n = n0 + 4 * u;
-            if (n < hid)
-                for (int k = lane; k < dim; k += 64) acc[u] += e0[k] * w0[(long long)n * dim + k];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int n = n0 + 4 * u;
-            const float v = wave_sum(acc[u]);
-            if (n < hid && lane == 0) h1[n] = act_apply(1.f * (v + (b0 ? b0[n] : 0.f)), IDIFF_ACT_GELU);
-        }
+    for (int i = 0; i < DIM / 4; ++i) {
+        const floatx4 e = reinterpret_cast<const floatx4*>(e0)[i];
+        acc += wr[i].x * e.x + wr[i].y * e.y + wr[i].z * e.z + wr[i].w * e.w;
     }
+    h1[tid] = act_apply(acc + (b0 ? b0[tid] : 0.f), IDIFF_ACT_GELU);
     __syncthreads();
-    const int per = (nout + 3) / 4, nb = blockIdx.x * per, ne = min(nout, nb + per);
-    for (int n0 = nb + wave; n0 < ne; n0 += 4 * 8) {
-        float acc[8];
+    float a2 = 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            acc[u] = 0.f;
-            const int n = n0 + 4 * u;
-            if (n < ne)
-                for (int k = lane; k < hid; k += 64) acc[u] += h1[k] * w2[(long long)n * hid + k];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int n = n0 + 4 * u;
-            const float v = wave_sum(acc[u]);
-            if (n < ne && lane == 0) out[(long long)b * nout + n] = 1.f * (v + (b2 ? b2[n] : 0.f));
-        }
+    for (int i = 0; i < 8; ++i) {
+        const floatx4 h = reinterpret_cast<const floatx4*>(h1 + kq * 32)[i];
+        a2 += w2r[i].x * h.x + w2r[i].y * h.y + w2r[i].z * h.z + w2r[i].w * h.w;
     }
+    a2 += __shfl_xor(a2, 1, 64);
+    a2 += __shfl_xor(a2, 2, 64);
+    a2 += __shfl_xor(a2, 4, 64);
+    if (live && kq == 0) out[(long long)b * nout + n] = a2 + (b2 ? b2[n] : 0.f);
 }
 
 __global__ void gather_channel_kernel(const float* __restrict__ x, const int* __restrict__ idx, float* __restrict__ out, int B, int C, int HW) {
@@ -575,10 +570,10 @@ extern "C" int idiff_scoremap_grouped_fwd(const idiff_scoremap_group* groups, in
 
 extern "C" int idiff_time_mlp_fwd(const float* t, const float* freqs, const float* w0, const float* b0, const float* w2, const float* b2, float* out,
                                   int B, int dim, int hid, int nout, idiff_stream_t stream) {
-    IDIFF_CHECK_ARG(t && w0 && w2 && out && B > 0 && dim >= 4 && dim % 2 == 0 && hid > 0 && nout > 0, "time_mlp: bad args");
-    IDIFF_CHECK_ARG((size_t)(dim + hid) * sizeof(float) <= 48 * 1024, "time_mlp: dim + hid too large (%d)", dim + hid);
-    hipLaunchKernelGGL(time_mlp_kernel, dim3(4, B), dim3(256), (size_t)(dim + hid) * sizeof(float), (hipStream_t)stream, t, freqs, w0, b0, w2, b2, out,
-                       dim, hid, nout);
+    IDIFF_CHECK_ARG(t && w0 && w2 && out && B > 0 && nout > 0, "time_mlp: bad args");
+    IDIFF_CHECK_ARG(dim == 64 && hid == 256 && nout <= 256, "time_mlp: the fused form is built for the UNet's 64 -> 256 -> <= 256 MLP (got %d -> %d -> %d)", dim, hid, nout);
+    IDIFF_CHECK_ARG(((reinterpret_cast<uintptr_t>(w0) | reinterpret_cast<uintptr_t>(w2)) & 15) == 0, "time_mlp: 16-byte aligned weights required");
+    hipLaunchKernelGGL(time_mlp_kernel, dim3(8, B), dim3(256), 0, (hipStream_t)stream, t, freqs, w0, b0, w2, b2, out, nout);
     IDIFF_CHECK_LAUNCH("time_mlp");
     return IDIFF_OK;
 }

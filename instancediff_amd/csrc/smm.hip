@@ -169,8 +169,9 @@ template <int CJ>  // channels per thread = C / 4 (16: C = 64, 32: C = 128)
 __device__ __forceinline__ void smm_memproj_gram_body(const float* __restrict__ feat, long long fbs, const float* __restrict__ g1,
                                                       const float* __restrict__ b1, const float* __restrict__ gram,
                                                       const float* __restrict__ hvec, float evar, float* __restrict__ out, int N, int Cm,
-                                                      float eps1, float eps2, const int b, const int bx) {
+                                                      float eps1, float eps2, const int b, const int bx, const float* __restrict__ evar_dev = nullptr) {
     constexpr int C = 4 * CJ;
+    if (evar_dev) evar = *evar_dev;  // training: the constant of the quadratic form is a device-side function of the weights
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xt = smem;                 // [C][64] normalised tile
     float* part = smem + C * MP_PX;   // [5][64]
@@ -258,8 +259,165 @@ template <int CJ>
 __global__ __launch_bounds__(256) void smm_memproj_gram_kernel(const float* __restrict__ feat, long long fbs, const float* __restrict__ g1,
                                                                const float* __restrict__ b1, const float* __restrict__ gram,
                                                                const float* __restrict__ hvec, float evar, float* __restrict__ out,
-                                                               int N, int Cm, float eps1, float eps2) {
-    smm_memproj_gram_body<CJ>(feat, fbs, g1, b1, gram, hvec, evar, out, N, Cm, eps1, eps2, blockIdx.y, blockIdx.x);
+                                                               int N, int Cm, float eps1, float eps2, const float* __restrict__ evar_dev) {
+    smm_memproj_gram_body<CJ>(feat, fbs, g1, b1, gram, hvec, evar, out, N, Cm, eps1, eps2, blockIdx.y, blockIdx.x, evar_dev);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Backward of the compact memory projection (training step, 64-channel levels; r05).  Forward, per pixel:
+//   xn = (x - mean_c x) rstd1 ;  xh = g1 xn + b1 ;  u = G xh ;  v = xh.u + 2 h.xh + e ;  r = (v + eps2)^-1/2 ;  m = [xh r ; r]
+// Given dm [B, Cm, N] (rows 0..C: the padding rows carry no gradient):
+//   dr = sum_c dm_c xh_c + dm_C ;  dv = -r^3 dr / 2 ;  dxh = dm_{0..C-1} r + 2 dv (u + h)          (G symmetric)
+//   dG += dv xh xh^T ;  dh += 2 dv xh ;  de += dv ;  dg1 += dxh xn ;  db1 += dxh                       (sums over all pixels)
+//   dx = rstd1 (g1 dxh - mean_c(g1 dxh) - xn mean_c(g1 dxh xn))
+// Thread = pixel x channel quarter as in the forward (channels wave, wave + 4, ..: x, dm, xn, xh in registers); u = G xh and
+// dG = (dv xh) xh^T (pixels as K) on v_mfma_f32_32x32x2_f32, one 32 x 32 tile per wave each; the per-pixel channel sums meet
+// through LDS.  A workgroup walks tiles blockIdx.x, + gridDim.x, .. with its parameter-gradient accumulators in registers and leaves
+// ONE partial row [C*C | dg1 | db1 | dh | de]; idiff_colsum reduces the rows in a fixed order (no atomics: bitwise reproducible).
+constexpr int MB_LD = 65;  // row stride of the [c][pixel] LDS tiles: odd, so that lane = channel reads are conflict-free too
+__global__ __launch_bounds__(256) void smm_memproj_gram_bwd_kernel(const float* __restrict__ feat, long long fbs, const float* __restrict__ g1,
+                                                                   const float* __restrict__ b1, const float* __restrict__ gram,
+                                                                   const float* __restrict__ hvec, const float* __restrict__ evar_dev,
+                                                                   const float* __restrict__ dm, float* __restrict__ dfeat, long long dbs,
+                                                                   float* __restrict__ ws, int N, int Cm, int ntx, int ntiles, float eps1,
+                                                                   float eps2) {
+    constexpr int CJ = 16, C = 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xt = smem;                    // [C][65] xh
+    float* ut = xt + C * MB_LD;          // [C][65] u + h
+    float* wt = ut + C * MB_LD;          // [C][65] dv xh
+    float* part = wt + C * MB_LD;        // [4 sums][4 waves][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const float evar = *evar_dev;
+    float gj[CJ], bj[CJ], pg1[CJ], pb1[CJ], ph[CJ];
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) gj[j] = g1[wave + 4 * j], bj[j] = b1[wave + 4 * j], pg1[j] = 0.f, pb1[j] = 0.f, ph[j] = 0.f;
+    float pe = 0.f;
+    floatx16 accG;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accG[r] = 0.f;
+    const int mt = wave & 1, nt = wave >> 1;  // this wave's 32 x 32 tile of u (rows c', pixel block) and of dG (rows c, columns c')
+    float ga[C / 2];                          // Gram rows of the u tile (constant over the tiles)
+    {
+        const float* wl = gram + (long long)half * C + mt * 32 + l31;
+#pragma unroll
+        for (int st = 0; st < C / 2; ++st) ga[st] = wl[(long long)(2 * st) * C];
+    }
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int b = t / ntx, p0 = (t - b * ntx) * MP_PX;
+        const int p = p0 + lane;
+        const bool ok = p < N;
+        const float* fb = feat + (long long)b * fbs + (ok ? p : 0);
+        const float* db = dm + (long long)b * Cm * N + (ok ? p : 0);
+        float x[CJ], d[CJ];
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) x[j] = ok ? fb[(long long)(wave + 4 * j) * N] : 0.f;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) d[j] = ok ? db[(long long)(wave + 4 * j) * N] : 0.f;
+        const float dC = ok ? db[(long long)C * N] : 0.f;
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) s += x[j];
+        part[wave * 64 + lane] = s;
+        __syncthreads();
+        const float mean1 = (part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane]) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+            const float e = x[j] - mean1;
+            q += e * e;
+        }
+        part[256 + wave * 64 + lane] = q;
+        __syncthreads();
+        const float rstd1 = rsqrtf((part[256 + lane] + part[256 + 64 + lane] + part[256 + 128 + lane] + part[256 + 192 + lane]) / (float)C + eps1);
+        float xh[CJ];  // x[] becomes xn
+        float drp = 0.f;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+            x[j] = (x[j] - mean1) * rstd1;
+            xh[j] = x[j] * gj[j] + bj[j];
+            xt[(wave + 4 * j) * MB_LD + lane] = xh[j];
+            drp += d[j] * xh[j];
+        }
+        part[512 + wave * 64 + lane] = drp;
+        __syncthreads();
+        // ---- u = G xh for (rows mt*32.., pixels nt*32..); v partial folded as in the forward; u + h parked for the per-pixel pass ----
+        {
+            floatx16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* xl = xt + half * MB_LD + nt * 32 + l31;
+#pragma unroll
+            for (int st = 0; st < C / 2; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[st], xl[2 * st * MB_LD], acc, 0, 0, 0);
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cp = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float hv = hvec[cp];
+                sum += xt[cp * MB_LD + nt * 32 + l31] * (acc[r] + 2.f * hv);
+                ut[cp * MB_LD + nt * 32 + l31] = acc[r] + hv;
+            }
+            sum += __shfl_xor(sum, 32, 64);
+            // pixel nt*32 + l31 gets this wave's share (its 32 rows c'); the other pixel block of this wave's slot stays zero
+            if (half == 0) {
+                part[wave * 64 + nt * 32 + l31] = sum;
+                part[wave * 64 + (nt ^ 1) * 32 + l31] = 0.f;
+            }
+        }
+        __syncthreads();
+        const float r2 = rsqrtf(part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane] + evar + eps2);
+        const float dr = (part[512 + lane] + part[512 + 64 + lane] + part[512 + 128 + lane] + part[512 + 192 + lane]) + dC;
+        const float dv = -0.5f * r2 * r2 * r2 * dr;
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+            const int c = wave + 4 * j;
+            const float dxh = d[j] * r2 + 2.f * dv * ut[c * MB_LD + lane];
+            wt[c * MB_LD + lane] = dv * xh[j];
+            pg1[j] += dxh * x[j];
+            pb1[j] += dxh;
+            ph[j] += 2.f * dv * xh[j];
+            d[j] = dxh * gj[j];  // d[] becomes d xn
+            a1 += d[j];
+            a2 += d[j] * x[j];
+        }
+        if (wave == 0) pe += dv;
+        part[256 + wave * 64 + lane] = a1;
+        part[768 + wave * 64 + lane] = a2;
+        __syncthreads();
+        const float m1 = (part[256 + lane] + part[256 + 64 + lane] + part[256 + 128 + lane] + part[256 + 192 + lane]) / (float)C;
+        const float m2 = (part[768 + lane] + part[768 + 64 + lane] + part[768 + 128 + lane] + part[768 + 192 + lane]) / (float)C;
+        if (ok) {
+            float* ob = dfeat + (long long)b * dbs + p;
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) ob[(long long)(wave + 4 * j) * N] = rstd1 * (d[j] - m1 - x[j] * m2);
+        }
+        // ---- dG[c][c'] += sum_px (dv xh)[c][px] xh[c'][px]: rows mt*32.., columns nt*32.. ----
+        {
+            const float* al = wt + (mt * 32 + l31) * MB_LD + half;
+            const float* bl = xt + (nt * 32 + l31) * MB_LD + half;
+#pragma unroll
+            for (int st = 0; st < MP_PX / 2; ++st) accG = __builtin_amdgcn_mfma_f32_32x32x2f32(al[2 * st], bl[2 * st], accG, 0, 0, 0);
+        }
+        __syncthreads();  // the tiles and the partial sums are rewritten by the next tile
+    }
+    // ---- this workgroup's partial row ----
+    float* wr = ws + (long long)blockIdx.x * (C * C + 3 * C + 1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wr[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * C + nt * 32 + l31] = accG[r];
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) {
+        const float a = wave_sum(pg1[j]), bb = wave_sum(pb1[j]), h2 = wave_sum(ph[j]);
+        if (lane == 0) {
+            wr[C * C + wave + 4 * j] = a;
+            wr[C * C + C + wave + 4 * j] = bb;
+            wr[C * C + 2 * C + wave + 4 * j] = h2;
+        }
+    }
+    if (wave == 0) {
+        const float e = wave_sum(pe);
+        if (lane == 0) wr[C * C + 3 * C] = e;
+    }
 }
 // Grouped launch (idiff_smm_memproj_compact_grouped_fwd): the compact memories of several ScoreMapModules in ONE launch; blockIdx.z
 // picks the level, blocks beyond a smaller level's pixels exit.  Same body, same bits.  The LDS of the launch is that of the widest
@@ -548,14 +706,57 @@ extern "C" int idiff_smm_memproj_compact_fwd(const float* feat, int64_t feat_bst
     IDIFF_CHECK_ARG(Cm > C, "smm_memproj_compact: Cm must exceed C (got %d, C = %d)", Cm, C);
     const size_t lds = (size_t)(C * MP_PX + 5 * MP_PX) * sizeof(float);  // <= 34 KB: no attribute needed
     const dim3 grid((N + MP_PX - 1) / MP_PX, B);
+    const float* nodev = nullptr;
     if (C == 64)
         hipLaunchKernelGGL(smm_memproj_gram_kernel<16>, grid, dim3(256), lds, (hipStream_t)stream, feat, (long long)feat_bstride, ln1_g, ln1_b, gram,
-                           hvec, evar, out, N, Cm, eps1, eps2);
+                           hvec, evar, out, N, Cm, eps1, eps2, nodev);
     else
         hipLaunchKernelGGL(smm_memproj_gram_kernel<32>, grid, dim3(256), lds, (hipStream_t)stream, feat, (long long)feat_bstride, ln1_g, ln1_b, gram,
-                           hvec, evar, out, N, Cm, eps1, eps2);
+                           hvec, evar, out, N, Cm, eps1, eps2, nodev);
     IDIFF_CHECK_LAUNCH("smm_memproj_compact_fwd");
     return IDIFF_OK;
+}
+
+extern "C" int idiff_smm_memproj_compact_train_fwd(const float* feat, int64_t feat_bstride, const float* ln1_g, const float* ln1_b, const float* gram,
+                                                   const float* hvec, const float* evar_dev, float* out, int B, int C, int N, int Cm, float eps1,
+                                                   float eps2, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(feat && ln1_g && ln1_b && gram && hvec && evar_dev && out, "smm_memproj_compact_train_fwd: null pointer");
+    IDIFF_CHECK_ARG(B > 0 && N > 0 && C == 64 && Cm > C, "smm_memproj_compact_train_fwd: C must be 64 (got %d), Cm > C", C);
+    IDIFF_CHECK_ARG(N % 4 == 0 && feat_bstride % 4 == 0, "smm_memproj_compact_train_fwd: N and feat_bstride must be multiples of 4");
+    const size_t lds = (size_t)(C * MP_PX + 5 * MP_PX) * sizeof(float);
+    hipLaunchKernelGGL(smm_memproj_gram_kernel<16>, dim3((N + MP_PX - 1) / MP_PX, B), dim3(256), lds, (hipStream_t)stream, feat, (long long)feat_bstride,
+                       ln1_g, ln1_b, gram, hvec, 0.f, out, N, Cm, eps1, eps2, evar_dev);
+    IDIFF_CHECK_LAUNCH("smm_memproj_compact_train_fwd");
+    return IDIFF_OK;
+}
+
+static int memproj_bwd_grid(int B, int N) {
+    const long long tiles = (long long)B * ((N + MP_PX - 1) / MP_PX);
+    return (int)(tiles < 1024 ? tiles : 1024);
+}
+extern "C" int64_t idiff_smm_memproj_compact_bwd_ws_floats(int B, int C, int N) {
+    return (int64_t)memproj_bwd_grid(B, N) * (C * C + 3 * C + 1);
+}
+extern "C" int idiff_smm_memproj_compact_bwd(const float* feat, int64_t feat_bstride, const float* ln1_g, const float* ln1_b, const float* gram,
+                                             const float* hvec, const float* evar_dev, const float* dm, float* dfeat, int64_t dfeat_bstride,
+                                             float* dparams, float* ws, int B, int C, int N, int Cm, float eps1, float eps2,
+                                             idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(feat && ln1_g && ln1_b && gram && hvec && evar_dev && dm && dfeat && dparams && ws, "smm_memproj_compact_bwd: null pointer");
+    IDIFF_CHECK_ARG(B > 0 && N > 0 && C == 64 && Cm > C, "smm_memproj_compact_bwd: C must be 64 (got %d), Cm > C", C);
+    const int ntx = (N + MP_PX - 1) / MP_PX, ntiles = B * ntx, grid = memproj_bwd_grid(B, N);
+    const int PW = C * C + 3 * C + 1;
+    const size_t lds = (size_t)(3 * C * MB_LD + 16 * 64) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(smm_memproj_gram_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) IDIFF_FAIL(IDIFF_E_HIP, "smm_memproj_compact_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr = true;
+    }
+    hipLaunchKernelGGL(smm_memproj_gram_bwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, feat, (long long)feat_bstride, ln1_g, ln1_b, gram,
+                       hvec, evar_dev, dm, dfeat, (long long)dfeat_bstride, ws, N, Cm, ntx, ntiles, eps1, eps2);
+    IDIFF_CHECK_LAUNCH("smm_memproj_compact_bwd");
+    // dparams [C*C | C | C | C | 1] = column sums of the workgroups' partial rows, fixed order
+    return idiff_colsum(ws, PW, dparams, grid, PW, 0, stream);
 }
 
 extern "C" int idiff_smm_memproj_compact_grouped_fwd(const idiff_memproj_group* groups, int ngroups, int B, float eps1, float eps2,

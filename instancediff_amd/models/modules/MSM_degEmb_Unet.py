@@ -739,8 +739,12 @@ class LearnableForwardUNet_MultiScoreMap(nn.Module):
         def ca_vec(ca_name, holder):
             return vecs[id(getattr(holder, ca_name))] if single else None
 
-        # sinusoidal embedding + both linears of the time MLP: one launch (the bits of time_embed -> linear(GELU) -> linear)
-        temb = ops.time_mlp(t, self.time_freqs, self.time_mlp[0].weight, self.time_mlp[0].bias, self.time_mlp[2].weight, self.time_mlp[2].bias)
+        # sinusoidal embedding + both linears of the time MLP: one launch where the MLP has the kernel's 64 -> 256 -> 256 geometry
+        if self.nf == 64 and self.time_dim == 256:
+            temb = ops.time_mlp(t, self.time_freqs, self.time_mlp[0].weight, self.time_mlp[0].bias, self.time_mlp[2].weight, self.time_mlp[2].bias)
+        else:
+            temb = ops.linear(ops.linear(ops.time_embed(t, self.nf, self.time_freqs), self.time_mlp[0].weight, self.time_mlp[0].bias, act_out=ops.ACT_GELU),
+                              self.time_mlp[2].weight, self.time_mlp[2].bias)
         films = self._films(temb)
 
         x = ops.conv2d(x_a, packed(self.init_conv), self.init_conv.bias, 7, self.nf, src1=x_b)

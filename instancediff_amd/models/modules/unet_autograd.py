@@ -6,13 +6,45 @@ import torch
 
 from ... import ops
 from .MSM_degEmb_Unet import branch_gains
-from ...train_ops import (ActFn, AddFn, AddVecFn, BgemmFn, ChanLayerNormFn, ChanNormalizeFn, ConvFn, GatherChannelFn, HeadFoldFn, LayerNormRowsFn,
-                          Linear3Fn, LinearFn, ResBlockFn, ScaleColsFn, SkipCatFn, SmmXattnFn, SoftmaxRowsFn, TokenAttnFn, _Slot, dropout, fork)
+from ...train_ops import (ActFn, AddFn, AddVecFn, BgemmFn, ChanLayerNormFn, ChanNormalizeFn, CompactMemFn, ConvFn, GatherChannelFn, HeadFoldFn,
+                          LayerNormRowsFn, Linear3Fn, LinearFn, ResBlockFn, ScaleColsFn, SkipCatFn, SmmXattnFn, SoftmaxRowsFn, StackRowsFn,
+                          TokenAttnFn, _Slot, dropout, fork)
 
 
 # IDIFF_FUSED_XATTN=0: the ScoreMapModule cross-attention of the training path as batched GEMMs + softmax (autograd-derived backward)
 import os  # noqa: E402
 FUSED_XATTN = bool(int(os.environ.get("IDIFF_FUSED_XATTN", "1")))
+# IDIFF_TRAIN_COMPACT=0: the 64-channel levels' ScoreMapModules attend to the materialised 256-row memory in the training step too (r04)
+TRAIN_COMPACT = bool(int(os.environ.get("IDIFF_TRAIN_COMPACT", "1")))
+_CEN = {}
+
+
+def _centering(n, dev):
+    """I - 11^T / n (symmetric): centring over the n outputs of the memory Linear as a matrix product"""
+    key = (n, str(dev))
+    if key not in _CEN:
+        _CEN[key] = (torch.eye(n, dtype=torch.float64) - 1.0 / n).float().to(dev)
+    return _CEN[key]
+
+
+def _memory_fold(mp, Cm, uses):
+    """The weight-side algebra of the compact memory (the sampling path does it once per weight version on the host,
+    MSM_degEmb_Unet._fold_memory_affine) as differentiable library launches, every step:
+        Wc = Cen W, bc = Cen b (centred over the Wd outputs);  Pt = g2 (.) [Wc^T ; bc ; 0]  [Cm, Wd]  (P^T: LayerNorm_Wd(W xh + b) = P m + b2)
+        gram = Wc^T Wc / Wd,  hvec = Wc^T bc / Wd,  evar = |bc|^2 / Wd                      (the variance's quadratic form)
+    -> (`uses` handles on Pt, gram [C,C], hvec [C], evar [1,1,1])"""
+    lin, ln2 = mp[1], mp[2]
+    Wd, C = lin.weight.shape
+    cen = _centering(Wd, lin.weight.device)
+    Wct = BgemmFn.apply(lin.weight[None], cen[None], True, False).reshape(C, Wd)   # W^T Cen = (Cen W)^T (reshape, not [0]: a view both ways)
+    bc = LinearFn.apply(lin.bias[None, :], cen, None)                   # b Cen              [1, Wd]
+    w0, w1, w2, w3 = fork(Wct, 4)
+    c0, c1, c2, c3 = fork(bc, 4)
+    Pt = ScaleColsFn.apply(StackRowsFn.apply(w0, c0, Cm), ln2.weight)
+    gram = BgemmFn.apply(w1[None], w2[None], False, True, 1.0 / Wd).reshape(C, C)
+    hvec = BgemmFn.apply(c1[None], w3[None], False, True, 1.0 / Wd).reshape(C)
+    evar = BgemmFn.apply(c2[None], c3[None], False, True, 1.0 / Wd)
+    return fork(Pt, uses), gram, hvec, evar
 
 
 def _resblock(rb, src0, src1, temb_act, vec=None, out=None):
@@ -100,9 +132,18 @@ def _smm(smm, feat, text_encoder, idx, feat_n=None):
     mp = dec.memory_proj
     if feat_n is None:
         feat, feat_n = fork(feat, 2)  # consumed by the memory projection and by the score map's normalisation
-    fn = ChanLayerNormFn.apply(feat, mp[0].weight, mp[0].bias, mp[0].eps)
-    m1 = ConvFn.apply(fn, None, mp[1].weight.reshape(Wd, C, 1, 1), mp[1].bias, 1, ops.CONV_NORMAL)
-    mem = ChanLayerNormFn.apply(m1, mp[2].weight, mp[2].bias, mp[2].eps).reshape(B, Wd, N)
+    fused_x = FUSED_XATTN and heads * K <= 32 and Wd == 256 and N % 4 == 0
+    compact = TRAIN_COMPACT and fused_x and C == 64 and feat.is_cuda
+    if compact:
+        # the (C + 1)-row pre-image of the memory (72 rows instead of 256) and the weights that fold its affine map into the attention
+        Cm = 72
+        pts, gram, hvec, evar = _memory_fold(mp, Cm, 2 * len(dec.decoder))
+        pts = list(pts)
+        mem = CompactMemFn.apply(feat, mp[0].weight, mp[0].bias, gram, hvec, evar, Cm, mp[0].eps, mp[2].eps)
+    else:
+        fn = ChanLayerNormFn.apply(feat, mp[0].weight, mp[0].bias, mp[0].eps)
+        m1 = ConvFn.apply(fn, None, mp[1].weight.reshape(Wd, C, 1, 1), mp[1].bias, 1, ops.CONV_NORMAL)
+        mem = ChanLayerNormFn.apply(m1, mp[2].weight, mp[2].bias, mp[2].eps).reshape(B, Wd, N)
     tp = dec.text_proj
     x = LinearFn.apply(LayerNormRowsFn.apply(t2d, tp[0].weight, tp[0].bias, tp[0].eps), tp[1].weight, tp[1].bias)
     R = B * K
@@ -110,7 +151,6 @@ def _smm(smm, feat, text_encoder, idx, feat_n=None):
     # MLP's inner Dropout and the block's output Dropout, models/_modified_BiomedCLIP.py:448-478,520-549); identity in eval()
     pd, tr = dec.dropout, smm.training
     mem_grad = {}  # the layers' gradients w.r.t. the shared memory are summed inside the fused backward kernel (SmmXattnFn)
-    fused_x = FUSED_XATTN and heads * K <= 32 and Wd == 256 and N % 4 == 0
     fused_t = K <= 8 and dh <= 64  # few-token self-attention: one fused forward / backward launch each
 
     def branch(y, g):  # TransformerDecoderLayer_scaled's per-channel gain on a residual branch (:586-589); plain layers: none
@@ -139,15 +179,26 @@ def _smm(smm, feat, text_encoder, idx, feat_n=None):
         qc = LinearFn.apply(n2, ca.q_proj.weight, None)  # [R, Wd]
         # k/v projections folded onto the queries: qf_h = q_h Wk_h ; S = qf mem ; o = P mem^T ; av_h = o_h Wv_h^T.
         # All heads' query rows are stacked ([B, K*heads, Wd]) so `mem` is read once per product, not once per head.
-        qf = HeadFoldFn.apply(qc, ca.k_proj.weight, heads, "in").reshape(B, K * heads, Wd)   # row = k*heads + h
-        if fused_x:
-            o = SmmXattnFn.apply(qf, mem, ca.scale, mem_grad)        # one fused forward, one fused backward pass over the keys
+        if compact:
+            # mem = P m + b2: fold P into the k / v weights (S = q Wk P m up to a per-row constant; o_256 = P (sum_n p_n m_n) + b2)
+            wkf = BgemmFn.apply(ca.k_proj.weight[None], pts.pop()[None], False, True).reshape(Wd, Cm)   # Wk P
+            wvp = BgemmFn.apply(ca.v_proj.weight[None], pts.pop()[None], False, True).reshape(Wd, Cm)   # Wv P
+            bvf = LinearFn.apply(mp[2].bias[None, :], ca.v_proj.weight, None)              # b2 Wv^T [1, Wd]: the softmax weights sum to 1
+            pbias = LinearFn.apply(bvf, ca.proj.weight, ca.proj.bias).reshape(Wd)          # ... carried through the output projection
+            qf = HeadFoldFn.apply(qc, wkf, heads, "in").reshape(B, K * heads, Cm)          # row = k*heads + h
+            o = SmmXattnFn.apply(qf, mem, ca.scale, mem_grad)
+            av = HeadFoldFn.apply(o.reshape(R, heads, Cm), wvp, heads, "out")              # [R, Wd]
+            x = AddFn.apply(xr, branch(dropout(LinearFn.apply(av, ca.proj.weight, pbias), pd, tr), g_ca), 1.0)
         else:
-            s_ = BgemmFn.apply(qf, mem, False, False)                # [B, K*heads, N]
-            p = SoftmaxRowsFn.apply(s_, ca.scale)
-            o = BgemmFn.apply(p, mem, False, True)                   # [B, K*heads, Wd]
-        av = HeadFoldFn.apply(o.reshape(R, heads, Wd), ca.v_proj.weight, heads, "out")       # [R, Wd]
-        x = AddFn.apply(xr, branch(dropout(LinearFn.apply(av, ca.proj.weight, ca.proj.bias), pd, tr), g_ca), 1.0)
+            qf = HeadFoldFn.apply(qc, ca.k_proj.weight, heads, "in").reshape(B, K * heads, Wd)   # row = k*heads + h
+            if fused_x:
+                o = SmmXattnFn.apply(qf, mem, ca.scale, mem_grad)        # one fused forward, one fused backward pass over the keys
+            else:
+                s_ = BgemmFn.apply(qf, mem, False, False)                # [B, K*heads, N]
+                p = SoftmaxRowsFn.apply(s_, ca.scale)
+                o = BgemmFn.apply(p, mem, False, True)                   # [B, K*heads, Wd]
+            av = HeadFoldFn.apply(o.reshape(R, heads, Wd), ca.v_proj.weight, heads, "out")       # [R, Wd]
+            x = AddFn.apply(xr, branch(dropout(LinearFn.apply(av, ca.proj.weight, ca.proj.bias), pd, tr), g_ca), 1.0)
         x, xr = fork(x, 2)
         n3 = LayerNormRowsFn.apply(x, layer.norm3.weight, layer.norm3.bias, layer.norm3.eps)
         hm = dropout(ActFn.apply(LinearFn.apply(n3, layer.mlp[0].weight, layer.mlp[0].bias), ops.ACT_GELU), pd, tr)

@@ -265,34 +265,96 @@ class BgemmFn(torch.autograd.Function):
     inner stride); transX -> the stored matrix is the transpose of the operand."""
 
     @staticmethod
-    def forward(ctx, A, B, transA, transB):
+    def forward(ctx, A, B, transA, transB, alpha=1.0):
         batch = A.shape[0]
         M, K = (A.shape[2], A.shape[1]) if transA else (A.shape[1], A.shape[2])
         N = B.shape[1] if transB else B.shape[2]
         assert A.stride(2) == 1 and B.stride(2) == 1 and B.shape[0] == batch
-        out = bgemm(A, B, M, N, K, A.stride(1), B.stride(1), transA, transB, A.stride(0), B.stride(0), batch)
+        out = bgemm(A, B, M, N, K, A.stride(1), B.stride(1), transA, transB, A.stride(0), B.stride(0), batch, alpha=alpha)
         ctx.save_for_backward(A, B)
-        ctx.tA, ctx.tB, ctx.dims = transA, transB, (M, N, K, batch)
+        ctx.tA, ctx.tB, ctx.dims, ctx.alpha = transA, transB, (M, N, K, batch), alpha
         return out
 
     @staticmethod
     def backward(ctx, dC):
         A, B = ctx.saved_tensors
-        tA, tB = ctx.tA, ctx.tB
+        tA, tB, al = ctx.tA, ctx.tB, ctx.alpha
         M, N, K, batch = ctx.dims
         dC = dC.contiguous()
         dA = dB = None
         if ctx.needs_input_grad[0]:
             if not tA:  # dA [M,K] = dC [M,N] . op(B)^T [N,K]
-                dA = bgemm(dC, B, M, K, N, N, B.stride(1), False, not tB, M * N, B.stride(0), batch)
+                dA = bgemm(dC, B, M, K, N, N, B.stride(1), False, not tB, M * N, B.stride(0), batch, alpha=al)
             else:       # dA stored [K,M] = op(B) [K,N] . dC^T [N,M]
-                dA = bgemm(B, dC, K, M, N, B.stride(1), N, tB, True, B.stride(0), M * N, batch)
+                dA = bgemm(B, dC, K, M, N, B.stride(1), N, tB, True, B.stride(0), M * N, batch, alpha=al)
         if ctx.needs_input_grad[1]:
             if not tB:  # dB [K,N] = op(A)^T [K,M] . dC [M,N]
-                dB = bgemm(A, dC, K, N, M, A.stride(1), N, not tA, False, A.stride(0), M * N, batch)
+                dB = bgemm(A, dC, K, N, M, A.stride(1), N, not tA, False, A.stride(0), M * N, batch, alpha=al)
             else:       # dB stored [N,K] = dC^T [N,M] . op(A) [M,K]
-                dB = bgemm(dC, A, N, K, M, N, A.stride(1), True, tA, M * N, A.stride(0), batch)
-        return dA, dB, None, None
+                dB = bgemm(dC, A, N, K, M, N, A.stride(1), True, tA, M * N, A.stride(0), batch, alpha=al)
+        return dA, dB, None, None, None
+
+
+class StackRowsFn(torch.autograd.Function):
+    """[A ; brow ; 0] -> [Cm, n]: the (C + 1) live rows of the compact memory's weight image above zero padding; backward = row slices"""
+
+    @staticmethod
+    def forward(ctx, A, brow, Cm):
+        A, brow = A.contiguous(), brow.contiguous()
+        Cr, n = A.shape
+        assert tuple(brow.shape) == (1, n) and Cm > Cr
+        out = torch.empty((Cm, n), device=A.device, dtype=torch.float32)
+        ops.axpby(A, A, 1.0, 0.0, out=out[:Cr])
+        ops.axpby(brow, brow, 1.0, 0.0, out=out[Cr:Cr + 1])
+        if Cm > Cr + 1:
+            z = out[Cr + 1:]
+            src = A.reshape(-1)[:z.numel()].reshape(z.shape) if A.numel() >= z.numel() else None
+            assert src is not None
+            ops.axpby(src, src, 0.0, 0.0, out=z)   # 0 * finite weights: the padding rows
+        ctx.Cr = Cr
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        return d[:ctx.Cr], d[ctx.Cr:ctx.Cr + 1], None
+
+
+class CompactMemFn(torch.autograd.Function):
+    """The compact (C + 1)-row memory of a 64-channel ScoreMapModule level in the TRAINING step (r05; the sampling path has used it
+    since r01): m = [xh r ; r ; 0] with xh = LayerNorm_C(feat), r = (xh^T G xh + 2 h.xh + e + eps)^-1/2 -- the 256-wide projection and
+    its LayerNorm are never materialised ([B, 72, N] instead of two [B, 256, N] tensors per level and pass).  gram / hvec / evar are
+    device-side functions of the memory Linear's weights (unet_autograd._memory_fold), so their gradients flow back to the weights.
+    Forward and backward are one fused launch each (idiff_smm_memproj_compact_train_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, feat, g1, b1, gram, hvec, evar, Cm, eps1, eps2):
+        lib = _lib.load()
+        B, Cc, H, W = feat.shape
+        N = H * W
+        gram, hvec, evar = gram.contiguous(), hvec.contiguous(), evar.contiguous()
+        out = torch.empty((B, Cm, N), device=feat.device, dtype=torch.float32)
+        check(lib.idiff_smm_memproj_compact_train_fwd(_p(feat), _bs(feat, "feat"), _p(_c(g1)), _p(_c(b1)), _p(_c(gram)), _p(_c(hvec)), _p(_c(evar)),
+                                                      _p(out), B, Cc, N, Cm, eps1, eps2, _stream()), "smm_memproj_compact_train_fwd")
+        ctx.save_for_backward(feat, g1, b1, gram, hvec, evar)
+        ctx.geom = (Cm, eps1, eps2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dm):
+        lib = _lib.load()
+        feat, g1, b1, gram, hvec, evar = ctx.saved_tensors
+        Cm, eps1, eps2 = ctx.geom
+        dm = dm.contiguous()
+        B, Cc, H, W = feat.shape
+        N = H * W
+        dfeat = torch.empty((B, Cc, H, W), device=feat.device, dtype=torch.float32)
+        dpar = torch.empty((Cc * Cc + 3 * Cc + 1,), device=feat.device, dtype=torch.float32)
+        ws = torch.empty((lib.idiff_smm_memproj_compact_bwd_ws_floats(B, Cc, N),), device=feat.device, dtype=torch.float32)
+        check(lib.idiff_smm_memproj_compact_bwd(_p(feat), _bs(feat, "feat"), _p(g1), _p(b1), _p(gram), _p(hvec), _p(evar), _p(dm), _p(dfeat),
+                                                Cc * N, _p(dpar), _p(ws), B, Cc, N, Cm, eps1, eps2, _stream()), "smm_memproj_compact_bwd")
+        o = Cc * Cc
+        return (dfeat, dpar[o:o + Cc], dpar[o + Cc:o + 2 * Cc], dpar[:o].reshape(Cc, Cc), dpar[o + 2 * Cc:o + 3 * Cc],
+                dpar[o + 3 * Cc:o + 3 * Cc + 1].reshape(evar.shape), None, None, None)
 
 
 class HeadFoldFn(torch.autograd.Function):
@@ -435,12 +497,12 @@ class SmmXattnFn(torch.autograd.Function):
             shared["pending"] = shared.get("pending", 0) + 1
         B, R, Cm = qf.shape
         N = mem.shape[2]
-        assert Cm == 256 and tuple(mem.shape[:2]) == (B, 256) and R <= 32
+        assert Cm in (72, 256) and tuple(mem.shape[:2]) == (B, Cm) and R <= 32   # 72: the compact (C + 1)-row memory of a 64-channel level
         o = torch.empty_like(qf)
         lse = torch.empty((B, R), device=qf.device, dtype=torch.float32)
-        ws = torch.empty((lib.idiff_smm_xattn_ws_floats(B, R, 1, 256, N),), device=qf.device, dtype=torch.float32)
-        with _prof("smm_xattn_fwd", 2 * 2.0 * 32 * 256 * N * B):  # S = qf.mem, o = P.mem^T; query rows padded to the 32-row MFMA tile
-            check(lib.idiff_smm_xattn_lse_fwd(_p(qf), _p(mem), _p(o), _p(lse), _p(ws), B, R, N, scale, _stream()), "smm_xattn_lse_fwd")
+        ws = torch.empty((lib.idiff_smm_xattn_ws_floats(B, R, 1, Cm, N),), device=qf.device, dtype=torch.float32)
+        with _prof("smm_xattn_fwd", 2 * 2.0 * 32 * Cm * N * B):  # S = qf.mem, o = P.mem^T; query rows padded to the 32-row MFMA tile
+            check(lib.idiff_smm_xattn_cm_lse_fwd(_p(qf), _p(mem), _p(o), _p(lse), _p(ws), B, R, Cm, N, scale, _stream()), "smm_xattn_cm_lse_fwd")
         ctx.save_for_backward(qf, mem, o, lse)
         ctx.scale = scale
         return o
@@ -450,7 +512,7 @@ class SmmXattnFn(torch.autograd.Function):
         lib = _lib.load()
         qf, mem, o, lse = ctx.saved_tensors
         d_o = d_o.contiguous()
-        B, R, _ = qf.shape
+        B, R, Cm = qf.shape
         N = mem.shape[2]
         dqf = torch.empty_like(qf)
         sh = ctx.shared
@@ -468,10 +530,10 @@ class SmmXattnFn(torch.autograd.Function):
                 sh["pending"], sh["buf"] = 0, None
                 raise RuntimeError("SmmXattnFn: more backward than forward calls on a shared memory gradient (retain_graph / double "
                                    "backward is not supported by the shared-gradient form; pass shared=None)")
-        ws = torch.empty((lib.idiff_smm_xattn_ws_floats(B, R, 1, 256, N),), device=qf.device, dtype=torch.float32)
-        with _prof("smm_xattn_bwd", 5 * 2.0 * 32 * 256 * N * B):  # S, dP, dqf, do^T P, qf^T G: five [32 x 256] products per key
-            check(lib.idiff_smm_xattn_bwd(_p(qf), _p(mem), _p(o), _p(lse), _p(d_o), _p(dqf), _p(dmem), acc, _p(ws), B, R, N, ctx.scale, _stream()),
-                  "smm_xattn_bwd")
+        ws = torch.empty((lib.idiff_smm_xattn_ws_floats(B, R, 1, Cm, N),), device=qf.device, dtype=torch.float32)
+        with _prof("smm_xattn_bwd", 5 * 2.0 * 32 * Cm * N * B):  # S, dP, dqf, do^T P, qf^T G: five [32 x Cm] products per key
+            check(lib.idiff_smm_xattn_cm_bwd(_p(qf), _p(mem), _p(o), _p(lse), _p(d_o), _p(dqf), _p(dmem), acc, _p(ws), B, R, Cm, N, ctx.scale,
+                                             _stream()), "smm_xattn_cm_bwd")
         if sh is not None:
             if sh["pending"] > 0:
                 return dqf, None, None, None   # the sum is still growing: the last call to run returns it

@@ -486,6 +486,11 @@ def test_hidden_register_loads_of_conv_wino4_are_only_touched_behind_a_wait(tmp_
         r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "lint_asm_loads.py"), str(asm), sym], capture_output=True, text=True)
         assert r.returncode == 0 and "violations: 0" in r.stdout, r.stdout[-2000:]
         assert "asm register loads: 0 " not in r.stdout   # the lint did see them
+    # r05: the item-crossing pipeline COUNTS an epilogue's stores (s_waitcnt vmcnt(NL + 16)) instead of draining them --
+    # scripts/lint_asm_stores.py walks the control-flow graph of every non-RAG instantiation (plain, prologue, two sources, upsample) and
+    # requires exactly 16 + 4 buffer stores on every path of an item-loop iteration, for both wave-class bodies
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "lint_asm_stores.py"), str(asm)], capture_output=True, text=True)
+    assert r.returncode == 0 and "symbols: 4 violations: 0" in r.stdout, r.stdout[-3000:]
 
 
 def test_pointer_rebuilt_from_a_signed_low_half_breaks_when_bit_31_is_set():

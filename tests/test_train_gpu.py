@@ -592,14 +592,18 @@ def test_training_gradients_are_the_same_bits_from_run_to_run():
         assert torch.equal(a, b), "flat gradient buffers differ from run to run"
 
 
-@pytest.mark.parametrize("B,R,N", [(2, 20, 1024), (1, 20, 4096 + 32), (3, 7, 96), (2, 32, 65536)])
-def test_fused_scoremap_cross_attention_forward_backward_vs_fp64(B, R, N):
+@pytest.mark.parametrize("B,R,N,Cm", [(2, 20, 1024, 256), (1, 20, 4096 + 32, 256), (3, 7, 96, 256), (2, 32, 65536, 256),
+                                      (2, 20, 1024, 72), (1, 20, 4096 + 32, 72), (3, 7, 96, 72), (2, 20, 65536, 72)])
+def test_fused_scoremap_cross_attention_forward_backward_vs_fp64(B, R, N, Cm):
     """SmmXattnFn (training path): o and lse of the flash-decoding forward, dqf and dmem of the one-pass fused backward, against
-    fp64 autograd of softmax(scale * qf mem) mem^T; the key split of the big case covers 64 splits with the fixed-order combine."""
+    fp64 autograd of softmax(scale * qf mem) mem^T; the key split of the big case covers 64 splits with the fixed-order combine.
+    Cm = 72: the compact (C + 1)-row memory of the 64-channel levels (r05), padding rows zero as the memory projection leaves them."""
     g = _g(90 + R)
-    qf = (torch.randn(B, R, 256, generator=g) * 0.3)
-    mem = torch.randn(B, 256, N, generator=g)
-    do = torch.randn(B, R, 256, generator=g)
+    qf = (torch.randn(B, R, Cm, generator=g) * 0.3)
+    mem = torch.randn(B, Cm, N, generator=g)
+    do = torch.randn(B, R, Cm, generator=g)
+    if Cm == 72:
+        mem[:, 65:] = 0.0
     scale = 0.125
     q64, m64 = qf.double().requires_grad_(True), mem.double().requires_grad_(True)
     s = torch.einsum('brc,bcn->brn', q64, m64) * scale
@@ -610,7 +614,7 @@ def test_fused_scoremap_cross_attention_forward_backward_vs_fp64(B, R, N):
     o.backward(do.to(DEV))
     for name, got, ref, tol in (("o", o, o64, 2e-5), ("dqf", qd.grad, q64.grad, 5e-5), ("dmem", md.grad, m64.grad, 5e-5)):
         e = float((got.detach().cpu().double() - ref.detach()).abs().max() / ref.detach().abs().max())
-        print(f"fused cross-attention B={B} R={R} N={N}: {name} rel err {e:.2e}")
+        print(f"fused cross-attention B={B} R={R} N={N} Cm={Cm}: {name} rel err {e:.2e}")
         assert e < tol, (name, e)
 
 
@@ -736,3 +740,37 @@ def test_token_side_fused_functions_vs_torch_autograd():
     assert _rel(a, ar) < 3e-6 and _rel(xd.grad, xr.grad) < 1e-5
     for wd_, wr_ in zip(wds, wrs):
         assert _rel(wd_.grad, wr_.grad) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 16, 16), (1, 24, 40), (3, 8, 8)])
+def test_compact_memory_function_forward_backward_vs_fp64(B, H, W):
+    """CompactMemFn (r05: the (C + 1)-row memory of the 64-channel levels in the TRAINING step): m = [xh r ; r ; 0] and its fused
+    backward -- dfeat and the gradients of the LayerNorm affine, the Gram matrix, hvec and evar (summed over all pixels through
+    per-workgroup partial rows) -- against fp64 autograd of the plain formula."""
+    g = _g(61)
+    C, Cm, N = 64, 72, H * W
+    feat = torch.randn(B, C, H, W, generator=g)
+    g1, b1 = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    Wm = torch.randn(256, C, generator=g) * 0.15
+    bm = torch.randn(256, generator=g) * 0.1
+    gram, hvec, evar = ops.memory_variance_form(Wm.to(DEV), bm.to(DEV))
+    gram, hvec = gram.cpu(), hvec.cpu()
+    dm = torch.randn(B, Cm, N, generator=g)
+    leaves = [_leaf(feat), _leaf(g1), _leaf(b1), _leaf(gram), _leaf(hvec), _leaf(torch.tensor([[[evar]]]))]
+    m = T.CompactMemFn.apply(*leaves, Cm, 1e-5, 1e-5)
+    m.backward(dm.to(DEV))
+    ref = [t.double().requires_grad_(True) for t in (feat, g1, b1, gram, hvec, torch.tensor([[[evar]]]))]
+    x = ref[0].reshape(B, C, N)
+    mu = x.mean(1, keepdim=True)
+    xn = (x - mu) / torch.sqrt(((x - mu) ** 2).mean(1, keepdim=True) + 1e-5)
+    xh = xn * ref[1][None, :, None] + ref[2][None, :, None]
+    v = torch.einsum('bcn,cd,bdn->bn', xh, ref[3], xh) + 2 * torch.einsum('c,bcn->bn', ref[4], xh) + ref[5].reshape(())
+    r = (v + 1e-5).rsqrt()
+    mr = torch.cat([xh * r[:, None], r[:, None], torch.zeros(B, Cm - C - 1, N, dtype=torch.float64)], 1)
+    mr.backward(dm.double())
+    assert _rel(m, mr) < 3e-6
+    for name, a, b_ in zip(("dfeat", "dg1", "db1", "dgram", "dhvec", "devar"), leaves, ref):
+        e = _rel(a.grad, b_.grad)
+        print(f"compact memory B={B} {H}x{W}: {name} rel err {e:.2e}")
+        # devar = sum of dv over all pixels: a signed sum with cancellation (its relative error is that of the terms times |sum|dv|| / |sum dv|)
+        assert e < (2e-3 if name == "devar" else 5e-5), (name, e)
