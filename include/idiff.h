@@ -360,6 +360,12 @@ int idiff_scoremap_grouped_fwd(const idiff_scoremap_group* groups, int ngroups, 
  * w [K,C,3,3] (torch layout), bias [K] or NULL, idx int32 [B] in [0,K), out [B,1,H,W]. */
 int idiff_conv3x3_select_fwd(const float* x, int64_t x_bstride, const float* w, const float* bias, const int32_t* idx, float* out,
                              int B, int C, int K, int H, int W, idiff_stream_t stream);
+/* Its backward (training step): dx [B,C,H,W] (dx_bstride) = the transposed conv of dpred [B,1,H,W] with each sample's class kernel,
+ * dw [K,C,3,3] / db [K] (db may be NULL) = sums over the samples of each class (classes without a sample get zeros); either of dx / dw
+ * may be NULL.  W % 4 == 0.  ws: idiff_conv3x3_select_bwd_ws_floats(B, C, H, W) floats (per-tile partials, reduced in a fixed order). */
+int64_t idiff_conv3x3_select_bwd_ws_floats(int B, int C, int H, int W);
+int idiff_conv3x3_select_bwd(const float* x, int64_t x_bstride, const float* w, const int32_t* idx, const float* dpred, float* dx,
+                             int64_t dx_bstride, float* dw, float* db, float* ws, int B, int C, int K, int H, int W, idiff_stream_t stream);
 /* out[b,0,p] = x[b, idx[b], p] */
 int idiff_gather_channel(const float* x, const int32_t* idx, float* out, int B, int C, int HW, idiff_stream_t stream);
 

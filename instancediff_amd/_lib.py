@@ -113,6 +113,8 @@ SIGNATURES = {
     "idiff_scoremap_grouped_fwd": (I, [C.POINTER(ScoremapGroup), I, P, I, I, c_stream]),
     "idiff_gather_channel": (I, [P, P, P, I, I, I, c_stream]),
     "idiff_conv3x3_select_fwd": (I, [P, I64, P, P, P, P, I, I, I, I, I, c_stream]),
+    "idiff_conv3x3_select_bwd_ws_floats": (I64, [I, I, I, I]),
+    "idiff_conv3x3_select_bwd": (I, [P, I64, P, P, P, P, I64, P, P, P, I, I, I, I, I, c_stream]),
     "idiff_irsde_reverse_step": (I, [P, P, P, P, P, I64, F, F, F, F, F, I, U64, U64, c_stream]),
     "idiff_irsde_map": (I, [I, P, P, P, P, F, P, I, I64, P, C.POINTER(C.c_float), U64, U64, c_stream]),
     "idiff_drift_reverse_step": (I, [P, P, P, P, P, P, P, I64, F, F, F, U64, U64, c_stream]),

@@ -293,8 +293,12 @@ def forward_train(net, x_a, x_b, t, names, text_encoder, image_context=None):
         mode = ops.CONV_UPSAMPLE2 if type(u).__name__ == "Upsample" else ops.CONV_NORMAL
         x = ConvFn.apply(x, None, u.conv.weight, u.conv.bias, 3, mode)
     x = _resblock(net.final_res, x, x_, tacts.pop())
-    out = ConvFn.apply(x, None, net.final_conv.weight, net.final_conv.bias, 3, ops.CONV_NORMAL)
-    pred = GatherChannelFn.apply(out, idx)
+    if x.shape[3] % 4 == 0 and x.shape[1] <= 256:
+        from ...train_ops import SelectConvFn
+        pred = SelectConvFn.apply(x, net.final_conv.weight, net.final_conv.bias, idx)   # output conv + class pick, one channel per sample
+    else:
+        out = ConvFn.apply(x, None, net.final_conv.weight, net.final_conv.bias, 3, ops.CONV_NORMAL)
+        pred = GatherChannelFn.apply(out, idx)
     if net.text_module == "scoremap":
         return pred, sms
     return pred

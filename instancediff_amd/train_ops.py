@@ -855,6 +855,35 @@ class ScaleColsFn(torch.autograd.Function):
         return dx, dg
 
 
+class SelectConvFn(torch.autograd.Function):
+    """The UNet's output layer fused with the class pick, as in the sampling path: pred[b] = conv3x3(x[b]; w[idx[b]]) + bias[idx[b]] -- ONE
+    output channel per sample (the reference computes out_nc = 5 and keeps one, models/drift_noise_model.py:250-268).  Backward = the
+    transposed conv with the sample's kernel and per-class sums of g * X (idiff_conv3x3_select_bwd): no [B,5,H,W] tensors, no scatter,
+    no matrix-core tiles padded from 5 channels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, idx):
+        ctx.save_for_backward(x, weight, idx)
+        ctx.has_bias = bias is not None
+        return ops.conv3x3_select(x, weight.detach().contiguous(), bias, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, weight, idx = ctx.saved_tensors
+        g = g.contiguous()
+        B, Cc, H, W = x.shape
+        K = weight.shape[0]
+        dx = torch.empty((B, Cc, H, W), device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        dw = torch.empty_like(weight) if need_w else None
+        db = torch.empty((K,), device=x.device, dtype=torch.float32) if (need_w and ctx.has_bias) else None
+        ws = torch.empty((lib.idiff_conv3x3_select_bwd_ws_floats(B, Cc, H, W),), device=x.device, dtype=torch.float32) if need_w else None
+        check(lib.idiff_conv3x3_select_bwd(_p(x), _bs(x, "x"), _p(_c(weight.detach())), C.c_void_p(idx.data_ptr()), _p(g), _p(dx), Cc * H * W, _p(dw),
+                                           _p(db), _p(ws), B, Cc, K, H, W, _stream()), "conv3x3_select_bwd")
+        return dx, dw, db, None
+
+
 class GatherChannelFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, idx):

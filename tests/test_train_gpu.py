@@ -774,3 +774,26 @@ def test_compact_memory_function_forward_backward_vs_fp64(B, H, W):
         print(f"compact memory B={B} {H}x{W}: {name} rel err {e:.2e}")
         # devar = sum of dv over all pixels: a signed sum with cancellation (its relative error is that of the terms times |sum|dv|| / |sum dv|)
         assert e < (2e-3 if name == "devar" else 5e-5), (name, e)
+
+
+@pytest.mark.parametrize("B,C,K,H,W", [(3, 64, 5, 32, 32), (4, 12, 5, 13, 40), (2, 64, 5, 72, 64)])
+def test_select_conv_function_vs_conv_then_gather_autograd(B, C, K, H, W):
+    """SelectConvFn (r05: the output layer fused with the class pick in the training step too): forward, data gradient and per-class
+    weight / bias gradients against fp64 autograd of conv2d(x, w, b) followed by the per-sample channel gather; one class has no
+    sample (its gradients must be exact zeros), one has two."""
+    g = _g(71)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) * 0.1
+    bias = torch.randn(K, generator=g) * 0.1
+    idx = torch.tensor([3, 0, 3, 1][:B], dtype=torch.int32)
+    up = torch.randn(B, 1, H, W, generator=g)
+    xd, wd, bd = _leaf(x), _leaf(w), _leaf(bias)
+    pred = T.SelectConvFn.apply(xd, wd, bd, idx.to(DEV))
+    pred.backward(up.to(DEV))
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), bias.double().requires_grad_(True)
+    full = F.conv2d(xr, wr, br, padding=1)
+    ref = full[torch.arange(B), idx.long()][:, None]
+    ref.backward(up.double())
+    assert _rel(pred, ref) < 3e-6 and _rel(xd.grad, xr.grad) < 3e-6 and _rel(wd.grad, wr.grad) < 1e-5 and _rel(bd.grad, br.grad) < 1e-5
+    unused = [k for k in range(K) if k not in idx.tolist()]
+    assert float(wd.grad[unused].abs().max()) == 0.0 and float(bd.grad[unused].abs().max()) == 0.0
