@@ -488,6 +488,13 @@ int idiff_colsum(const float* x, int64_t ldx, float* out, int R, int N, int accu
 /* out[r,n] = x[r,n]*g[n]  and  out[n] = sum_r x[r,n]*y[r,n]  (dense [R,N]; ScoreMapModule gamma and its gradient) */
 int idiff_scale_cols(const float* x, const float* g, float* out, int R, int N, idiff_stream_t stream);
 int idiff_colsum_prod(const float* x, const float* y, float* out, int R, int N, idiff_stream_t stream);
+/* Grouped forms for STACKED token matrices (r05: the same layer of a net's four ScoreMapModule decoders as one [groups * Rg, .] matrix):
+ * R rows in `groups` equal groups, each with its own parameter / output row -- gamma, beta, dgamma, dbeta [groups][C]; out [groups][N]. */
+int idiff_layernorm_rows_g_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out, int64_t ldo, int R, int C,
+                               float eps, float* mean_rstd, int groups, idiff_stream_t stream);
+int idiff_layernorm_rows_g_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean_rstd,
+                               float* dx, int64_t lddx, float* dgamma, float* dbeta, int R, int C, int groups, idiff_stream_t stream);
+int idiff_colsum_g(const float* x, int64_t ldx, float* out, int R, int N, int groups, idiff_stream_t stream);
 int idiff_layernorm_rows_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                              const float* mean_rstd, float* dx, int64_t lddx, float* dgamma, float* dbeta, int R, int C,
                              int accumulate, idiff_stream_t stream);
@@ -511,6 +518,10 @@ int64_t idiff_bgemm_ws_floats(int M, int N, int K, int batch); /* 0 unless the s
 int idiff_bgemm(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
                 int transA, int transB, int64_t sA, int64_t sB, int64_t sC, int batch, float alpha, float beta, float* ws,
                 idiff_stream_t stream);
+/* the same with a per-column bias per batch entry (colbias [batch][N] with batch stride sbias, or NULL), beta = 0, no K split */
+int idiff_bgemm_bias(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int transA,
+                     int transB, int64_t sA, int64_t sB, int64_t sC, int batch, float alpha, const float* colbias, int64_t sbias,
+                     idiff_stream_t stream);
 /* y [R,N] = x [R,K] . w [N,K]^T (+ bias [N] or NULL) through the same kernel: the training path's token-side linear layers
  * (reference: nn.Linear inside TransformerDecoderLayer / ContextDecoder, models/modules/_modified_BiomedCLIP.py); any R */
 int idiff_linear_mfma_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* out, int64_t ldo, int R,

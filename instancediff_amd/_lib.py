@@ -150,6 +150,10 @@ SIGNATURES = {
     "idiff_scatter_channel": (I, [P, P, P, I, I, I, c_stream]),
     "idiff_bgemm_ws_floats": (I64, [I, I, I, I]),
     "idiff_bgemm": (I, [P, P, P, I, I, I, I64, I64, I64, I, I, I64, I64, I64, I, F, F, P, c_stream]),
+    "idiff_bgemm_bias": (I, [P, P, P, I, I, I, I64, I64, I64, I, I, I64, I64, I64, I, F, P, I64, c_stream]),
+    "idiff_layernorm_rows_g_fwd": (I, [P, I64, P, P, P, I64, I, I, F, P, I, c_stream]),
+    "idiff_layernorm_rows_g_bwd": (I, [P, I64, P, I64, P, P, P, I64, P, P, I, I, I, c_stream]),
+    "idiff_colsum_g": (I, [P, I64, P, I, I, I, c_stream]),
     "idiff_linear_mfma_fwd": (I, [P, I64, P, I64, P, P, I64, I, I, I, c_stream]),
     "idiff_softmax_rows_fwd": (I, [P, I64, P, I64, I, I, F, c_stream]),
     "idiff_softmax_rows_bwd": (I, [P, I64, P, I64, P, I64, I, I, F, c_stream]),

@@ -215,9 +215,11 @@ __device__ __forceinline__ float colsum_lanes(float v, float (&red)[CS_LANES][CS
     __syncthreads();
     return t;  // valid on row lane 0
 }
-// out[n] (+)= sum_r x[r, n]
+// out[n] (+)= sum_r x[r, n]   (blockIdx.y = group of R rows with its own output row: the stacked decoders' bias gradients)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long long ldx, float* __restrict__ out, int R, int N, int accumulate) {
     __shared__ float red[CS_LANES][CS_COLS + 1];
+    x += (long long)blockIdx.y * R * ldx;
+    out += (long long)blockIdx.y * N;
     const int n = blockIdx.x * CS_COLS + threadIdx.x % CS_COLS, rl = threadIdx.x / CS_COLS;
     float s = 0.f;
     if (n < N)
@@ -245,10 +247,11 @@ __global__ __launch_bounds__(256) void colsum_prod_kernel(const float* __restric
 // LayerNorm rows backward: dx (wave per row) ; dgamma/dbeta by a column pass
 __global__ __launch_bounds__(256) void ln_rows_bwd_dx_kernel(const float* __restrict__ dy, long long lddy, const float* __restrict__ x,
                                                              long long ldx, const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
-                                                             float* __restrict__ dx, long long lddx, int R, int C) {
+                                                             float* __restrict__ dx, long long lddx, int R, int C, int rpg = 0) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
+    if (rpg > 0) gamma += (long long)(r / rpg) * C;  // grouped form: a gamma row per group of rpg rows
     const float mean = mean_rstd[2 * r], rstd = mean_rstd[2 * r + 1];
     const float* dyr = dy + (long long)r * lddy;
     const float* xr = x + (long long)r * ldx;
@@ -269,6 +272,12 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_param_kernel(const float* __r
                                                                 const float* __restrict__ mean_rstd, float* __restrict__ dgamma,
                                                                 float* __restrict__ dbeta, int R, int C, int accumulate) {
     __shared__ float red[CS_LANES][CS_COLS + 1];
+    // blockIdx.y = group of R rows with its own dgamma / dbeta row
+    dy += (long long)blockIdx.y * R * lddy;
+    x += (long long)blockIdx.y * R * ldx;
+    mean_rstd += (long long)blockIdx.y * R * 2;
+    dgamma += (long long)blockIdx.y * C;
+    dbeta += (long long)blockIdx.y * C;
     const int c = blockIdx.x * CS_COLS + threadIdx.x % CS_COLS, rl = threadIdx.x / CS_COLS;
     float dg = 0.f, db = 0.f;
     if (c < C)
@@ -739,6 +748,23 @@ extern "C" int idiff_colsum(const float* x, int64_t ldx, float* out, int R, int 
     IDIFF_CHECK_ARG(x && out && R > 0 && N > 0 && ldx >= N, "colsum: bad args");
     hipLaunchKernelGGL(colsum_kernel, dim3((N + CS_COLS - 1) / CS_COLS), dim3(256), 0, ST, x, (long long)ldx, out, R, N, accumulate);
     IDIFF_CHECK_LAUNCH("colsum");
+    return IDIFF_OK;
+}
+extern "C" int idiff_colsum_g(const float* x, int64_t ldx, float* out, int R, int N, int groups, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(x && out && R > 0 && N > 0 && ldx >= N && groups > 0 && R % groups == 0, "colsum_g: R must be a multiple of groups");
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + CS_COLS - 1) / CS_COLS, groups), dim3(256), 0, ST, x, (long long)ldx, out, R / groups, N, 0);
+    IDIFF_CHECK_LAUNCH("colsum_g");
+    return IDIFF_OK;
+}
+extern "C" int idiff_layernorm_rows_g_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean_rstd,
+                                          float* dx, int64_t lddx, float* dgamma, float* dbeta, int R, int C, int groups, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(dy && x && gamma && mean_rstd && dx && dgamma && dbeta && R > 0 && C > 0 && groups > 0 && R % groups == 0, "layernorm_rows_g_bwd: bad args");
+    hipLaunchKernelGGL(ln_rows_bwd_dx_kernel, dim3((R + 3) / 4), dim3(256), 0, ST, dy, (long long)lddy, x, (long long)ldx, gamma, mean_rstd, dx,
+                       (long long)lddx, R, C, R / groups);
+    IDIFF_CHECK_LAUNCH("layernorm_rows_g_bwd_dx");
+    hipLaunchKernelGGL(ln_rows_bwd_param_kernel, dim3((C + CS_COLS - 1) / CS_COLS, groups), dim3(256), 0, ST, dy, (long long)lddy, x, (long long)ldx, mean_rstd,
+                       dgamma, dbeta, R / groups, C, 0);
+    IDIFF_CHECK_LAUNCH("layernorm_rows_g_bwd_param");
     return IDIFF_OK;
 }
 extern "C" int idiff_scale_cols(const float* x, const float* g, float* out, int R, int N, idiff_stream_t stream) {

@@ -174,12 +174,18 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
 }
 
 // LayerNorm over rows of C elements: one wave per row (two-pass, like ATen's fp32 path)
+// rpg > 0: the rows form groups of rpg rows with their own gamma / beta rows ([groups][C]: the same LayerNorm of several stacked decoders)
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ out, long long ldo, int R,
-                                                             int C, float eps, float* __restrict__ mean_rstd) {
+                                                             int C, float eps, float* __restrict__ mean_rstd, int rpg = 0) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
+    if (rpg > 0) {
+        const int grp = r / rpg;
+        if (gamma) gamma += (long long)grp * C;
+        if (beta) beta += (long long)grp * C;
+    }
     const float* xr = x + (long long)r * ldx;
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += xr[c];
@@ -498,8 +504,16 @@ extern "C" int idiff_layernorm_rows_fwd(const float* x, int64_t ldx, const float
                                         int C, float eps, float* mean_rstd, idiff_stream_t stream) {
     IDIFF_CHECK_ARG(x && out && R > 0 && C > 0, "layernorm_rows: bad args");
     hipLaunchKernelGGL(layernorm_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, (long long)ldx, gamma, beta, out,
-                       (long long)ldo, R, C, eps, mean_rstd);
+                       (long long)ldo, R, C, eps, mean_rstd, 0);
     IDIFF_CHECK_LAUNCH("layernorm_rows");
+    return IDIFF_OK;
+}
+extern "C" int idiff_layernorm_rows_g_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* out, int64_t ldo, int R,
+                                          int C, float eps, float* mean_rstd, int groups, idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(x && out && gamma && beta && R > 0 && C > 0 && groups > 0 && R % groups == 0, "layernorm_rows_g: R must be a multiple of groups");
+    hipLaunchKernelGGL(layernorm_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, (long long)ldx, gamma, beta, out,
+                       (long long)ldo, R, C, eps, mean_rstd, R / groups);
+    IDIFF_CHECK_LAUNCH("layernorm_rows_g");
     return IDIFF_OK;
 }
 

@@ -21,7 +21,7 @@ template <int TM, int TN>
 __global__ __launch_bounds__(256) void bgemm_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N,
                                                     int K, long long lda, long long ldb, long long ldc, int transA, int transB, long long sA,
                                                     long long sB, long long sC, float alpha, float beta, int nsplit, int kper,
-                                                    const float* __restrict__ colbias) {
+                                                    const float* __restrict__ colbias, long long sbias = 0) {
     constexpr int WN = TN / 32;  // waves along n; waves along m = 4 / WN = TM / 32
     constexpr int NA = TM * GK / 256, NB = TN * GK / 256;
     __shared__ float As[GK][TM + 1];
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const float* __restrict__ A,
     }
     const int n = n0 + wn * 32 + l31;
     if (n < N) {
-        const float cb = colbias ? colbias[n] : 0.f;
+        const float cb = colbias ? colbias[(long long)bz * sbias + n] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -193,6 +193,28 @@ extern "C" int idiff_bgemm(const float* A, const float* B, float* C, int M, int 
         hipLaunchKernelGGL(bgemm_reduce_kernel, grid, dim3(256), 0, st, ws, C, M, N, (long long)ldc, (long long)sC, ns, beta);
         IDIFF_CHECK_LAUNCH("bgemm_reduce");
     }
+    return IDIFF_OK;
+}
+
+// idiff_bgemm with a per-column bias per batch entry (colbias [batch][N], batch stride sbias): the stacked token-side linears of the
+// training step (r05: the same layer of a net's four ScoreMapModule decoders as ONE batch-4 launch).  No K split (K <= 1024 there).
+extern "C" int idiff_bgemm_bias(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int transA,
+                                int transB, int64_t sA, int64_t sB, int64_t sC, int batch, float alpha, const float* colbias, int64_t sbias,
+                                idiff_stream_t stream) {
+    IDIFF_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535, "bgemm_bias: bad args");
+    IDIFF_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "bgemm_bias: bad leading dims");
+    hipStream_t st = (hipStream_t)stream;
+    const int kper = ((K + GK - 1) / GK) * GK;
+    if (M <= 32) {
+        dim3 grid((N + 127) / 128, (M + 31) / 32, batch);
+        hipLaunchKernelGGL((bgemm_kernel<32, 128>), grid, dim3(256), 0, st, A, B, C, M, N, K, (long long)lda, (long long)ldb, (long long)ldc, transA, transB,
+                           (long long)sA, (long long)sB, (long long)sC, alpha, 0.f, 1, kper, colbias, (long long)sbias);
+    } else {
+        dim3 grid((N + 63) / 64, (M + 63) / 64, batch);
+        hipLaunchKernelGGL((bgemm_kernel<64, 64>), grid, dim3(256), 0, st, A, B, C, M, N, K, (long long)lda, (long long)ldb, (long long)ldc, transA, transB,
+                           (long long)sA, (long long)sB, (long long)sC, alpha, 0.f, 1, kper, colbias, (long long)sbias);
+    }
+    IDIFF_CHECK_LAUNCH("bgemm_bias");
     return IDIFF_OK;
 }
 

@@ -139,6 +139,7 @@ def _smm(smm, feat, text_encoder, idx, feat_n=None):
         Cm = 72
         pts, gram, hvec, evar = _memory_fold(mp, Cm, 2 * len(dec.decoder))
         pts = list(pts)
+        b2rows = list(fork(mp[2].bias[None, :], len(dec.decoder)))  # a parameter with several consumers is forked too (no ATen accumulate)
         mem = CompactMemFn.apply(feat, mp[0].weight, mp[0].bias, gram, hvec, evar, Cm, mp[0].eps, mp[2].eps)
     else:
         fn = ChanLayerNormFn.apply(feat, mp[0].weight, mp[0].bias, mp[0].eps)
@@ -181,14 +182,16 @@ def _smm(smm, feat, text_encoder, idx, feat_n=None):
         # All heads' query rows are stacked ([B, K*heads, Wd]) so `mem` is read once per product, not once per head.
         if compact:
             # mem = P m + b2: fold P into the k / v weights (S = q Wk P m up to a per-row constant; o_256 = P (sum_n p_n m_n) + b2)
+            wv_a, wv_b = fork(ca.v_proj.weight, 2)
+            wp_a, wp_b = fork(ca.proj.weight, 2)
             wkf = BgemmFn.apply(ca.k_proj.weight[None], pts.pop()[None], False, True).reshape(Wd, Cm)   # Wk P
-            wvp = BgemmFn.apply(ca.v_proj.weight[None], pts.pop()[None], False, True).reshape(Wd, Cm)   # Wv P
-            bvf = LinearFn.apply(mp[2].bias[None, :], ca.v_proj.weight, None)              # b2 Wv^T [1, Wd]: the softmax weights sum to 1
-            pbias = LinearFn.apply(bvf, ca.proj.weight, ca.proj.bias).reshape(Wd)          # ... carried through the output projection
+            wvp = BgemmFn.apply(wv_a[None], pts.pop()[None], False, True).reshape(Wd, Cm)               # Wv P
+            bvf = LinearFn.apply(b2rows.pop(), wv_b, None)                                 # b2 Wv^T [1, Wd]: the softmax weights sum to 1
+            pbias = LinearFn.apply(bvf, wp_a, ca.proj.bias).reshape(Wd)                    # ... carried through the output projection
             qf = HeadFoldFn.apply(qc, wkf, heads, "in").reshape(B, K * heads, Cm)          # row = k*heads + h
             o = SmmXattnFn.apply(qf, mem, ca.scale, mem_grad)
             av = HeadFoldFn.apply(o.reshape(R, heads, Cm), wvp, heads, "out")              # [R, Wd]
-            x = AddFn.apply(xr, branch(dropout(LinearFn.apply(av, ca.proj.weight, pbias), pd, tr), g_ca), 1.0)
+            x = AddFn.apply(xr, branch(dropout(LinearFn.apply(av, wp_b, pbias), pd, tr), g_ca), 1.0)
         else:
             qf = HeadFoldFn.apply(qc, ca.k_proj.weight, heads, "in").reshape(B, K * heads, Wd)   # row = k*heads + h
             if fused_x:

@@ -1,0 +1,20 @@
+#!/bin/bash
+# r05 collection, part A (part B = `IDIFF_ROUND=r05 bash scripts/collect_profiles.sh gpurun_out/r05/c1` in a call of its own: PMC table ->
+# kernel stats -> secondary lines -> training profile -> MFMA utilisation -> headline last): the whole GPU suite in one process, smoke,
+# the training iteration's single-stream stats, the 2-rank rehearsal of the default line (training leg across ranks)
+set -u
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=${1:-gpurun_out/r05/c1}; mkdir -p $O
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/t_smoke_final.log 2>&1; tail -2 $O/t_smoke_final.log
+timeout -k 10 1000 python -m pytest tests -x -q -m gpu > $O/t_gpu_tests_final.log 2>&1; rc=$?; tail -3 $O/t_gpu_tests_final.log; [ $rc -eq 0 ] || { tail -40 $O/t_gpu_tests_final.log; exit 1; }
+export IDIFF_TRAIN_TWO_STREAMS=0
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python3 bench.py --mode train --batch 32 --steps 3 --warmup 2 --no-roofline > $O/stats1.log 2>&1
+cp $(find $O/stats1 -name "*kernel_stats.csv" | head -1) $O/train_kernel_stats_single_stream.csv; rm -rf $O/stats1
+python3 - $O/train_kernel_stats_single_stream.csv <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+print("training, single stream: %.1f ms of kernels per iteration, %d launches" % (sum(float(r["TotalDurationNs"]) for r in rows) / 5e6, sum(int(r["Calls"]) for r in rows) / 5))
+PY
+unset IDIFF_TRAIN_TWO_STREAMS
+IDIFF_BENCH_REHEARSAL=1 timeout -k 10 600 python3 bench.py --gpus 2 --no-cpu-baseline --no-roofline > $O/a_bench_gpus2_default_line_rehearsal.json 2> $O/a_bench_gpus2_default_line_rehearsal.err; echo "rehearsal rc=$?"
+ls $O
