@@ -6,9 +6,10 @@ import torch
 
 from ... import ops
 from .MSM_degEmb_Unet import branch_gains
-from ...train_ops import (ActFn, AddFn, AddVecFn, BgemmFn, ChanLayerNormFn, ChanNormalizeFn, CompactMemFn, ConvFn, GatherChannelFn, HeadFoldFn,
-                          LayerNormRowsFn, Linear3Fn, LinearFn, ResBlockFn, ScaleColsFn, SkipCatFn, SmmXattnFn, SoftmaxRowsFn, StackRowsFn,
-                          TokenAttnFn, _Slot, dropout, fork)
+from ...train_ops import (ActFn, AddFn, AddVecFn, BLayerNormFn, BLinear3Fn, BLinearFn, BgemmFn, ChanLayerNormFn, ChanNormalizeFn, CompactMemFn,
+                          ConvFn, GatherChannelFn, HeadFoldFn, HeadFoldInLFn, HeadFoldOutLFn, JoinFn, LayerNormRowsFn, Linear3Fn, LinearFn,
+                          ResBlockFn, ScaleColsFn, SkipCatFn, SmmXattnFn, SoftmaxRowsFn, StackFn, StackParamsFn, StackRowsFn, TokenAttnFn,
+                          UnstackFn, _Slot, dropout, fork)
 
 
 # IDIFF_FUSED_XATTN=0: the ScoreMapModule cross-attention of the training path as batched GEMMs + softmax (autograd-derived backward)
@@ -16,6 +17,8 @@ import os  # noqa: E402
 FUSED_XATTN = bool(int(os.environ.get("IDIFF_FUSED_XATTN", "1")))
 # IDIFF_TRAIN_COMPACT=0: the 64-channel levels' ScoreMapModules attend to the materialised 256-row memory in the training step too (r04)
 TRAIN_COMPACT = bool(int(os.environ.get("IDIFF_TRAIN_COMPACT", "1")))
+# IDIFF_TRAIN_STACKED=0: every ScoreMapModule's decoder chain by itself, right behind its level (r04 .. first half of r05)
+TRAIN_STACKED = bool(int(os.environ.get("IDIFF_TRAIN_STACKED", "1")))
 _CEN = {}
 
 
@@ -218,6 +221,158 @@ def _smm(smm, feat, text_encoder, idx, feat_n=None):
     return score, sel
 
 
+def _skip_with_embedding(net, i, score, x_skip, skipbuf, din):
+    """the level's skip cat(x, conv3x3(score map)): written in place into the skip buffer where there is one"""
+    if skipbuf is not None:
+        emb = ConvFn.apply(score, None, net.sm_embed[i].weight, net.sm_embed[i].bias, 3, ops.CONV_NORMAL, _Slot(skipbuf[:, din:].detach()))
+        return SkipCatFn.apply(x_skip, emb, _Slot(skipbuf))
+    emb = ConvFn.apply(score, None, net.sm_embed[i].weight, net.sm_embed[i].bias, 3, ops.CONV_NORMAL)
+    return ("cat", x_skip, emb)
+
+
+def _stackable(smms):
+    """the stacked form covers plain ContextDecoders of one geometry (the default model); anything else runs level by level"""
+    if len(smms) < 2:
+        return False
+    d0 = smms[0].context_decoder
+    for m in smms:
+        d = m.context_decoder
+        if type(d).__name__ != "ContextDecoder" or (d.width, d.heads, len(d.decoder), d.dropout) != (d0.width, d0.heads, len(d0.decoder), d0.dropout):
+            return False
+        if (m.n_cls, m.text_dim, m.training) != (smms[0].n_cls, smms[0].text_dim, smms[0].training) or d.width // d.heads > 64 or m.n_cls > 8:
+            return False
+    return True
+
+
+def _smm_all(smms, feats, feats_n, text_encoder, idx):
+    """The ScoreMapModules of a net's L levels with their decoder token chains STACKED (r05): every token-side operation -- the same
+    [B*K, 256]-row LayerNorm / linear / attention of each level, with its own weights -- is ONE batch-L launch forward and backward
+    (weights gathered into [L, ..] stacks by one launch per step, StackParamsFn; BLinearFn / BLinear3Fn / BLayerNormFn; the five-token
+    self-attention over L*B samples), as the sampling path has advanced the four chains in lock step since r03.  Per level remain what
+    sees the image: the memory (compact for 64 channels), the fold of its affine map, the cross-attention over the memory, and the
+    head of the module (out_proj / text_to_visual / score map: the channel count differs).  -> [(score, sel)] per level"""
+    L = len(smms)
+    decs = [m.context_decoder for m in smms]
+    Wd, heads, nlayers = decs[0].width, decs[0].heads, len(decs[0].decoder)
+    dh = Wd // heads
+    B = feats[0].shape[0]
+    K = smms[0].n_cls
+    R = B * K
+    pd, tr = decs[0].dropout, smms[0].training
+    dev = feats[0].device
+    # ---- per level: memory (+ fold) -------------------------------------------------------------------------------------------
+    lv = []
+    for m, dec, feat in zip(smms, decs, feats):
+        Bc, C, H, W = feat.shape
+        N = H * W
+        mp = dec.memory_proj
+        fused_x = FUSED_XATTN and heads * K <= 32 and Wd == 256 and N % 4 == 0
+        compact = TRAIN_COMPACT and fused_x and C == 64
+        e = dict(C=C, N=N, H=H, W=W, fused_x=fused_x, compact=compact, Cm=72 if compact else Wd, mem_grad={}, mp=mp)
+        if compact:
+            pts, gram, hvec, evar = _memory_fold(mp, 72, 2 * nlayers)
+            e["pts"] = list(pts)
+            e["b2rows"] = list(fork(mp[2].bias[None, :], nlayers))
+            e["mem"] = CompactMemFn.apply(feat, mp[0].weight, mp[0].bias, gram, hvec, evar, 72, mp[0].eps, mp[2].eps)
+        else:
+            fn = ChanLayerNormFn.apply(feat, mp[0].weight, mp[0].bias, mp[0].eps)
+            m1 = ConvFn.apply(fn, None, mp[1].weight.reshape(Wd, C, 1, 1), mp[1].bias, 1, ops.CONV_NORMAL)
+            e["mem"] = ChanLayerNormFn.apply(m1, mp[2].weight, mp[2].bias, mp[2].eps).reshape(B, Wd, N)
+        lv.append(e)
+    # ---- stacked parameters: one gather launch ---------------------------------------------------------------------------------
+    kinds, flat = [], []
+
+    def add(name, tensors):
+        kinds.append(name)
+        flat.extend(tensors)
+    add("tp_g", [d.text_proj[0].weight for d in decs]), add("tp_b", [d.text_proj[0].bias for d in decs])
+    add("tp_w", [d.text_proj[1].weight for d in decs]), add("tp_wb", [d.text_proj[1].bias for d in decs])
+    proj_w_rest = []  # per layer, per level: the handle on cross_attn.proj.weight kept for the compact levels' bias fold
+    for li in range(nlayers):
+        lay = [d.decoder[li] for d in decs]
+        add(f"{li}.n1g", [l.norm1.weight for l in lay]), add(f"{li}.n1b", [l.norm1.bias for l in lay])
+        add(f"{li}.wq", [l.self_attn.q_proj.weight for l in lay]), add(f"{li}.wk", [l.self_attn.k_proj.weight for l in lay])
+        add(f"{li}.wv", [l.self_attn.v_proj.weight for l in lay])
+        add(f"{li}.wp", [l.self_attn.proj.weight for l in lay]), add(f"{li}.bp", [l.self_attn.proj.bias for l in lay])
+        add(f"{li}.n2g", [l.norm2.weight for l in lay]), add(f"{li}.n2b", [l.norm2.bias for l in lay])
+        add(f"{li}.wqc", [l.cross_attn.q_proj.weight for l in lay])
+        hs_, rest = [], []
+        for l, e in zip(lay, lv):
+            if e["compact"]:
+                a, b_ = fork(l.cross_attn.proj.weight, 2)
+                hs_.append(a), rest.append(b_)
+            else:
+                hs_.append(l.cross_attn.proj.weight), rest.append(None)
+        add(f"{li}.wpc", hs_)
+        proj_w_rest.append(rest)
+        add(f"{li}.n3g", [l.norm3.weight for l in lay]), add(f"{li}.n3b", [l.norm3.bias for l in lay])
+        add(f"{li}.w0", [l.mlp[0].weight for l in lay]), add(f"{li}.b0", [l.mlp[0].bias for l in lay])
+        add(f"{li}.w3", [l.mlp[3].weight for l in lay]), add(f"{li}.b3", [l.mlp[3].bias for l in lay])
+    S = dict(zip(kinds, StackParamsFn.apply(L, len(kinds), *flat)))
+    # ---- stacked chain -----------------------------------------------------------------------------------------------------------
+    t2ds, t2vs_in = [], []
+    for m in smms:
+        t2d = m.text_embeddings(text_encoder, B).reshape(R, m.text_dim)
+        a, b_ = fork(t2d, 2)  # text projection (stacked) and text_to_visual (per level)
+        t2ds.append(a), t2vs_in.append(b_)
+    X = BLinearFn.apply(BLayerNormFn.apply(StackFn.apply(*t2ds), S["tp_g"], S["tp_b"], decs[0].text_proj[0].eps), S["tp_w"], S["tp_wb"])
+    for li in range(nlayers):
+        lay = [d.decoder[li] for d in decs]
+        sa0 = lay[0].self_attn
+        X, Xr = fork(X, 2)
+        n1 = BLayerNormFn.apply(X, S[f"{li}.n1g"], S[f"{li}.n1b"], lay[0].norm1.eps)
+        qkv = BLinear3Fn.apply(n1, S[f"{li}.wq"], S[f"{li}.wk"], S[f"{li}.wv"])
+        a = TokenAttnFn.apply(qkv.reshape(L * R, 3 * Wd), L * B, K, heads, sa0.scale).reshape(L, R, Wd)
+        X = AddFn.apply(Xr, dropout(BLinearFn.apply(a, S[f"{li}.wp"], S[f"{li}.bp"]), pd, tr), 1.0)
+        X, Xr = fork(X, 2)
+        n2 = BLayerNormFn.apply(X, S[f"{li}.n2g"], S[f"{li}.n2b"], lay[0].norm2.eps)
+        QC = BLinearFn.apply(n2, S[f"{li}.wqc"], None)
+        with torch.no_grad():
+            AV = torch.empty((L, R, Wd), device=dev, dtype=torch.float32)
+        shared_q, avs, pbs = {}, [], []
+        for l, (layer, e) in enumerate(zip(lay, lv)):
+            ca = layer.cross_attn
+            Cm = e["Cm"]
+            if e["compact"]:
+                wv_a, wv_b = fork(ca.v_proj.weight, 2)
+                wkf = BgemmFn.apply(ca.k_proj.weight[None], e["pts"].pop()[None], False, True).reshape(Wd, Cm)   # Wk P
+                wvp = BgemmFn.apply(wv_a[None], e["pts"].pop()[None], False, True).reshape(Wd, Cm)               # Wv P
+                bvf = LinearFn.apply(e["b2rows"].pop(), wv_b, None)                                 # b2 Wv^T
+                pbs.append(LinearFn.apply(bvf, proj_w_rest[li][l], ca.proj.bias))                   # ... through the output projection [1, Wd]
+            else:
+                wkf, wvp = ca.k_proj.weight, ca.v_proj.weight
+                pbs.append(ca.proj.bias[None, :])
+            qf = HeadFoldInLFn.apply(QC, wkf, heads, l, shared_q).reshape(B, K * heads, Cm)        # row = k*heads + h
+            if e["fused_x"]:
+                o = SmmXattnFn.apply(qf, e["mem"], ca.scale, e["mem_grad"])
+            else:
+                s_ = BgemmFn.apply(qf, e["mem"], False, False)
+                o = BgemmFn.apply(SoftmaxRowsFn.apply(s_, ca.scale), e["mem"], False, True)
+            avs.append(HeadFoldOutLFn.apply(o.reshape(R, heads, Cm), wvp, heads, _Slot(AV[l].detach())))
+        AVs = JoinFn.apply(_Slot(AV), *avs)
+        PB = StackFn.apply(*pbs).reshape(L, Wd)
+        X = AddFn.apply(Xr, dropout(BLinearFn.apply(AVs, S[f"{li}.wpc"], PB), pd, tr), 1.0)
+        X, Xr = fork(X, 2)
+        n3 = BLayerNormFn.apply(X, S[f"{li}.n3g"], S[f"{li}.n3b"], lay[0].norm3.eps)
+        hm = dropout(ActFn.apply(BLinearFn.apply(n3, S[f"{li}.w0"], S[f"{li}.b0"]), ops.ACT_GELU), pd, tr)
+        X = AddFn.apply(Xr, dropout(BLinearFn.apply(hm, S[f"{li}.w3"], S[f"{li}.b3"]), pd, tr), 1.0)
+    xs = UnstackFn.apply(X)
+    # ---- per level: the module's head ------------------------------------------------------------------------------------------
+    outs = []
+    for m, dec, e, x, t2d, fn_ in zip(smms, decs, lv, xs, t2vs_in, feats_n):
+        C, H, W, N = e["C"], e["H"], e["W"], e["N"]
+        op = dec.out_proj
+        diff = LinearFn.apply(LayerNormRowsFn.apply(x, op[0].weight, op[0].bias, op[0].eps), op[1].weight, op[1].bias)  # [R, C]
+        t2v = LinearFn.apply(t2d, m.text_to_visual.weight, m.text_to_visual.bias)
+        tv = AddFn.apply(t2v, ScaleColsFn.apply(diff, m.gamma), 1.0)
+        tvn = ChanNormalizeFn.apply(tv.reshape(R, C, 1)).reshape(B, K, C)
+        fnm = ChanNormalizeFn.apply(fn_).reshape(B, C, N)
+        score = BgemmFn.apply(tvn, fnm, False, False).reshape(B, K, H, W)
+        score, score_g = fork(score, 2)
+        outs.append((score, GatherChannelFn.apply(score_g, idx)))
+    return outs
+
+
 def forward_train(net, x_a, x_b, t, names, text_encoder, image_context=None):
     dev = x_a.device
     B, _, H, W = x_a.shape
@@ -248,6 +403,8 @@ def forward_train(net, x_a, x_b, t, names, text_encoder, image_context=None):
     x, x_ = fork(x, 2)
     hs, sms = [], []
     use_sm = net.CLIP_ScoreMapModule is not None
+    stacked = use_sm and TRAIN_STACKED and x.is_cuda and _stackable(list(net.CLIP_ScoreMapModule))
+    pending = []
     for i, lv in enumerate(net.downs):
         x = _resblock(lv.res1, x, None, tacts.pop(), vec_of(lv, "ca1"))
         if general:
@@ -264,20 +421,27 @@ def forward_train(net, x_a, x_b, t, names, text_encoder, image_context=None):
             x = _ca_general(lv.ca2, x, ctx)
         if use_sm:
             x, x_smm, x_smm2, x_skip = fork(x, 4)  # down conv, memory projection, score-map normalisation, skip
-            score, sel = _smm(net.CLIP_ScoreMapModule[i], x_smm, text_encoder, idx, feat_n=x_smm2)
-            sms.append(sel)
-            if skipbuf is not None:
-                emb = ConvFn.apply(score, None, net.sm_embed[i].weight, net.sm_embed[i].bias, 3, ops.CONV_NORMAL, _Slot(skipbuf[:, din:].detach()))
-                hs.append(SkipCatFn.apply(x_skip, emb, _Slot(skipbuf)))
+            if stacked:
+                # the level's ScoreMapModule only feeds its skip (read by the decoder) and the pyramid loss: the L modules run together
+                # behind the encoder, their token chains stacked (_smm_all)
+                pending.append((len(hs), i, x_smm, x_smm2, x_skip, skipbuf))
+                hs.append(None)
+                sms.append(None)
             else:
-                emb = ConvFn.apply(score, None, net.sm_embed[i].weight, net.sm_embed[i].bias, 3, ops.CONV_NORMAL)
-                hs.append(("cat", x_skip, emb))
+                score, sel = _smm(net.CLIP_ScoreMapModule[i], x_smm, text_encoder, idx, feat_n=x_smm2)
+                sms.append(sel)
+                hs.append(_skip_with_embedding(net, i, score, x_skip, skipbuf, din))
         else:
             x, xs = fork(x, 2)
             hs.append(xs)
         down = lv.down
         mode = ops.CONV_UNSHUFFLE2 if type(down).__name__ == "Downsample" else ops.CONV_NORMAL
         x = ConvFn.apply(x, None, down.conv.weight, down.conv.bias, 1 if mode == ops.CONV_UNSHUFFLE2 else 3, mode)
+    if pending:
+        res = _smm_all([net.CLIP_ScoreMapModule[p_[1]] for p_ in pending], [p_[2] for p_ in pending], [p_[3] for p_ in pending], text_encoder, idx)
+        for (slot_i, i, _, _, x_skip, skipbuf), (score, sel) in zip(pending, res):
+            sms[i] = sel
+            hs[slot_i] = _skip_with_embedding(net, i, score, x_skip, skipbuf, net.level_dims[i][0])
     x = _resblock(net.mid_res1, x, None, tacts.pop())
     x = _self_attention(net.mid_attn, x, vec_of(net, "mid_ca"))
     if general:

@@ -295,6 +295,281 @@ class BgemmFn(torch.autograd.Function):
         return dA, dB, None, None, None
 
 
+# ---- stacked token chains (r05): the same layer of a net's four ScoreMapModule decoders as ONE batch-L launch ----------------------
+class StackParamsFn(torch.autograd.Function):
+    """nk kinds x L levels of parameter tensors (kind-major: kind k of level l at index k*L + l; the L tensors of a kind share their
+    shape) -> nk stacked [L, *shape] tensors, gathered by ONE launch (idiff_gather_segments; the segment table is built once per set
+    of addresses and stays on the device).  Backward hands every parameter the view dstack_k[l] -- no copy."""
+    _tables = {}
+
+    @staticmethod
+    def forward(ctx, L, nk, *params):
+        import numpy as np
+        assert len(params) == L * nk
+        dev = params[0].device
+        shapes, sizes = [], []
+        for k in range(nk):
+            sh = tuple(params[k * L].shape)
+            for l in range(L):
+                p = params[k * L + l]
+                assert tuple(p.shape) == sh and p.is_contiguous() and p.dtype == torch.float32, (k, l, tuple(p.shape), sh)
+            shapes.append(sh)
+            sizes.append(params[k * L].numel())
+        total = L * sum(sizes)
+        flat = torch.empty((total,), device=dev, dtype=torch.float32)
+        key = tuple(p.data_ptr() for p in params)
+        hit = StackParamsFn._tables.get(key)
+        if hit is None:
+            tab = np.zeros((L * nk, 4), dtype=np.int64)
+            o = 0
+            for k in range(nk):
+                for l in range(L):
+                    tab[k * L + l, :3] = (params[k * L + l].data_ptr(), o, sizes[k])
+                    o += sizes[k]
+            nb = (tab[:, 2] + 4095) // 4096
+            tab[:, 3] = np.cumsum(nb) - nb
+            if len(StackParamsFn._tables) > 64:
+                StackParamsFn._tables.clear()
+            hit = StackParamsFn._tables[key] = (torch.from_numpy(tab).to(dev), int(nb.sum()))
+        check(_lib.load().idiff_gather_segments(hit[0].data_ptr(), L * nk, hit[1], _p(flat), _stream()), "gather_segments")
+        outs, o = [], 0
+        for k in range(nk):
+            outs.append(flat[o:o + L * sizes[k]].view((L,) + shapes[k]))
+            o += L * sizes[k]
+        ctx.L, ctx.nk = L, nk
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        L, nk = ctx.L, ctx.nk
+        out = [None, None]
+        for k in range(nk):
+            for l in range(L):
+                out.append(None if gs[k] is None else gs[k][l])
+        return tuple(out)
+
+
+class StackFn(torch.autograd.Function):
+    """L same-shaped activations -> [L, *shape] (L copy launches); backward = views"""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        L = len(xs)
+        out = torch.empty((L,) + tuple(xs[0].shape), device=xs[0].device, dtype=torch.float32)
+        for l, x in enumerate(xs):
+            x = x.contiguous()
+            ops.axpby(x, x, 1.0, 0.0, out=out[l])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g[l] for l in range(g.shape[0]))
+
+
+class UnstackFn(torch.autograd.Function):
+    """[L, ...] -> L views; backward gathers the L gradients into one stacked tensor (L copy launches)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        return tuple(x[l].detach() for l in range(x.shape[0]))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        live = next(g for g in gs if g is not None)
+        out = torch.empty(ctx.shape, device=live.device, dtype=torch.float32)
+        for l, g in enumerate(gs):
+            if g is None:
+                ops.axpby(live.contiguous(), live.contiguous(), 0.0, 0.0, out=out[l])
+            else:
+                g = g.contiguous()
+                ops.axpby(g, g, 1.0, 0.0, out=out[l])
+        return out
+
+
+class JoinFn(torch.autograd.Function):
+    """L parts that their producers wrote straight into the slices buf[l] of one stacked buffer -> the buffer (no copy); backward = views"""
+
+    @staticmethod
+    def forward(ctx, slot, *parts):
+        buf = slot.t
+        for l, p_ in enumerate(parts):
+            assert p_.data_ptr() == buf[l].data_ptr() and p_.numel() == buf[l].numel()
+        return buf.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None,) + tuple(g[l] for l in range(g.shape[0]))
+
+
+def _bgemm_bias(A, B, out, M, N, K, lda, ldb, ldc, tA, tB, sA, sB, sC, batch, bias=None, sbias=0):
+    with _prof("bgemm", 2.0 * M * N * K * batch):
+        check(_lib.load().idiff_bgemm_bias(_p(A), _p(B), _p(out), M, N, K, lda, ldb, ldc, 1 if tA else 0, 1 if tB else 0, sA, sB, sC, batch, 1.0,
+                                           _p(bias), sbias, _stream()), "bgemm_bias")
+    return out
+
+
+class BLinearFn(torch.autograd.Function):
+    """y[l] = x[l] w[l]^T + b[l] for the L stacked decoders in ONE launch each way: x [L,R,K], w [L,N,K], b [L,N] or None"""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w = x.contiguous(), w.contiguous()
+        L, R, K = x.shape
+        N = w.shape[1]
+        assert tuple(w.shape) == (L, N, K) and (b is None or tuple(b.shape) == (L, N))
+        y = torch.empty((L, R, N), device=x.device, dtype=torch.float32)
+        _bgemm_bias(x, w, y, R, N, K, K, K, N, False, True, R * K, N * K, R * N, L, bias=None if b is None else b.contiguous(), sbias=N)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        L, R, K = x.shape
+        N = w.shape[1]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = bgemm(dy, w, R, K, N, N, K, False, False, R * N, N * K, L)          # dy [R,N] w [N,K]
+        if ctx.needs_input_grad[1]:
+            dw = bgemm(dy, x, N, K, R, N, K, True, False, R * N, R * K, L)           # dy^T [N,R] x [R,K]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty((L, N), device=dy.device, dtype=torch.float32)
+            check(_lib.load().idiff_colsum_g(_p(dy), N, _p(db), L * R, N, L, _stream()), "colsum_g")
+        return dx, dw, db
+
+
+class BLinear3Fn(torch.autograd.Function):
+    """[x wq^T | x wk^T | x wv^T] -> packed [L, R, 3N] (bias-free), three batch-L launches; dx accumulates through beta = 1"""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv):
+        x = x.contiguous()
+        L, R, K = x.shape
+        N = wq.shape[1]
+        y = torch.empty((L, R, 3 * N), device=x.device, dtype=torch.float32)
+        for i, w in enumerate((wq, wk, wv)):
+            w = w.contiguous()
+            assert tuple(w.shape) == (L, N, K)
+            _bgemm_bias(x, w, y[:, :, i * N:], R, N, K, K, K, 3 * N, False, True, R * K, N * K, R * 3 * N, L)
+        ctx.save_for_backward(x, wq, wk, wv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wq, wk, wv = ctx.saved_tensors
+        dy = dy.contiguous()
+        L, R, K = x.shape
+        N = wq.shape[1]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dws = [None, None, None]
+        for i, w in enumerate((wq, wk, wv)):
+            dyi = dy[:, :, i * N:]   # base pointer of column block i; row stride 3N, batch stride R*3N
+            if dx is not None:
+                bgemm(dyi, w.contiguous(), R, K, N, 3 * N, K, False, False, R * 3 * N, N * K, L, out=dx, beta=0.0 if i == 0 else 1.0, ldc=K, sC=R * K)
+            if ctx.needs_input_grad[1 + i]:
+                dws[i] = bgemm(dyi, x, N, K, R, 3 * N, K, True, False, R * 3 * N, R * K, L)
+        return dx, dws[0], dws[1], dws[2]
+
+
+class BLayerNormFn(torch.autograd.Function):
+    """LayerNorm over the last dim of x [L, R, C] with a parameter row per level: gamma, beta [L, C]"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        lib = _lib.load()
+        x, gamma, beta = x.contiguous(), gamma.contiguous(), beta.contiguous()
+        L, R, Cc = x.shape
+        y = torch.empty_like(x)
+        mr = torch.empty((L * R, 2), device=x.device, dtype=torch.float32)
+        check(lib.idiff_layernorm_rows_g_fwd(_p(x), Cc, _p(gamma), _p(beta), _p(y), Cc, L * R, Cc, eps, _p(mr), L, _stream()), "layernorm_rows_g_fwd")
+        ctx.save_for_backward(x, gamma, mr)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, gamma, mr = ctx.saved_tensors
+        dy = dy.contiguous()
+        L, R, Cc = x.shape
+        dx = torch.empty_like(x)
+        dg = torch.empty((L, Cc), device=x.device, dtype=torch.float32)
+        db = torch.empty_like(dg)
+        check(lib.idiff_layernorm_rows_g_bwd(_p(dy), Cc, _p(x), Cc, _p(gamma), _p(mr), _p(dx), Cc, _p(dg), _p(db), L * R, Cc, L, _stream()),
+              "layernorm_rows_g_bwd")
+        return dx, dg, db, None
+
+
+class HeadFoldInLFn(torch.autograd.Function):
+    """HeadFoldFn "in" for level l of a STACKED query matrix xq [L, R, heads*dh] (read in place); the L calls of a layer share the
+    gradient buffer dxq: each writes its slice, the last one to run hands it to autograd (the others return None)."""
+
+    @staticmethod
+    def forward(ctx, xq, w, heads, l, shared):
+        w = w.contiguous()
+        L, R, HD = xq.shape
+        Wd = w.shape[1]
+        dh = HD // heads
+        y = torch.empty((R, heads, Wd), device=xq.device, dtype=torch.float32)
+        bgemm(xq[l], w, R, Wd, dh, HD, Wd, False, False, dh, dh * Wd, heads, out=y, ldc=heads * Wd, sC=Wd)
+        ctx.save_for_backward(xq, w)
+        ctx.geom, ctx.shared = (R, Wd, dh, heads, l), shared
+        shared["pending"] = shared.get("pending", 0) + 1
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xq, w = ctx.saved_tensors
+        R, Wd, dh, heads, l = ctx.geom
+        sh = ctx.shared
+        dy = dy.contiguous()
+        if sh.get("buf") is None:
+            sh["buf"] = torch.empty_like(xq)
+        bgemm(dy, w, R, dh, Wd, heads * Wd, Wd, False, True, Wd, dh * Wd, heads, out=sh["buf"][l], ldc=heads * dh, sC=dh)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            bgemm(xq[l], dy, dh, Wd, R, heads * dh, heads * Wd, True, False, dh, Wd, heads, out=dw, ldc=Wd, sC=dh * Wd)
+        sh["pending"] -= 1
+        if sh["pending"] > 0:
+            return None, dw, None, None, None
+        buf, sh["buf"] = sh["buf"], None
+        return buf, dw, None, None, None
+
+
+class HeadFoldOutLFn(torch.autograd.Function):
+    """HeadFoldFn "out" writing into slot.t (= slice l of a stacked buffer): y[r, h*dh:(h+1)*dh] = x[r, h, :] @ w[h*dh:(h+1)*dh, :]^T"""
+
+    @staticmethod
+    def forward(ctx, x, w, heads, slot):
+        x, w = x.contiguous(), w.contiguous()
+        R = x.shape[0]
+        Wd = w.shape[1]
+        dh = w.shape[0] // heads
+        y = slot.t
+        assert tuple(y.shape) == (R, heads * dh) and y.is_contiguous()
+        bgemm(x, w, R, dh, Wd, heads * Wd, Wd, False, True, Wd, dh * Wd, heads, out=y, ldc=heads * dh, sC=dh)
+        ctx.save_for_backward(x, w)
+        ctx.geom = (R, Wd, dh, heads)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        R, Wd, dh, heads = ctx.geom
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            bgemm(dy, w, R, Wd, dh, heads * dh, Wd, False, False, dh, dh * Wd, heads, out=dx, ldc=heads * Wd, sC=Wd)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            bgemm(dy, x, dh, Wd, R, heads * dh, heads * Wd, True, False, dh, Wd, heads, out=dw, ldc=Wd, sC=dh * Wd)
+        return dx, dw, None, None
+
+
 class StackRowsFn(torch.autograd.Function):
     """[A ; brow ; 0] -> [Cm, n]: the (C + 1) live rows of the compact memory's weight image above zero padding; backward = row slices"""
 

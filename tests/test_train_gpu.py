@@ -516,11 +516,24 @@ def test_training_dropout_of_the_decoder_blocks_vs_oracle_with_the_same_masks():
     finally:
         T.DropoutState.record = None
     n_sites = 2 * 4 * 3 * 4   # nets x ScoreMapModules x decoder layers x dropout sites
-    assert len(record) == n_sites, len(record)
     r = rec.cpu()
     loss = float(r[0] + r[1] + r[2:6].sum() / 2 + r[6:10].sum() / 2)
-    # the same masks, as 0/1 tensors, in the oracle's call order (drift net then noise net; level, layer, site -- the product's order)
-    unet_ref.InjectedDropout.queue = [(ops.dropout(torch.ones(shape, device=DEV), p, seed, off) != 0).float().cpu() for shape, seed, off, p in record]
+    masks = [(ops.dropout(torch.ones(shape, device=DEV), p, seed, off) != 0).float().cpu() for shape, seed, off, p in record]
+    if len(record) == n_sites // 4:
+        # stacked token chains (r05): one draw per (net, layer, site) over the [L = 4 levels, rows, width] stack.  The oracle calls its
+        # dropouts level by level (drift net then noise net; level, layer, site): deal the level slices out in that order
+        assert all(len(shape) == 3 and shape[0] == 4 for shape, _, _, _ in record)
+        per_net = len(masks) // 2
+        queue = []
+        for net_i in range(2):
+            mine = masks[net_i * per_net:(net_i + 1) * per_net]   # [layer][site]
+            for level in range(4):
+                for j in range(per_net):
+                    queue.append(mine[j][level])
+        masks = queue
+    assert len(masks) == n_sites, len(masks)
+    # the same masks, as 0/1 tensors, in the oracle's call order (drift net then noise net; level, layer, site)
+    unet_ref.InjectedDropout.queue = masks
     kept = sum(float(m.sum()) for m in unet_ref.InjectedDropout.queue) / sum(m.numel() for m in unet_ref.InjectedDropout.queue)
     assert 0.88 < kept < 0.92, kept
     osde = sde_ref.DriftSDERef(T_, rd, rn, max_sigma=0.4)
@@ -797,3 +810,65 @@ def test_select_conv_function_vs_conv_then_gather_autograd(B, C, K, H, W):
     assert _rel(pred, ref) < 3e-6 and _rel(xd.grad, xr.grad) < 3e-6 and _rel(wd.grad, wr.grad) < 1e-5 and _rel(bd.grad, br.grad) < 1e-5
     unused = [k for k in range(K) if k not in idx.tolist()]
     assert float(wd.grad[unused].abs().max()) == 0.0 and float(bd.grad[unused].abs().max()) == 0.0
+
+
+def test_stacked_token_functions_vs_torch_autograd():
+    """BLinearFn / BLinear3Fn / BLayerNormFn / StackParamsFn / StackFn / UnstackFn / JoinFn / HeadFoldInLFn / HeadFoldOutLFn (r05: the
+    token chains of a net's four ScoreMapModule decoders as one stack) against torch autograd of the per-level formulas in fp64."""
+    g = _g(83)
+    L, R, K, N = 4, 15, 40, 24
+    xs = [torch.randn(R, K, generator=g) for _ in range(L)]
+    ws = [torch.randn(N, K, generator=g) * 0.2 for _ in range(L)]
+    bs = [torch.randn(N, generator=g) * 0.1 for _ in range(L)]
+    gs_ = [torch.rand(K, generator=g) + 0.5 for _ in range(L)]
+    be = [torch.randn(K, generator=g) * 0.1 for _ in range(L)]
+    up = torch.randn(L, R, N, generator=g)
+    xd, wd, bd, gd, bed = ([_leaf(t) for t in ts] for ts in (xs, ws, bs, gs_, be))
+    W, Bb, G, Be = T.StackParamsFn.apply(L, 4, *wd, *bd, *gd, *bed)
+    X = T.StackFn.apply(*xd)
+    Y = T.BLinearFn.apply(T.BLayerNormFn.apply(X, G, Be, 1e-5), W, Bb)
+    ys = T.UnstackFn.apply(Y)
+    sum((y * up[l].to(DEV)).sum() for l, y in enumerate(ys)).backward()
+    for l in range(L):
+        xr, wr, br, gr, ber = (t.double().requires_grad_(True) for t in (xs[l], ws[l], bs[l], gs_[l], be[l]))
+        yr = F.layer_norm(xr, (K,), gr, ber, 1e-5) @ wr.t() + br
+        (yr * up[l].double()).sum().backward()
+        assert _rel(ys[l], yr) < 3e-6
+        for a, b_ in ((xd[l], xr), (wd[l], wr), (bd[l], br), (gd[l], gr), (bed[l], ber)):
+            assert _rel(a.grad, b_.grad) < 2e-5
+    # packed q | k | v projection
+    w3 = [[torch.randn(N, K, generator=g) * 0.2 for _ in range(L)] for _ in range(3)]
+    w3d = [[_leaf(t) for t in ws_] for ws_ in w3]
+    xd2 = [_leaf(t) for t in xs]
+    Wq, Wk, Wv = T.StackParamsFn.apply(L, 3, *w3d[0], *w3d[1], *w3d[2])
+    up3 = torch.randn(L, R, 3 * N, generator=g)
+    (T.BLinear3Fn.apply(T.StackFn.apply(*xd2), Wq, Wk, Wv) * up3.to(DEV)).sum().backward()
+    for l in range(L):
+        xr = xs[l].double().requires_grad_(True)
+        wr = [w3[i][l].double().requires_grad_(True) for i in range(3)]
+        (torch.cat([xr @ w.t() for w in wr], 1) * up3[l].double()).sum().backward()
+        assert _rel(xd2[l].grad, xr.grad) < 2e-5
+        for i in range(3):
+            assert _rel(w3d[i][l].grad, wr[i].grad) < 2e-5
+    # per-level head folds on a stacked query matrix / into a stacked output
+    heads, dh, Cm = 4, 8, 12
+    q = torch.randn(L, R, heads * dh, generator=g)
+    wf = [torch.randn(heads * dh, Cm, generator=g) * 0.3 for _ in range(L)]
+    upq = torch.randn(L, R, heads * dh, generator=g)
+    qd, wfd = _leaf(q), [_leaf(t) for t in wf]
+    shared, AV, parts = {}, torch.empty(L, R, heads * dh, device=DEV), []
+    for l in range(L):
+        y = T.HeadFoldInLFn.apply(qd, wfd[l], heads, l, shared)                     # [R, heads, Cm]
+        parts.append(T.HeadFoldOutLFn.apply(y, wfd[l], heads, T._Slot(AV[l].detach())))
+    (T.JoinFn.apply(T._Slot(AV), *parts) * upq.to(DEV)).sum().backward()
+    qr = q.double().requires_grad_(True)
+    wfr = [t.double().requires_grad_(True) for t in wf]
+    tot = 0
+    for l in range(L):
+        wh = wfr[l].reshape(heads, dh, Cm)
+        y = torch.einsum("rhd,hdn->rhn", qr[l].reshape(R, heads, dh), wh)
+        tot = tot + (torch.einsum("rhn,hdn->rhd", y, wh).reshape(R, heads * dh) * upq[l].double()).sum()
+    tot.backward()
+    assert _rel(qd.grad, qr.grad) < 2e-5
+    for l in range(L):
+        assert _rel(wfd[l].grad, wfr[l].grad) < 2e-5
