@@ -244,6 +244,25 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def matrix_gflop_per_launch(kernel, B=16, size=256, heads=4, K=5):
+    """Executed f32 matrix-core GFLOP per launch of the attention kernels at the default workload (None for other kernels): 4096 FLOP per
+    v_mfma_f32_32x32x2.  ScoreMapModule cross-attention, per 32-key block: the wave-per-block form (72 rows) issues 36 + 48 MFMAs, the
+    channel-split forms 4 waves x (XCW/2 + 16 * ceil(XCW/32)); the grouped launch covers the four levels.  Mid self-attention (4 heads x 64
+    at 32x32 tokens): 4 N^2 dh heads B FLOP."""
+    if kernel.startswith("smm_xattn_grouped_kernel"):
+        mf = 0
+        for lvl, C in enumerate((64, 64, 128, 256)):
+            blocks = B * ((size >> lvl) ** 2) // 32
+            Cm = 72 if C + 1 <= 72 else (136 if C + 1 <= 136 else 256)
+            xcw = Cm // 4
+            mf += blocks * (84 if Cm == 72 else 4 * (xcw // 2 + 16 * ((xcw + 31) // 32)))
+        return mf * 4096 / 1e9
+    if kernel.startswith("attn_self_kernel"):
+        n = (size // 8) ** 2
+        return 4.0 * n * n * 64 * heads * B / 1e9
+    return None
+
+
 def pmc_evidence(kernel):
     """Counter evidence from the newest profiles/r*/pmc_kernels.json (scripts/collect_pmc_table.sh: counter-free trace + separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command's single-stream eager step, reduced per kernel by
@@ -278,6 +297,15 @@ def pmc_evidence(kernel):
                                "share_of_step_kernel_time": k["share_of_step_kernel_time"], "bytes_per_launch": k["hbm_bytes_per_launch"],
                                "achieved": k["achieved_GBps"], "peak": k["peak_GBps"], "unit": "GB/s", "frac": k["frac"]}
                               for k in doc["kernels"] if "frac" in k and not k["kernel"].startswith("conv_wino") and k["share_of_step_kernel_time"] >= 0.02]
+        # ... of which the attention kernels are bound by the f32 matrix rate, not by HBM: their executed matrix-core FLOP per launch at the
+        # default workload (256x256, batch 16; query rows padded to the 32-row tile) against the 157.3 TFLOP/s peak
+        for k in out["hbm_kernels"]:
+            gf = matrix_gflop_per_launch(k["kernel"])
+            if gf is not None:
+                tf = gf / k["avg_us"] / 1e-3
+                k.update(bound="mfma", executed_gflop_per_launch=round(gf, 2), achieved_tflops=round(tf, 1), peak_tflops=F32_MFMA_PEAK_TFLOPS,
+                         frac_mfma=round(tf / F32_MFMA_PEAK_TFLOPS, 4),
+                         note="f32-MFMA-bound (20 query rows on 32-row tiles); `frac` / `achieved` = its HBM traffic, for reference")
         # matrix-pipe utilisation of the dominant kernel per layer shape: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), its own
         # --pmc passes (scripts/collect_mfma_util.sh), stored next to the traffic table and hash-gated like it
         mu = os.path.join(os.path.dirname(cands[-1]), "mfma_util.json")

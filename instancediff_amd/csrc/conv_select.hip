@@ -4,6 +4,8 @@
 // once, so no matrix cores here (a 5 -> 32 padded MFMA tile would spend 6x the time on zeros).
 // Workgroup = 8 x 32 output pixels of one sample, one pixel per thread; 8-channel chunks of the input patch (with halo)
 // are staged through LDS, the 9*C weights of the sample's class once.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -61,6 +63,61 @@ __global__ __launch_bounds__(256) void conv3x3_select_kernel(const float* __rest
     }
     const int oy = y0 + ty, ox = x0 + tx;
     if (oy < H && ox < W) out[(long long)b * HW + oy * W + ox] = acc + (bias ? bias[k] : 0.f);
+}
+
+// r05 streaming form (W % 4 == 0, 16-byte rows): thread = a strip of 4 consecutive output pixels; per input channel its 3 x 6 window comes
+// straight from global memory (one 16-byte load + two halo dwords per row: the halo of a strip is its neighbours' data, an L1 hit) and
+// feeds 36 FMAs with the class kernel broadcast from LDS -- no staged patch, no barrier per channel chunk.  Per pixel the multiply-adds
+// run in the order of the tiled kernel above (channels ascending, taps row-major): the same bits.  The tiled form was bound by its LDS
+// reads (two per multiply-add: 130 us at 256 x 256, batch 16, for 268 MB of input).
+__global__ __launch_bounds__(256) void conv3x3_select4_kernel(const float* __restrict__ x, long long xbs, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, const int* __restrict__ idx, float* __restrict__ out,
+                                                              int C, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float wk[];  // [C][9]
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int k = idx[b];
+    for (int i = tid; i < C * 9; i += 256) wk[i] = w[(long long)k * C * 9 + i];
+    __syncthreads();
+    const long long HW = (long long)H * W;
+    const long long p = ((long long)blockIdx.x * 256 + tid) * 4;
+    if (p >= HW) return;
+    const int y = (int)(p / W), x0 = (int)(p - (long long)y * W);
+    const float* xb = x + (long long)b * xbs + p;
+    const bool up = y > 0, dn = y + 1 < H, lf = x0 > 0, rt = x0 + 4 < W;
+    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+    constexpr int UN = 4;  // channels of loads in flight
+    for (int c0 = 0; c0 < C; c0 += UN) {
+        float d[UN][3][6];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const float* xc = xb + (long long)(c0 + u < C ? c0 + u : C - 1) * HW;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const bool rowok = r == 0 ? up : (r == 2 ? dn : true);
+                const float* xr = xc + (long long)(r - 1) * W;
+                const floatx4 m = rowok ? *reinterpret_cast<const floatx4*>(xr) : floatx4{0.f, 0.f, 0.f, 0.f};
+                d[u][r][0] = (rowok && lf) ? xr[-1] : 0.f;
+                d[u][r][1] = m.x, d[u][r][2] = m.y, d[u][r][3] = m.z, d[u][r][4] = m.w;
+                d[u][r][5] = (rowok && rt) ? xr[4] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (c0 + u < C) {  // uniform
+                const float* wc = wk + (c0 + u) * 9;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float wv = wc[ky * 3 + kx];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(d[u][ky][j + kx], wv, acc[j]);
+                    }
+            }
+        }
+    }
+    const float bv = bias ? bias[k] : 0.f;
+    *reinterpret_cast<floatx4*>(out + (long long)b * HW + p) = floatx4{acc.x + bv, acc.y + bv, acc.z + bv, acc.w + bv};
 }
 
 // ---- backward of the fused output layer (training step, r05).  With k_b = idx[b] and g = d pred [B, 1, H, W]:
@@ -221,6 +278,17 @@ extern "C" int idiff_conv3x3_select_fwd(const float* x, int64_t x_bstride, const
     IDIFF_CHECK_ARG(x && w && idx && out, "conv3x3_select: null pointer");
     IDIFF_CHECK_ARG(B > 0 && C > 0 && K > 0 && H > 0 && W > 0 && C <= 1024, "conv3x3_select: bad dims");
     IDIFF_CHECK_ARG(x_bstride >= (long long)C * H * W, "conv3x3_select: x_bstride too small");
+    static const bool strip_off = [] {
+        const char* e = getenv("IDIFF_SELECT_STRIPS");
+        return e && e[0] == '0';
+    }();
+    if (!strip_off && W % 4 == 0 && x_bstride % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        const long long HW = (long long)H * W;
+        hipLaunchKernelGGL(conv3x3_select4_kernel, dim3((unsigned)((HW / 4 + 255) / 256), B), dim3(256), (size_t)C * 9 * sizeof(float), (hipStream_t)stream, x,
+                           (long long)x_bstride, w, bias, idx, out, C, H, W);
+        IDIFF_CHECK_LAUNCH("conv3x3_select_fwd(strips)");
+        return IDIFF_OK;
+    }
     const int tiles_x = (W + STW - 1) / STW, tiles_y = (H + STH - 1) / STH;
     const size_t lds = ((size_t)SCK * SPS + (size_t)C * 9) * sizeof(float);
     hipLaunchKernelGGL(conv3x3_select_kernel, dim3(tiles_x * tiles_y, B), dim3(256), lds, (hipStream_t)stream, x, (long long)x_bstride, w, bias, idx,

@@ -168,7 +168,7 @@ def test_linear_t_heads_matches_per_head_calls():
         _close(av[:, h * dh:(h + 1) * dh], ref_v, 3e-6, f"head {h} value fold")
 
 
-@pytest.mark.parametrize("B,C,K,H,W", [(3, 64, 5, 32, 32), (2, 12, 5, 13, 40), (1, 64, 5, 8, 64)])
+@pytest.mark.parametrize("B,C,K,H,W", [(3, 64, 5, 32, 32), (2, 12, 5, 13, 40), (1, 64, 5, 8, 64), (2, 12, 5, 9, 30), (2, 7, 5, 5, 8)])
 def test_conv3x3_select_equals_conv_then_gather(B, C, K, H, W):
     g = torch.Generator().manual_seed(51)
     x = torch.randn(B, C, H, W, generator=g)
