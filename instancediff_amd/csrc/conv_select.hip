@@ -70,6 +70,11 @@ __global__ __launch_bounds__(256) void conv3x3_select_kernel(const float* __rest
 // feeds 36 FMAs with the class kernel broadcast from LDS -- no staged patch, no barrier per channel chunk.  Per pixel the multiply-adds
 // run in the order of the tiled kernel above (channels ascending, taps row-major): the same bits.  The tiled form was bound by its LDS
 // reads (two per multiply-add: 130 us at 256 x 256, batch 16, for 268 MB of input).
+// This translation unit is compiled with -fno-slp-vectorize (Makefile).  hipcc's SLP pass turns the four accumulator chains into
+// v_pk_fma_f32 pairs (72 of them + 149 moves that assemble register pairs around the exec-masked halo loads), and that form produced
+// intermittently WRONG low halves of the pairs (pixels 0 and 2 of a strip, lanes 48..63 of a wave) -- only while the other net's
+// kernels shared the CUs (two streams), never alone, never with AMD_SERIALIZE_KERNEL=3: the bitwise batch-invariance test of the 256^2
+// chain caught it (profiles/r05/x_select_strips_packed_fma.txt).  The scalar form is bit-stable in every configuration tried.
 __global__ __launch_bounds__(256) void conv3x3_select4_kernel(const float* __restrict__ x, long long xbs, const float* __restrict__ w,
                                                               const float* __restrict__ bias, const int* __restrict__ idx, float* __restrict__ out,
                                                               int C, int H, int W) {

@@ -104,17 +104,19 @@ class CLIPDriftModel():
                 return nn.ModuleList([ScoreMapModule(visual_dim=score_map_ngf * score_map_ch_mult[i], CLIP_Type=CLIP_Type,
                                                      token_embed_dim=token_embed_dim, dropout=score_map_dropout, decoder_type=score_map_decoder)
                                       for i in range(len(score_map_ch_mult))])
-            # reference models/drift_noise_model.py:113-114,130-131 builds ONE default ScoreMapModule() here and hands it to create_net();
-            # the UNet that consumes it (models/modules/*, chosen by dnet_settings.module_name) is not part of the reference snapshot,
-            # so how a single module is wired into the levels cannot be restated -- config.yml sets if_MultiScoreMap: True
-            raise NotImplementedError("if_MultiScoreMap=False: the single-ScoreMapModule UNet is absent from the reference snapshot "
-                                      "(models/modules/), nothing to restate; Configurations/config.yml uses if_MultiScoreMap: True")
+            # reference models/drift_noise_model.py:113-114,130-131: ONE default ScoreMapModule() handed to create_net().  The UNet that
+            # consumes it is not part of the reference snapshot; this build's frozen spec puts it on the
+            # full-resolution level (visual_dim = nf, the module's default 64) with its score map embedded into `score_map_chan` channels
+            # of that level's skip
+            nf = int(settings.get('nf', 64) or 64)
+            return ScoreMapModule(visual_dim=nf, CLIP_Type=CLIP_Type, token_embed_dim=token_embed_dim, dropout=score_map_dropout,
+                                  decoder_type=score_map_decoder)
 
         self.drift_prompt = prompts(dnet_settings)
         self.noise_prompt = prompts(nnet_settings)
         if class_tokens is not None:  # real class-prompt token ids [K, N1] (the reference: clip.tokenize(prompts, context_length=N1))
             for smms in (self.drift_prompt, self.noise_prompt):
-                for m in (smms or []):
+                for m in ([] if smms is None else (smms if isinstance(smms, nn.ModuleList) else [smms])):
                     m.set_class_tokens(class_tokens)
         self.drift_net = create_net(dnet_settings, CLIP_ScoreMapModule=self.drift_prompt).to(self.device)
         self.noise_net = create_net(nnet_settings, CLIP_ScoreMapModule=self.noise_prompt).to(self.device)

@@ -619,13 +619,17 @@ class LearnableForwardUNet_MultiScoreMap(nn.Module):
                              persistent=False)
         use_sm = text_module == "scoremap"
         self.CLIP_ScoreMapModule = CLIP_ScoreMapModule if use_sm else None
+        # if_MultiScoreMap False (reference models/drift_noise_model.py:113-114,130-131: ONE default ScoreMapModule() handed to create_net;
+        # frozen spec): the module sits on the full-resolution level, its score map is embedded into score_map_chan
+        # channels of that level's skip and is the one score map returned; the other levels carry no score-map channels
+        self.n_sm = (self.depth if if_MultiScoreMap else 1) if use_sm else 0
         self.downs = nn.ModuleList()
         self.ups = nn.ModuleList()
         self.sm_embed = nn.ModuleList()
         self.level_dims = []
         for i in range(self.depth):
             din, dout = nf * mult[i], nf * mult[i + 1]
-            smc = score_map_ngf * score_map_ch_mult[i] if use_sm else 0
+            smc = (score_map_ngf * score_map_ch_mult[i] if if_MultiScoreMap else score_map_chan) if i < self.n_sm else 0
             self.level_dims.append((din, dout, smc))
             lv = Level()
             lv.res1 = ResBlock(din, din, time_dim, gn_groups)
@@ -635,7 +639,7 @@ class LearnableForwardUNet_MultiScoreMap(nn.Module):
                 lv.ca2 = CrossAttention(din, context_dim, attn_heads)
             lv.down = Downsample(din, dout) if i != self.depth - 1 else SameConv(din, dout)
             self.downs.append(lv)
-            if use_sm:
+            if i < self.n_sm:
                 self.sm_embed.append(nn.Conv2d(K, smc, 3, padding=1))
             up = Level()
             up.res1 = ResBlock(dout + din + smc, dout, time_dim, gn_groups)
@@ -657,6 +661,13 @@ class LearnableForwardUNet_MultiScoreMap(nn.Module):
         self._idx_cache = {}
 
     # ---- helpers ---------------------------------------------------------------------------------
+    def score_map_modules(self):
+        """the net's ScoreMapModules as a list: one per level (if_MultiScoreMap) or the single module of level 0"""
+        m = self.CLIP_ScoreMapModule
+        if m is None:
+            return []
+        return list(m) if isinstance(m, (nn.ModuleList, list, tuple)) else [m]
+
     def resblocks(self):
         rbs = []
         for lv in self.downs:
@@ -759,6 +770,7 @@ class LearnableForwardUNet_MultiScoreMap(nn.Module):
             if general:
                 x = lv.ca1.run(x, ctx)
             hs.append(x)
+            use_sm = i < self.n_sm
             if use_sm:
                 skip = torch.empty((B, din + smc, Hi, Wi), device=dev, dtype=torch.float32)
                 xo = skip[:, :din]
@@ -775,12 +787,12 @@ class LearnableForwardUNet_MultiScoreMap(nn.Module):
                 hs.append(x)
             x = lv.down.run(x)
         side = cur = None
-        if use_sm:
+        if self.n_sm > 0:
             # A level's ScoreMapModule only feeds its skip connection (and the returned score maps), which the decoder reads much
             # later: the four modules run here, together -- every latency-bound token-side launch of their decoder chains serves all
             # four levels at once (decoder_tokens_grouped), 23 launches per net instead of 92.
             def smm_phase():
-                smms = list(self.CLIP_ScoreMapModule)
+                smms = self.score_map_modules()
                 texts = [m.text_embeddings(text_encoder, B) for m in smms]
                 tvs = decoder_tokens_grouped(smms, sm_feats, texts)
                 scores = _scoremaps(sm_feats, [tv.reshape(B, m.n_cls, feat.shape[1]) for m, feat, tv in zip(smms, sm_feats, tvs)], idx)

@@ -402,10 +402,11 @@ def forward_train(net, x_a, x_b, t, names, text_encoder, image_context=None):
     x = ConvFn.apply(x_a.contiguous(), x_b.contiguous(), net.init_conv.weight, net.init_conv.bias, 7, ops.CONV_NORMAL)
     x, x_ = fork(x, 2)
     hs, sms = [], []
-    use_sm = net.CLIP_ScoreMapModule is not None
-    stacked = use_sm and TRAIN_STACKED and x.is_cuda and _stackable(list(net.CLIP_ScoreMapModule))
+    smms = net.score_map_modules()   # one per level, or the single module of level 0 (if_MultiScoreMap False)
+    stacked = bool(smms) and TRAIN_STACKED and x.is_cuda and _stackable(smms)
     pending = []
     for i, lv in enumerate(net.downs):
+        use_sm = i < net.n_sm
         x = _resblock(lv.res1, x, None, tacts.pop(), vec_of(lv, "ca1"))
         if general:
             x = _ca_general(lv.ca1, x, ctx)
@@ -428,7 +429,7 @@ def forward_train(net, x_a, x_b, t, names, text_encoder, image_context=None):
                 hs.append(None)
                 sms.append(None)
             else:
-                score, sel = _smm(net.CLIP_ScoreMapModule[i], x_smm, text_encoder, idx, feat_n=x_smm2)
+                score, sel = _smm(smms[i], x_smm, text_encoder, idx, feat_n=x_smm2)
                 sms.append(sel)
                 hs.append(_skip_with_embedding(net, i, score, x_skip, skipbuf, din))
         else:
@@ -438,7 +439,7 @@ def forward_train(net, x_a, x_b, t, names, text_encoder, image_context=None):
         mode = ops.CONV_UNSHUFFLE2 if type(down).__name__ == "Downsample" else ops.CONV_NORMAL
         x = ConvFn.apply(x, None, down.conv.weight, down.conv.bias, 1 if mode == ops.CONV_UNSHUFFLE2 else 3, mode)
     if pending:
-        res = _smm_all([net.CLIP_ScoreMapModule[p_[1]] for p_ in pending], [p_[2] for p_ in pending], [p_[3] for p_ in pending], text_encoder, idx)
+        res = _smm_all([smms[p_[1]] for p_ in pending], [p_[2] for p_ in pending], [p_[3] for p_ in pending], text_encoder, idx)
         for (slot_i, i, _, _, x_skip, skipbuf), (score, sel) in zip(pending, res):
             sms[i] = sel
             hs[slot_i] = _skip_with_embedding(net, i, score, x_skip, skipbuf, net.level_dims[i][0])

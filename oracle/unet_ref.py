@@ -301,12 +301,16 @@ class LearnableForwardUNet_MultiScoreMap(nn.Module):
         self.time_mlp = nn.Sequential(nn.Linear(nf, time_dim), nn.GELU(), nn.Linear(time_dim, time_dim))
         use_sm = text_module == "scoremap"
         self.CLIP_ScoreMapModule = CLIP_ScoreMapModule if use_sm else None
+        # if_MultiScoreMap False (models/drift_noise_model.py:113-114,130-131: ONE default ScoreMapModule() handed to the net; frozen spec,
+        # DESIGN.md section 2): the module sits on the full-resolution level, its score map is embedded into score_map_chan channels of
+        # that level's skip; the other levels have no score-map channels
+        self.n_sm = (self.depth if if_MultiScoreMap else 1) if use_sm else 0
         self.downs = nn.ModuleList()
         self.ups = nn.ModuleList()
         self.sm_embed = nn.ModuleList()
         for i in range(self.depth):
             din, dout = nf * mult[i], nf * mult[i + 1]
-            smc = score_map_ngf * score_map_ch_mult[i] if use_sm else 0
+            smc = (score_map_ngf * score_map_ch_mult[i] if if_MultiScoreMap else score_map_chan) if i < self.n_sm else 0
             lv = Level()
             lv.res1 = ResBlock(din, din, time_dim, gn_groups)
             lv.res2 = ResBlock(din, din, time_dim, gn_groups)
@@ -315,7 +319,7 @@ class LearnableForwardUNet_MultiScoreMap(nn.Module):
                 lv.ca2 = CrossAttention(din, context_dim, attn_heads)
             lv.down = Downsample(din, dout) if i != self.depth - 1 else SameConv(din, dout)
             self.downs.append(lv)
-            if use_sm:
+            if i < self.n_sm:
                 self.sm_embed.append(nn.Conv2d(K, smc, 3, padding=1))
             up = Level()
             up.res1 = ResBlock(dout + din + smc, dout, time_dim, gn_groups)
@@ -358,8 +362,9 @@ class LearnableForwardUNet_MultiScoreMap(nn.Module):
             x = lv.res2(x, temb)
             if ctx is not None:
                 x = x + lv.ca2(x, ctx)
-            if self.CLIP_ScoreMapModule is not None:
-                score = self.CLIP_ScoreMapModule[i](x, text_encoder)  # [B,K,h,w]
+            if i < self.n_sm:
+                smm = self.CLIP_ScoreMapModule[i] if isinstance(self.CLIP_ScoreMapModule, (nn.ModuleList, list, tuple)) else self.CLIP_ScoreMapModule
+                score = smm(x, text_encoder)  # [B,K,h,w]
                 sms.append(score[torch.arange(B), idx][:, None])
                 h.append(torch.cat([x, self.sm_embed[i](score)], dim=1))
             else:

@@ -321,3 +321,79 @@ def test_non_square_160x288_chain_vs_oracle():
     assert torch.equal(out2[1:], out1)
     ref = _oracle_chain(model, T, b2, x_T, noises)
     _check_vs_oracle(out2, ref, b2['target'], "160x288 (non-square)")
+
+
+def test_single_scoremap_module_option_chain_and_gradients_vs_oracle():
+    """`if_MultiScoreMap: False` (reference models/drift_noise_model.py:113-114,130-131: ONE default ScoreMapModule() handed to the net; r05):
+    the module sits on the full-resolution level, its score map is embedded into `score_map_chan` channels of that level's skip and is the
+    one score map returned.  A 3-step injected-noise chain and one training forward / backward (loss record, every parameter gradient)
+    against the oracle built the same way; the pyramid loss has its single term."""
+    import copy
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from instancediff_amd import train_ops as T_
+    from oracle import sde_ref, unet_ref
+    opt = copy.deepcopy(pipeline.load_options())
+    mo = opt['models']['DriftNoise']
+    mo['if_MultiScoreMap'] = False
+    mo['dnet_settings']['if_MultiScoreMap'] = False
+    mo['nnet_settings']['if_MultiScoreMap'] = False
+    T, B, H = 3, 2, 64
+    model, sde = pipeline.build(opt=opt, phase="train", device=torch.device(DEV), T=T, seed=0, score_map_dropout=0.0)
+    assert not isinstance(model.drift_prompt, nn.ModuleList) and model.drift_net.n_sm == 1 and len(model.drift_net.sm_embed) == 1
+    with torch.no_grad():
+        for net in (model.drift_net, model.noise_net):
+            net.CLIP_ScoreMapModule.gamma.fill_(0.3)
+    refs = []
+    for key, net in (('dnet_settings', model.drift_net), ('nnet_settings', model.noise_net)):
+        s = {k: v for k, v in dict(mo[key]).items() if k not in ("module_name", "class_name")}
+        r = unet_ref.LearnableForwardUNet_MultiScoreMap(CLIP_ScoreMapModule=unet_ref.ScoreMapModule(visual_dim=64), use_image_context=True, **s)
+        r.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()})
+        refs.append(r)
+    batch = make_batch(B, H, seed=5, mixed=True)
+    te = unet_ref.StubTextEncoder()
+    # ---- training forward / backward ----
+    model.set_train()
+    g = torch.Generator().manual_seed(3)
+    t = torch.tensor([[[[2]]], [[[3]]]])
+    eps = torch.randn(batch['input'].shape, generator=g)
+    model.input, model.target = batch['input'].to(DEV), batch['target'].to(DEV)
+    model.names, model.A_emb = batch['names'], batch['A_emb'].to(DEV)
+    model.t, model.drift_noised_x, _, model.std_noise, _ = sde.forward_diffusion(model.target, model.input, t=t, eps=eps.to(DEV))
+    rec, _, _, _ = T_.forward_backward_inputRes(model)
+    r_ = rec.cpu()
+    assert float(r_[3:6].abs().sum()) == 0.0 and float(r_[7:10].abs().sum()) == 0.0   # one pyramid term per net
+    loss = float(r_[0] + r_[1] + r_[2] / 2 + r_[6] / 2)
+    osde = sde_ref.DriftSDERef(T, refs[0], refs[1], max_sigma=0.4)
+    _, x_t, _, std_noise, _ = osde.forward_diffusion(batch['target'], batch['input'], t, eps)
+    tt = t.reshape(-1)
+    refs[0].train(), refs[1].train()
+    pd, dsm = refs[0](x_t - batch['input'], batch['input'], tt, batch['names'], te, image_context=batch['A_emb'])
+    pn, nsm = refs[1](x_t - batch['input'], x_t, tt, batch['names'], te, image_context=batch['A_emb'])
+    assert len(dsm) == 1 and len(nsm) == 1
+    tgt = batch['input'] - batch['target']
+    l0 = F.mse_loss(pd, tgt) + F.mse_loss(pn, std_noise) + F.mse_loss(dsm[0], tgt) / 2 + F.mse_loss(nsm[0], std_noise) / 2
+    l0.backward()
+    assert abs(loss - float(l0.detach())) < 2e-5 * abs(float(l0.detach()))
+    worst = 0.0
+    for net, ref in ((model.drift_net, refs[0]), (model.noise_net, refs[1])):
+        refg = dict(ref.named_parameters())
+        for k, p_ in net.named_parameters():
+            rg = refg[k].grad
+            scale = float(rg.abs().max())
+            if scale < 1e-12:
+                continue
+            worst = max(worst, float((p_.grad.cpu() - rg).abs().max()) / scale)
+    assert worst < 1e-3, worst
+    # ---- sampling chain ----
+    model.set_eval()
+    refs[0].eval(), refs[1].eval()
+    gch = torch.Generator().manual_seed(6)
+    x_T = batch['input'] + 0.4 * torch.randn(batch['input'].shape, generator=gch)
+    noises = torch.randn((T,) + tuple(batch['input'].shape), generator=gch)
+    out = _chain(model, batch, x_T, noises)
+    with torch.no_grad():
+        ref = osde.reverse_ddpm(batch['input'], batch['names'], te, x_T, noises, image_context=batch['A_emb'])
+    err = float((out - ref).abs().max())
+    print(f"if_MultiScoreMap False: loss {loss:.6f}, worst gradient error {worst:.2e}, chain max diff {err:.2e}")
+    assert err < 1e-4
