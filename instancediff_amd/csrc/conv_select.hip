@@ -283,11 +283,14 @@ extern "C" int idiff_conv3x3_select_fwd(const float* x, int64_t x_bstride, const
     IDIFF_CHECK_ARG(x && w && idx && out, "conv3x3_select: null pointer");
     IDIFF_CHECK_ARG(B > 0 && C > 0 && K > 0 && H > 0 && W > 0 && C <= 1024, "conv3x3_select: bad dims");
     IDIFF_CHECK_ARG(x_bstride >= (long long)C * H * W, "conv3x3_select: x_bstride too small");
-    static const bool strip_off = [] {
+    // The strip form is opt-in (IDIFF_SELECT_STRIPS=1): built without SLP packing it is bit-stable but no faster than the tiled form
+    // (126 vs 130 us at 256 x 256, batch 16: both end up bound by their ~2 VALU / LDS issue slots per multiply-add), and its packed
+    // build was the one kernel of the library that was ever wrong only in company (note above).
+    static const bool strip_on = [] {
         const char* e = getenv("IDIFF_SELECT_STRIPS");
-        return e && e[0] == '0';
+        return e && e[0] == '1';
     }();
-    if (!strip_off && W % 4 == 0 && x_bstride % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+    if (strip_on && W % 4 == 0 && x_bstride % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
         const long long HW = (long long)H * W;
         hipLaunchKernelGGL(conv3x3_select4_kernel, dim3((unsigned)((HW / 4 + 255) / 256), B), dim3(256), (size_t)C * 9 * sizeof(float), (hipStream_t)stream, x,
                            (long long)x_bstride, w, bias, idx, out, C, H, W);
