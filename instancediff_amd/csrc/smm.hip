@@ -71,16 +71,41 @@ __global__ __launch_bounds__(256) void smm_memproj_kernel(const float* __restric
     const float* wl = wpk + (long long)half * MP_W + wave * 64 + l31;
     const float* xl = xt + half * MP_PX + l31;
     const int nsteps = C / 2;
-    for (int st = 0; st < nsteps; ++st) {
-        const float a0 = wl[(long long)(2 * st) * MP_W];
-        const float a1 = wl[(long long)(2 * st) * MP_W + 32];
+    // The weight operand comes straight from L2, one 4-byte element per lane and MFMA row block: a block of MP_PF k-steps is requested
+    // while the previous block's 4 * MP_PF MFMAs run (r05: with one step in flight the loop was one L2 round trip per step -- 81 us for
+    // 256 -> 256 at 32 x 32, batch 16, against 14 us of matrix time).  Same k order, same sums.
+    constexpr int MP_PF = 8;
+    auto wload = [&](float (&w)[MP_PF][2], int st0) {
+#pragma unroll
+        for (int u = 0; u < MP_PF; ++u) {
+            w[u][0] = wl[(long long)(2 * (st0 + u)) * MP_W];
+            w[u][1] = wl[(long long)(2 * (st0 + u)) * MP_W + 32];
+        }
+    };
+    auto step = [&](int st, float a0, float a1) {
         const float x0 = xl[2 * st * MP_PX];
         const float x1 = xl[2 * st * MP_PX + 32];
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, x0, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, x1, acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, x0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, x1, acc[1][1], 0, 0, 0);
+    };
+    const int nfull = nsteps / MP_PF * MP_PF;  // whole blocks; the remainder (C not a multiple of 16) one step at a time
+    if (nfull > 0) {
+        float wa[MP_PF][2];
+        wload(wa, 0);
+        for (int st0 = 0; st0 < nfull; st0 += MP_PF) {
+            float wn[MP_PF][2];
+            // (the last block requests the matrix's first rows again: in range, unused)
+            wload(wn, st0 + MP_PF < nfull ? st0 + MP_PF : 0);
+            __builtin_amdgcn_sched_barrier(0);  // (left alone, the scheduler sinks the requests behind the block's MFMAs)
+#pragma unroll
+            for (int u = 0; u < MP_PF; ++u) step(st0 + u, wa[u][0], wa[u][1]);
+#pragma unroll
+            for (int u = 0; u < MP_PF; ++u) wa[u][0] = wn[u][0], wa[u][1] = wn[u][1];
+        }
     }
+    for (int st = nfull; st < nsteps; ++st) step(st, wl[(long long)(2 * st) * MP_W], wl[(long long)(2 * st) * MP_W + 32]);
     // ---- + bias, LayerNorm over the 256 output channels per pixel ------------------------------------
     float bv[2][16], gv[2][16], ov[2][16];
 #pragma unroll
@@ -539,6 +564,27 @@ __device__ __forceinline__ void linear_t_mfma_body(const float* __restrict__ x, 
     float* red = lm_smem + LM_ROWS * KS;                // [8 waves][4 mfma][64 lanes][4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = by * LM_ROWS, n0 = bx * 64;
+    // this wave's K range, in whole steps of 4
+    const int nsteps = (K + 3) / 4;
+    const int sper = (nsteps + LM_WAVES - 1) / LM_WAVES;
+    const int s0 = wave * sper, s1 = min(nsteps, s0 + sper);
+    const int n = lane & 15, kk = lane >> 4;
+    const int col = n0 + 4 * n;
+    const bool col_ok = col < N;  // N % 4 == 0: a lane's four features are in or out together
+    const float* wp = wT + (col_ok ? col : 0);
+    constexpr int UN = 8;  // steps in flight: 8 x 16 B per lane
+    // The weights do not depend on the rows: the wave's first block (all of its K range at K <= 256) is requested BEFORE the rows are
+    // staged and normalised, so the two round trips of the launch overlap (r05: 42 launches of 11.7 us per sampling step, all latency).
+    floatx4 w[UN];
+    auto wload = [&](int sb) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int k = (sb + u) * 4 + kk;
+            const bool ok = sb + u < s1 && k < K;
+            w[u] = (ok && col_ok) ? *reinterpret_cast<const floatx4*>(wp + (long long)k * ldw) : floatx4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    wload(s0);
     for (int i = tid; i < LM_ROWS * K; i += 512) {
         const int r = i / K, k = i - r * K;
         const int rr = r0 + r < R ? r0 + r : R - 1;
@@ -560,27 +606,17 @@ __device__ __forceinline__ void linear_t_mfma_body(const float* __restrict__ x, 
         for (int k = l; k < K; k += 32) xr[k] = (xr[k] - mean) * rstd * ln_g[k] + ln_b[k];
         __syncthreads();
     }
-    // this wave's K range, in whole steps of 4
-    const int nsteps = (K + 3) / 4;
-    const int sper = (nsteps + LM_WAVES - 1) / LM_WAVES;
-    const int s0 = wave * sper, s1 = min(nsteps, s0 + sper);
-    const int n = lane & 15, kk = lane >> 4;
-    const int col = n0 + 4 * n;
-    const bool col_ok = col < N;  // N % 4 == 0: a lane's four features are in or out together
-    const float* wp = wT + (col_ok ? col : 0);
     const float* xp = xs + n * KS + kk;
     floatx4 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-    constexpr int UN = 8;  // steps in flight: 8 x 16 B per lane
     for (int sb = s0; sb < s1; sb += UN) {
-        floatx4 w[UN];
         float a[UN];
+        if (sb != s0) wload(sb);
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int k = (sb + u) * 4 + kk;
             const bool ok = sb + u < s1 && k < K;
-            w[u] = (ok && col_ok) ? *reinterpret_cast<const floatx4*>(wp + (long long)k * ldw) : floatx4{0.f, 0.f, 0.f, 0.f};
             a[u] = ok ? xp[(sb + u) * 4] : 0.f;
         }
 #pragma unroll
