@@ -123,10 +123,14 @@ __global__ __launch_bounds__(256) void attn_self_kernel(const float* __restrict_
         }
         lrun = lrun * alpha + ps;
         mrun = mnew;
+        // (the running maximum of a row rarely moves after the first key blocks: alpha == 1 in every lane -> the products are skipped,
+        // the result is the same bits)
+        if (__any(alpha != 1.f)) {
 #pragma unroll
-        for (int m = 0; m < MB; ++m)
+            for (int m = 0; m < MB; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) O[m][r] *= alpha;
+                for (int r = 0; r < 16; ++r) O[m][r] *= alpha;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r)
 #pragma unroll
@@ -273,10 +277,14 @@ __global__ __launch_bounds__(256) void attn_self_half_kernel(const float* __rest
         }
         lrun = lrun * alpha + ps;
         mrun = mnew;
+        // (the running maximum of a row rarely moves after the first key blocks: alpha == 1 in every lane -> the products are skipped,
+        // the result is the same bits)
+        if (__any(alpha != 1.f)) {
 #pragma unroll
-        for (int m = 0; m < MB; ++m)
+            for (int m = 0; m < MB; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) O[m][r] *= alpha;
+                for (int r = 0; r < 16; ++r) O[m][r] *= alpha;
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -567,10 +575,14 @@ __device__ __forceinline__ void smm_xattn_body(const float* __restrict__ qf, con
         }
         lrun = lrun * alpha + ps;
         mrun = mnew;
+        // (the running maximum of a row rarely moves after the first key blocks: alpha == 1 in every lane -> the products are skipped,
+        // the result is the same bits)
+        if (__any(alpha != 1.f)) {
 #pragma unroll
-        for (int m = 0; m < XCB; ++m)
+            for (int m = 0; m < XCB; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) O[m][r] *= alpha;
+                for (int r = 0; r < 16; ++r) O[m][r] *= alpha;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r)
 #pragma unroll
@@ -686,10 +698,14 @@ __device__ __forceinline__ void smm_xattn_w_body(const float* __restrict__ qf, c
         }
         lrun = lrun * alpha + ps;
         mrun = mnew;
+        // (the running maximum of a row rarely moves after the first key blocks: alpha == 1 in every lane -> the products are skipped,
+        // the result is the same bits)
+        if (__any(alpha != 1.f)) {
 #pragma unroll
-        for (int m = 0; m < CB; ++m)
+            for (int m = 0; m < CB; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) O[m][r] *= alpha;
+                for (int r = 0; r < 16; ++r) O[m][r] *= alpha;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r)
 #pragma unroll
@@ -1035,13 +1051,19 @@ __global__ __launch_bounds__(256) void smm_xattn_bwd_combine_kernel(const float*
 
 inline void smm_split(int B, int N, int* nsplit, int* kps) {
     // The split is a function of N alone, so a sample's reduction order (and its bits) does not depend on the batch it sits
-    // in: 32..1024 keys per split, at most 64 splits up to N = 65536 (256 at the 512x512 level).  At batch 16 this is the
-    // split the old batch-dependent rule chose; small batches get fewer, longer splits (the launch is latency-bound there).
+    // in: 64..2048 keys per split, at most 32 splits up to N = 65536 (128 at the 512x512 level).  r05: half the splits of r04 --
+    // at batch 16 the 65 536-key level is 512 workgroups, one round of the two that fit a CU, each wave walks 16 key blocks instead
+    // of 8 behind the same fixed cost (tile reset, query rows, first tile's latency, the waves' merge), and the merge launch reads
+    // half the partials.  IDIFF_XATTN_SPLITS=64 (A/B runs): the r04 rule.
     (void)B;
+    static const int per = [] {
+        const char* e = getenv("IDIFF_XATTN_SPLITS");
+        return e && atoi(e) == 64 ? 64 : 32;
+    }();
     const int nkb = (N + 31) / 32;
-    int k = nkb / 64;
+    int k = nkb / per;
     if (k < 2) k = 2;
-    if (k > 32) k = 32;
+    if (k > 2048 / per) k = 2048 / per;
     if (k > nkb) k = nkb;
     *kps = k;
     *nsplit = (nkb + k - 1) / k;
