@@ -20,6 +20,6 @@ bash scripts/train_mfma_util.sh $O/train_mfma_util.txt > $O/train_mfma_util.log 
 bash scripts/step_mfma_util.sh $O/step_mfma_util.txt > $O/step_mfma_util.log 2>&1; echo "step mfma util done"
 rocprofv3 --kernel-trace --output-format csv -d $O/trace2 -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-train-leg > $O/trace2.log 2>&1
 python3 scripts/step_overlap.py $O/trace2 > $O/g_two_stream_step_overlap.txt 2>&1; rm -rf $O/trace2; tail -4 $O/g_two_stream_step_overlap.txt
-for i in 1 2 3; do python3 bench.py --no-cpu-baseline --no-train-leg --no-roofline 2>/dev/null | python3 -c "import sys, json; d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], 'steps/s', d['ms_per_step'], 'ms/step', d['launches_per_step'], 'launches')"; done > $O/a_bench_headline_repeats.txt; cat $O/a_bench_headline_repeats.txt
+for i in 1 2 3; do python3 bench.py --no-cpu-baseline --no-train-leg --no-roofline 2>/dev/null | python3 -c "import sys, json; d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], 'steps/s', d['ms_per_step'], 'ms/step')"; done > $O/a_bench_headline_repeats.txt; cat $O/a_bench_headline_repeats.txt
 IDIFF_BENCH_REHEARSAL=1 timeout -k 10 600 python3 bench.py --gpus 2 --no-cpu-baseline --no-roofline > $O/a_bench_gpus2_default_line_rehearsal.json 2> $O/a_bench_gpus2_default_line_rehearsal.err; echo "rehearsal rc=$?"
 ls $O
