@@ -227,8 +227,10 @@ def cpu_baseline(args, batch_full):
 
 
 # translation units none of whose kernels a sampling step launches (profiles/r*/g_steady_state_step_single_stream.txt lists them all):
-# the weight-gradient / backward / batched-GEMM kernels of the training path and the PSNR metrics
-TRAIN_ONLY_SOURCES = ("backward.hip", "conv_wgrad.hip", "conv_wgrad_args.h", "conv_wino_wgrad.hip", "conv_wino4_wgrad.hip", "gemm.hip", "metrics.hip")
+# the weight-gradient / backward / batched-GEMM kernels of the training path, the PSNR metrics, and the fp16 form of the ScoreMapModule
+# decoder attentions (model option score_map_if_flash: a labelled variant, never in the default step)
+TRAIN_ONLY_SOURCES = ("backward.hip", "conv_wgrad.hip", "conv_wgrad_args.h", "conv_wino_wgrad.hip", "conv_wino4_wgrad.hip", "gemm.hip", "metrics.hip",
+                      "attention_flash.hip")
 
 
 def kernel_source_hash():

@@ -303,6 +303,19 @@ int idiff_attn_tokens_bwd(const float* q, const float* k, const float* v, const 
 /* idiff_attn_tokens_fwd for ngroups (<= IDIFF_LINEAR_MAX_GROUPS) operand sets of one shape in ONE launch (host arrays of device pointers) */
 int idiff_attn_tokens_grouped_fwd(const float* const* q, const float* const* k, const float* const* v, float* const* out, int ngroups,
                                   int B, int Nq, int M, int C, int heads, float scale, int64_t ldq, int64_t ldkv, idiff_stream_t stream);
+/* The reference's half-precision attention form for the ScoreMapModule decoder (Attention_flash, models/_modified_BiomedCLIP.py:481-517,
+ * selected by TransformerDecoderLayer_scaled(if_flash=True), :552-590): q / k / v clamped to +-255 and rounded to fp16, fp32 scores and
+ * softmax statistics, probabilities rounded to fp16 for the second product, fp32 accumulation, result rounded to fp16 (returned as
+ * fp32).  Labelled REDUCED-PRECISION VARIANT (model option score_map_if_flash, inference only); csrc/attention_flash.hip.
+ * idiff_attn_tokens_f16_fwd: the operands of idiff_attn_tokens_fwd.
+ * idiff_smm_xattn_kv_f16_fwd: q [B, Nq, heads*64] (after q_proj), k, v [B, heads*64, N] channel-major (after k_proj / v_proj: unfolded --
+ * the folded form has no k / v tensor to clamp), out [B, Nq, heads*64]; heads == 4, Nq <= 8, N % 4 == 0;
+ * ws: idiff_smm_xattn_kv_f16_ws_floats(B, N) floats. */
+int idiff_attn_tokens_f16_fwd(const float* q, const float* k, const float* v, float* out, int B, int Nq, int M, int C, int heads, float scale,
+                              int64_t ldq, int64_t ldkv, idiff_stream_t stream);
+int64_t idiff_smm_xattn_kv_f16_ws_floats(int B, int N);
+int idiff_smm_xattn_kv_f16_fwd(const float* q, const float* k, const float* v, float* out, float* ws, int B, int Nq, int heads, int C, int N,
+                               float scale, idiff_stream_t stream);
 /* ScoreMapModule cross-attention, K/V projections folded onto the query side:
  *   S[b,h,q,n] = scale * sum_c qf[b,q,h,c] * mem[b,c,n];  P = softmax_n(S);  o[b,q,h,c] = sum_n P * mem[b,c,n]
  * qf, o: [B, Nq, heads, Cm];  mem: [B, Cm, N] channel-major;  Nq*heads <= 32, Cm in {72, 136, 256}.

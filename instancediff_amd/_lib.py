@@ -103,6 +103,9 @@ SIGNATURES = {
     "idiff_attn_tokens_fwd": (I, [P, P, P, P, I, I, I, I, I, F, I64, I64, c_stream]),
     "idiff_attn_tokens_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, F, I64, I64, I64, I64, I64, c_stream]),
     "idiff_smm_xattn_ws_floats": (I64, [I, I, I, I, I]),
+    "idiff_attn_tokens_f16_fwd": (I, [P, P, P, P, I, I, I, I, I, F, I64, I64, c_stream]),
+    "idiff_smm_xattn_kv_f16_ws_floats": (I64, [I, I]),
+    "idiff_smm_xattn_kv_f16_fwd": (I, [P, P, P, P, P, I, I, I, I, I, F, c_stream]),
     "idiff_smm_xattn_fwd": (I, [P, P, P, P, I, I, I, I, I, F, c_stream]),
     "idiff_smm_xattn_grouped_fwd": (I, [C.POINTER(XattnGroup), I, I, I, I, F, c_stream]),
     "idiff_smm_xattn_lse_fwd": (I, [P, P, P, P, P, I, I, I, F, c_stream]),

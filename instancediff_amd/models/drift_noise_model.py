@@ -67,12 +67,15 @@ class CLIPDriftModel():
                  dist=False, gpu=True, optimize_type='predict_noise', optimize_target='std', if_train=True, dnet_settings=None,
                  nnet_settings=None, drift_loss='l2', noise_loss='none', if_MultiScoreMap=False, score_map_ch_mult=[1, 1, 2, 4],
                  score_map_ngf=64, use_image_context=False, use_degra_context=False, CLIP_Type="CLIP", device=None, text_encoder=None,
-                 class_tokens=None, score_map_dropout=0.1, score_map_decoder="ContextDecoder"):
+                 class_tokens=None, score_map_dropout=0.1, score_map_decoder="ContextDecoder", score_map_if_flash=False):
         """score_map_dropout: dropout of the ScoreMapModules' decoder blocks in training mode -- the reference builds them with
         ContextDecoder's default 0.1 (models/_modified_BiomedCLIP.py:1194-1201; drift_noise_model.py:110-112 passes no value);
         model option `score_map_dropout` overrides (0 = the deterministic training function of rounds 1-2).
         score_map_decoder: "ContextDecoder" (the frozen spec) or "ContextDecoder_Hierachical" (TransformerDecoderLayer_scaled blocks,
-        models/_modified_BiomedCLIP.py:552-590,1247-1308); model option of the same name."""
+        models/_modified_BiomedCLIP.py:552-590,1247-1308); model option of the same name.
+        score_map_if_flash (with ContextDecoder_Hierachical): the decoder attentions in the reference's half-precision form
+        (Attention_flash, :481-517; the reference class's default) -- a labelled reduced-precision variant, inference only; False =
+        fp32, what if_flash=False computes."""
         dnet_settings = dict(dnet_settings)
         nnet_settings = dict(nnet_settings)
         for s in (dnet_settings, nnet_settings):  # :58-61
@@ -102,7 +105,7 @@ class CLIPDriftModel():
                 return None
             if settings.get('if_MultiScoreMap'):
                 return nn.ModuleList([ScoreMapModule(visual_dim=score_map_ngf * score_map_ch_mult[i], CLIP_Type=CLIP_Type,
-                                                     token_embed_dim=token_embed_dim, dropout=score_map_dropout, decoder_type=score_map_decoder)
+                                                     token_embed_dim=token_embed_dim, dropout=score_map_dropout, decoder_type=score_map_decoder, if_flash=score_map_if_flash)
                                       for i in range(len(score_map_ch_mult))])
             # reference models/drift_noise_model.py:113-114,130-131: ONE default ScoreMapModule() handed to create_net().  The UNet that
             # consumes it is not part of the reference snapshot; this build's frozen spec puts it on the
@@ -110,7 +113,7 @@ class CLIPDriftModel():
             # of that level's skip
             nf = int(settings.get('nf', 64) or 64)
             return ScoreMapModule(visual_dim=nf, CLIP_Type=CLIP_Type, token_embed_dim=token_embed_dim, dropout=score_map_dropout,
-                                  decoder_type=score_map_decoder)
+                                  decoder_type=score_map_decoder, if_flash=score_map_if_flash)
 
         self.drift_prompt = prompts(dnet_settings)
         self.noise_prompt = prompts(nnet_settings)
@@ -362,5 +365,7 @@ def create_CLIPDriftModel(train_opt, model_opt, phase='train', **extra):  # :758
         kw.update(score_map_dropout=float(model_opt['score_map_dropout']))
     if model_opt.get('score_map_decoder'):
         kw.update(score_map_decoder=str(model_opt['score_map_decoder']))
+    if model_opt.get('score_map_if_flash') is not None:
+        kw.update(score_map_if_flash=bool(model_opt['score_map_if_flash']))
     kw.update(extra)
     return CLIPDriftModel(model_opt['text_encoder_pretrain_path'], **kw)

@@ -138,6 +138,7 @@ def branch_gains(layer):
 
 class ContextDecoder(nn.Module):  # :1194-1244
     layer_cls = TransformerDecoderLayer
+    if_flash = False  # the plain TransformerDecoderLayer has no half-precision form (:520-549)
 
     def __init__(self, transformer_width=256, transformer_heads=4, transformer_layers=3, visual_dim=512, text_dim=512, dropout=0.1, outdim=None):
         super().__init__()
@@ -168,8 +169,13 @@ class ContextDecoder_Hierachical(ContextDecoder):  # :1247-1308 (if_scale=True, 
     ScoreMapModule needs outdim == visual_dim, which is what it passes).  State-dict keys equal the reference class's."""
     layer_cls = TransformerDecoderLayer_scaled
 
-    def __init__(self, transformer_width=256, transformer_heads=4, transformer_layers=6, visual_dim=512, text_dim=512, dropout=0.1, outdim=512):
+    def __init__(self, transformer_width=256, transformer_heads=4, transformer_layers=6, visual_dim=512, text_dim=512, dropout=0.1, outdim=512,
+                 if_flash=False):
+        """if_flash: the layers' attentions in the reference's half-precision form (Attention_flash, :481-517 -- the reference class's
+        default, True; here False = fp32, what `if_flash=False` computes).  The same parameters either way.  A labelled
+        reduced-precision VARIANT, inference only: decoder_tokens_flash below."""
         super().__init__(transformer_width, transformer_heads, transformer_layers, visual_dim, text_dim, dropout, outdim=outdim)
+        self.if_flash = bool(if_flash)
 
 
 DECODER_TYPES = {"ContextDecoder": ContextDecoder, "ContextDecoder_Hierachical": ContextDecoder_Hierachical}
@@ -198,9 +204,10 @@ class ScoreMapModule(nn.Module):
 
     def __init__(self, visual_dim=64, CLIP_Type="CLIP", token_embed_dim=512, text_dim=512, n_ctx=8, n_cls=5, prompt_len=10,
                  decoder_layers=3, decoder_width=256, decoder_heads=4, tokenizer=None, class_names=ARTIFACT_TYPES, dropout=0.1,
-                 decoder_type="ContextDecoder"):
+                 decoder_type="ContextDecoder", if_flash=False):
         """decoder_type: "ContextDecoder" (the frozen spec) or "ContextDecoder_Hierachical" (scaled layers,
-        _modified_BiomedCLIP.py:1247-1308) -- the candidate building blocks SURVEY.md section 8 a6 lists for the missing module."""
+        _modified_BiomedCLIP.py:1247-1308) -- the candidate building blocks SURVEY.md section 8 a6 lists for the missing module.
+        if_flash (ContextDecoder_Hierachical only): its attentions in the reference's fp16 form (Attention_flash)."""
         super().__init__()
         self.visual_dim, self.n_cls, self.text_dim = visual_dim, n_cls, text_dim
         self.contexts = nn.Parameter(torch.zeros(1, n_ctx, token_embed_dim))
@@ -214,8 +221,10 @@ class ScoreMapModule(nn.Module):
         self.text_to_visual = nn.Linear(text_dim, visual_dim)
         if decoder_type not in DECODER_TYPES:
             raise ValueError(f"decoder_type {decoder_type!r}: expected one of {sorted(DECODER_TYPES)}")
+        if if_flash and decoder_type == "ContextDecoder":
+            raise ValueError("if_flash needs decoder_type ContextDecoder_Hierachical: the reference's plain TransformerDecoderLayer has no half-precision form")
         self.context_decoder = DECODER_TYPES[decoder_type](decoder_width, decoder_heads, decoder_layers, visual_dim, text_dim, dropout=dropout,
-                                                           **({} if decoder_type == "ContextDecoder" else {"outdim": visual_dim}))
+                                                           **({} if decoder_type == "ContextDecoder" else {"outdim": visual_dim, "if_flash": if_flash}))
         self.gamma = nn.Parameter(torch.ones(visual_dim) * 1e-4)
         self._text_cache = None
 
@@ -296,6 +305,9 @@ def decoder_tokens_grouped(smms, feats, texts, cache_prefix=True, plain_out=Fals
     whatever the row count), so a net's four chains cost 23 token launches instead of 92.  Per module and layer there remain the
     passes over the feature map: the fused memory projection and the cross-attention (idiff_smm_xattn_fwd).
     Returns, per module, tv [B*K, C] = text_to_visual(text) + gamma * out_proj(LN(x_L))   (plain_out: out_proj(LN(x_L)))."""
+    if any(m.context_decoder.if_flash for m in smms):  # the half-precision variant: module by module, unfolded keys / values
+        assert all(m.context_decoder.if_flash for m in smms)  # (the training step refuses the variant: unet_autograd.forward_train)
+        return [decoder_tokens_flash(m, f, t, plain_out=plain_out) for m, f, t in zip(smms, feats, texts)]
     L = len(smms)
     dec0 = smms[0].context_decoder
     Wd, heads, nlayers = dec0.width, dec0.heads, len(dec0.decoder)
@@ -438,6 +450,48 @@ def decoder_tokens_grouped(smms, feats, texts, cache_prefix=True, plain_out=Fals
     # residual, per-column gain and LayerNorm fused into the last linear
     return ops.linear_t_grouped([dict(x=x, wT=wT(s["dec"].out_proj[1]), bias=s["dec"].out_proj[1].bias, res=t2v, gscale=s["m"].gamma,
                                       ln=(s["dec"].out_proj[0].weight, s["dec"].out_proj[0].bias, s["dec"].out_proj[0].eps)) for x, s, t2v in zip(xs, st, t2vs)])
+
+
+def decoder_tokens_flash(m, feat, text, plain_out=False):
+    """decoder_tokens_grouped for ONE ScoreMapModule whose ContextDecoder_Hierachical runs its attentions in the reference's
+    half-precision form (TransformerDecoderLayer_scaled(if_flash=True) -> Attention_flash, _modified_BiomedCLIP.py:481-517,552-590):
+    every layer's q / k / v go through the clamp to +-255 and the fp16 rounding, so the keys and values are materialised --
+    k = k_proj(mem), v = v_proj(mem) as 1x1 convs over the full 256-row memory, [B, 256, N] each and per layer -- instead of being
+    folded onto the queries.  3 x 2 passes over a [B, 256, N] tensor more than the fp32 path: the variant exists for the reference's
+    option surface (BASELINE c5 "fp16 MFMA attention"), not for speed.  Linears, LayerNorms, the MLP and the gains are the fp32 path's."""
+    dec = m.context_decoder
+    Wd, heads = dec.width, dec.heads
+    assert Wd == 256 and heads == 4, "the half-precision cross-attention kernel is built for 4 heads x 64"
+    B, C, H, W = feat.shape
+    K = text.shape[1]
+    R = B * K
+    mp = dec.memory_proj
+    wmp = _PREP.get(("mp", mp[1]), (mp[1].weight,), lambda: ops.pack_conv_weight(mp[1].weight.detach().reshape(Wd, C, 1, 1).contiguous()))
+    mem = ops.smm_memproj(feat, mp[0].weight, mp[0].bias, wmp, mp[1].bias, mp[2].weight, mp[2].bias, eps=mp[0].eps).reshape(B, Wd, H, W)
+    t2d = text.reshape(R, m.text_dim)
+    x = ops.linear_t(t2d, wT(dec.text_proj[1]), bias=dec.text_proj[1].bias, ln=(dec.text_proj[0].weight, dec.text_proj[0].bias, dec.text_proj[0].eps))
+    for l in dec.decoder:
+        g_sa, g_ca, g_mlp = branch_gains(l)
+        sa, ca = l.self_attn, l.cross_attn
+        qkvT = _PREP.get(("qkvT", sa), (sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight),
+                         lambda sa=sa: torch.cat([sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight], 0).detach().t().contiguous())
+        qkv = ops.linear_t(x, qkvT, ln=(l.norm1.weight, l.norm1.bias, l.norm1.eps))
+        att = ops.attn_tokens_packed_f16(qkv.reshape(B, K, 3 * Wd), heads, sa.scale)
+        x = ops.linear_t(att.reshape(R, Wd), wT(sa.proj), bias=sa.proj.bias, res=x, gscale=g_sa)
+        qc = ops.linear_t(x, wT(ca.q_proj), ln=(l.norm2.weight, l.norm2.bias, l.norm2.eps))
+        wk = _PREP.get(("kconv", ca), (ca.k_proj.weight,), lambda ca=ca: ops.pack_conv_weight(ca.k_proj.weight.detach().reshape(Wd, Wd, 1, 1).contiguous()))
+        wv = _PREP.get(("vconv", ca), (ca.v_proj.weight,), lambda ca=ca: ops.pack_conv_weight(ca.v_proj.weight.detach().reshape(Wd, Wd, 1, 1).contiguous()))
+        kk = ops.conv2d(mem, wk, None, 1, Wd).reshape(B, Wd, H * W)
+        vv = ops.conv2d(mem, wv, None, 1, Wd).reshape(B, Wd, H * W)
+        av = ops.smm_xattn_kv_f16(qc.reshape(B, K, Wd), kk, vv, heads, ca.scale)
+        x = ops.linear_t(av.reshape(R, Wd), wT(ca.proj), bias=ca.proj.bias, res=x, gscale=g_ca)
+        hm = ops.linear_t(x, wT(l.mlp[0]), bias=l.mlp[0].bias, act_out=ops.ACT_GELU, ln=(l.norm3.weight, l.norm3.bias, l.norm3.eps))
+        x = ops.linear_t(hm, wT(l.mlp[3]), bias=l.mlp[3].bias, res=x, gscale=g_mlp)
+    op = dec.out_proj
+    if plain_out:
+        return ops.linear_t(x, wT(op[1]), bias=op[1].bias, ln=(op[0].weight, op[0].bias, op[0].eps))
+    t2v = ops.linear_t(t2d, wT(m.text_to_visual), bias=m.text_to_visual.bias)
+    return ops.linear_t(x, wT(op[1]), bias=op[1].bias, res=t2v, gscale=m.gamma, ln=(op[0].weight, op[0].bias, op[0].eps))
 
 
 def _scoremaps(feats, tvs, idx):

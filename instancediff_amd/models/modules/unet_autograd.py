@@ -374,6 +374,9 @@ def _smm_all(smms, feats, feats_n, text_encoder, idx):
 
 
 def forward_train(net, x_a, x_b, t, names, text_encoder, image_context=None):
+    if any(m.context_decoder.if_flash for m in net.score_map_modules()):
+        raise RuntimeError("score_map_if_flash (the fp16 form of the ScoreMapModule decoder attentions) is an inference-only variant: "
+                           "no backward is built for it")
     dev = x_a.device
     B, _, H, W = x_a.shape
     if not torch.is_tensor(t):

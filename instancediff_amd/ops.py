@@ -510,6 +510,34 @@ def attn_tokens_packed(qkv, heads, scale):
     return out
 
 
+def attn_tokens_packed_f16(qkv, heads, scale):
+    """attn_tokens_packed in the reference's half-precision form (Attention_flash: +-255 clamp, fp16 operands and result, fp32
+    statistics; idiff_attn_tokens_f16_fwd) -- the `if_flash` variant of the ScoreMapModule decoder"""
+    lib = _lib.load()
+    _c(qkv, "qkv")
+    B, Nq, C3 = qkv.shape
+    Cc = C3 // 3
+    out = torch.empty((B, Nq, Cc), device=qkv.device, dtype=torch.float32)
+    base = qkv.data_ptr()
+    check(lib.idiff_attn_tokens_f16_fwd(C.c_void_p(base), C.c_void_p(base + 4 * Cc), C.c_void_p(base + 8 * Cc), _p(out), B, Nq, Nq, Cc, heads, scale,
+                                        C3, C3, _stream()), "attn_tokens_f16_fwd")
+    return out
+
+
+def smm_xattn_kv_f16(q, k, v, heads, scale):
+    """cross-attention of q [B,Nq,C] over UNFOLDED keys / values k, v [B,C,N] (channel-major) in the reference's half-precision form
+    (Attention_flash) -> [B,Nq,C]; C = heads * 64, heads = 4, Nq <= 8"""
+    lib = _lib.load()
+    _c(q, "q"), _c(k, "k"), _c(v, "v")
+    B, Nq, Cc = q.shape
+    N = k.shape[2]
+    assert tuple(k.shape) == (B, Cc, N) and tuple(v.shape) == (B, Cc, N)
+    ws = torch.empty((lib.idiff_smm_xattn_kv_f16_ws_floats(B, N),), device=q.device, dtype=torch.float32)
+    out = torch.empty_like(q)
+    check(lib.idiff_smm_xattn_kv_f16_fwd(_p(q), _p(k), _p(v), _p(out), _p(ws), B, Nq, heads, Cc, N, scale, _stream()), "smm_xattn_kv_f16_fwd")
+    return out
+
+
 def smm_xattn(qf, mem, scale):
     """qf [B,Nq,heads,Cm]; mem [B,Cm,N] -> o [B,Nq,heads,Cm] (attention-weighted mem rows)."""
     lib = _lib.load()

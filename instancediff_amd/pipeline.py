@@ -16,10 +16,11 @@ def load_options(path=DEFAULT_YAML, is_train=False):
     return option.dict_to_nonedict(option.parse(path, is_train=is_train))
 
 
-def build(opt=None, phase="test", device=None, T=None, seed=0, dist=False, sde_overrides=None, score_map_dropout=None, score_map_decoder=None):
+def build(opt=None, phase="test", device=None, T=None, seed=0, dist=False, sde_overrides=None, score_map_dropout=None, score_map_decoder=None, score_map_if_flash=None):
     """-> (model: CLIPDriftModel, sde).  Random-init weights (seed) as the reference does for a fresh run.
     score_map_dropout: overrides the model option of that name (training-mode dropout of the ScoreMapModule decoder blocks; 0.1).
-    score_map_decoder: overrides the model option of that name ("ContextDecoder" | "ContextDecoder_Hierachical")."""
+    score_map_decoder: overrides the model option of that name ("ContextDecoder" | "ContextDecoder_Hierachical").
+    score_map_if_flash: overrides the model option of that name (the fp16 form of the Hierachical decoder's attentions)."""
     opt = opt or load_options()
     train_opt = copy.deepcopy(dict(opt['train']))
     train_opt['dist'] = dist
@@ -31,6 +32,9 @@ def build(opt=None, phase="test", device=None, T=None, seed=0, dist=False, sde_o
     if score_map_decoder is not None:
         model_opt = copy.copy(model_opt)
         model_opt['score_map_decoder'] = str(score_map_decoder)
+    if score_map_if_flash is not None:
+        model_opt = copy.copy(model_opt)
+        model_opt['score_map_if_flash'] = bool(score_map_if_flash)
     torch.manual_seed(seed)
     from .models.drift_noise_model import create_CLIPDriftModel  # registry target, imported for the device kwarg
     model = create_CLIPDriftModel(train_opt, model_opt, phase=phase, device=device) if device is not None else \

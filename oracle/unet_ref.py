@@ -41,7 +41,29 @@ def attention_core(q, k, v, num_heads, scale):
     return torch.einsum('bknm,bmkc->bnkc', attn, v).reshape(B, N, C)
 
 
-class Attention(nn.Module):  # _modified_BiomedCLIP.py:448-478 (qkv_bias=False, dropouts = 0)
+def attention_core_flash(q, k, v, num_heads, scale):
+    """The attention of Attention_flash (_modified_BiomedCLIP.py:509-513):
+        flash_attn_func(clamp(q, -255, 255).half(), clamp(k, ...).half(), clamp(v, ...).half(), softmax_scale=scale).float()
+    restated on the CPU.  PARITY UNPINNED for this form: flash_attn (Dao-AILab/flash-attention, unpinned in the reference: a bare import,
+    _modified_BiomedCLIP.py:14-20) is not importable here, so the recipe of its forward pass is restated from the FlashAttention-2 paper
+    (arXiv:2307.08691, Algorithm 1) and its published kernel: scores and softmax statistics in fp32, the unnormalised probabilities cast
+    to the input dtype (fp16) for the second product, fp32 accumulation, the normalised output cast to fp16.  (flash-attn takes the
+    probabilities against the RUNNING row maximum of its key blocks; this restatement uses the row's final maximum -- the fp16 roundings
+    of the probabilities then differ in their last bit for the blocks seen before the maximum: covered by the tests' tolerance.)"""
+    B, N, C = q.shape
+    M = k.shape[1]
+    h16 = lambda t: t.clamp(min=-255, max=255).to(torch.float16).to(torch.float32)  # noqa: E731
+    q = h16(q).reshape(B, N, num_heads, C // num_heads)
+    k = h16(k).reshape(B, M, num_heads, C // num_heads)
+    v = h16(v).reshape(B, M, num_heads, C // num_heads)
+    s = torch.einsum('bnkc,bmkc->bknm', q, k) * scale
+    p = torch.exp(s - s.amax(dim=-1, keepdim=True))
+    l = p.sum(dim=-1)                                        # [B, heads, N], fp32 probabilities
+    o = torch.einsum('bknm,bmkc->bnkc', p.to(torch.float16).to(torch.float32), v) / l.permute(0, 2, 1)[..., None]
+    return o.to(torch.float16).to(torch.float32).reshape(B, N, C)
+
+
+class Attention(nn.Module):  # _modified_BiomedCLIP.py:448-478 (qkv_bias=False, dropouts = 0); flash = True: Attention_flash, :481-517 (same parameters)
     def __init__(self, dim, num_heads=8):
         super().__init__()
         self.num_heads = num_heads
@@ -50,9 +72,11 @@ class Attention(nn.Module):  # _modified_BiomedCLIP.py:448-478 (qkv_bias=False, 
         self.k_proj = nn.Linear(dim, dim, bias=False)
         self.v_proj = nn.Linear(dim, dim, bias=False)
         self.proj = nn.Linear(dim, dim)
+        self.flash = False
 
     def forward(self, q, k, v):
-        x = attention_core(self.q_proj(q), self.k_proj(k), self.v_proj(v), self.num_heads, self.scale)
+        core = attention_core_flash if self.flash else attention_core
+        x = core(self.q_proj(q), self.k_proj(k), self.v_proj(v), self.num_heads, self.scale)
         return self.proj(x)
 
 
@@ -95,9 +119,10 @@ class TransformerDecoderLayer(nn.Module):  # :520-549; dropout sites as the refe
         return x
 
 
-class TransformerDecoderLayer_scaled(TransformerDecoderLayer):  # :552-590 with if_flash=False (plain Attention)
-    def __init__(self, d_model, nhead, dropout=0.1):
+class TransformerDecoderLayer_scaled(TransformerDecoderLayer):  # :552-590; if_flash=False: plain Attention, True: Attention_flash (:561-566)
+    def __init__(self, d_model, nhead, dropout=0.1, if_flash=False):
         super().__init__(d_model, nhead, dropout)
+        self.self_attn.flash = self.cross_attn.flash = bool(if_flash)
         self.gamma_sa = nn.Parameter(torch.ones((1, 1, d_model)) * 1e-1)
         self.gamma_ca = nn.Parameter(torch.ones((1, 1, d_model)) * 1e-1)
         self.gamma_mlp = nn.Parameter(torch.ones((1, 1, d_model)) * 1e-1)
@@ -131,11 +156,13 @@ class ContextDecoder(nn.Module):  # :1194-1244
         return self.out_proj(x)
 
 
-class ContextDecoder_Hierachical(ContextDecoder):  # :1247-1308, if_scale=True / if_flash=False: scaled layers, free output width
+class ContextDecoder_Hierachical(ContextDecoder):  # :1247-1308, if_scale=True: scaled layers, free output width; if_flash as the layers'
     layer_cls = TransformerDecoderLayer_scaled
 
-    def __init__(self, transformer_width=256, transformer_heads=4, transformer_layers=6, visual_dim=512, text_dim=512, outdim=512):
+    def __init__(self, transformer_width=256, transformer_heads=4, transformer_layers=6, visual_dim=512, text_dim=512, outdim=512, if_flash=False):
         super().__init__(transformer_width, transformer_heads, transformer_layers, visual_dim, text_dim, outdim=outdim)
+        for layer in self.decoder:
+            layer.self_attn.flash = layer.cross_attn.flash = bool(if_flash)
 
 
 class ScoreMapModule(nn.Module):
@@ -143,7 +170,7 @@ class ScoreMapModule(nn.Module):
     conv feature -> text (+) -> text (x) feature -> score map [B,K,h,w]  (figure LDD_Overall2.png)."""
 
     def __init__(self, visual_dim=64, CLIP_Type="CLIP", token_embed_dim=512, text_dim=512, n_ctx=8, n_cls=5,
-                 prompt_len=10, decoder_layers=3, decoder_width=256, decoder_heads=4, decoder_type="ContextDecoder"):
+                 prompt_len=10, decoder_layers=3, decoder_width=256, decoder_heads=4, decoder_type="ContextDecoder", if_flash=False):
         super().__init__()
         self.visual_dim = visual_dim
         self.contexts = nn.Parameter(torch.zeros(1, n_ctx, token_embed_dim))
@@ -152,7 +179,8 @@ class ScoreMapModule(nn.Module):
         if decoder_type == "ContextDecoder":
             self.context_decoder = ContextDecoder(decoder_width, decoder_heads, decoder_layers, visual_dim, text_dim)
         else:
-            self.context_decoder = ContextDecoder_Hierachical(decoder_width, decoder_heads, decoder_layers, visual_dim, text_dim, outdim=visual_dim)
+            self.context_decoder = ContextDecoder_Hierachical(decoder_width, decoder_heads, decoder_layers, visual_dim, text_dim, outdim=visual_dim,
+                                                              if_flash=if_flash)
         self.gamma = nn.Parameter(torch.ones(visual_dim) * 1e-4)
 
     def forward(self, feat, text_encoder):

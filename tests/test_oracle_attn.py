@@ -78,3 +78,41 @@ def test_hierarchical_context_decoder_matches_reference(golden_attn, tag):
         out = m(torch.from_numpy(golden_attn[f"{tag}/text"]), torch.from_numpy(golden_attn[f"{tag}/visual"]))
     assert out.shape == (2, 5, outdim)
     assert rel_err(out, golden_attn[f"{tag}/out"]) < TOL
+
+
+def test_oracle_flash_form_is_the_fp32_attention_on_rounded_operands():
+    """oracle/unet_ref.attention_core_flash (the restatement of Attention_flash's flash_attn_func call, :509-513; parity unpinned:
+    flash_attn is not importable here) against first principles: on operands that are exactly representable in fp16 and within
+    +-255 the only differences from the fp32 attention are the fp16 roundings of the probabilities and of the result (<= 2^-10
+    relative each); operands beyond +-255 are clamped; and the option reaches every layer of the oracle's hierarchical decoder."""
+    from oracle import unet_ref
+    g = torch.Generator().manual_seed(5)
+    B, N, M, C, heads = 2, 5, 40, 256, 4
+    q = (torch.randn(B, N, C, generator=g) * 2).half().float()
+    k = (torch.randn(B, M, C, generator=g) * 2).half().float()
+    v = (torch.randn(B, M, C, generator=g) * 2).half().float()
+    scale = (C // heads) ** -0.5
+    plain = unet_ref.attention_core(q, k, v, heads, scale)
+    flash = unet_ref.attention_core_flash(q, k, v, heads, scale)
+    rel = float((plain - flash).abs().max() / plain.abs().max())
+    assert 0.0 < rel < 3e-3, rel
+    assert torch.equal(flash, flash.half().float())  # the result is fp16-valued
+    big = v.clone()
+    big[0, 3, 17] = 1000.0
+    clamped = v.clone()
+    clamped[0, 3, 17] = 255.0
+    assert torch.equal(unet_ref.attention_core_flash(q, k, big, heads, scale), unet_ref.attention_core_flash(q, k, clamped, heads, scale))
+    smm = unet_ref.ScoreMapModule(visual_dim=64, decoder_type="ContextDecoder_Hierachical", if_flash=True)
+    assert all(l.self_attn.flash and l.cross_attn.flash for l in smm.context_decoder.decoder)
+    assert not any(l.self_attn.flash for l in unet_ref.ScoreMapModule(visual_dim=64, decoder_type="ContextDecoder_Hierachical").context_decoder.decoder)
+
+
+def test_product_refuses_flash_form_on_the_plain_decoder():
+    """the reference's plain TransformerDecoderLayer (:520-549) has no half-precision form: ScoreMapModule(if_flash=True) needs the
+    hierarchical decoder"""
+    import pytest
+    from instancediff_amd.models.modules.MSM_degEmb_Unet import ScoreMapModule
+    with pytest.raises(ValueError, match="ContextDecoder_Hierachical"):
+        ScoreMapModule(visual_dim=64, if_flash=True)
+    m = ScoreMapModule(visual_dim=64, decoder_type="ContextDecoder_Hierachical", if_flash=True)
+    assert m.context_decoder.if_flash and not ScoreMapModule(visual_dim=64, decoder_type="ContextDecoder_Hierachical").context_decoder.if_flash

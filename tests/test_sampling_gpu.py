@@ -17,13 +17,14 @@ from oracle import sde_ref, unet_ref  # noqa: E402
 DEV = "cuda"
 
 
-def oracle_nets(model, decoder_type="ContextDecoder"):
+def oracle_nets(model, decoder_type="ContextDecoder", if_flash=False):
     opt = pipeline.load_options()
     mo = opt['models']['DriftNoise']
     refs = []
     for key, net in (('dnet_settings', model.drift_net), ('nnet_settings', model.noise_net)):
         s = {k: v for k, v in dict(mo[key]).items() if k not in ("module_name", "class_name")}
-        smm = nn.ModuleList([unet_ref.ScoreMapModule(visual_dim=mo['score_map_ngf'] * m, decoder_type=decoder_type) for m in mo['score_map_ch_mult']])
+        smm = nn.ModuleList([unet_ref.ScoreMapModule(visual_dim=mo['score_map_ngf'] * m, decoder_type=decoder_type, if_flash=if_flash)
+                             for m in mo['score_map_ch_mult']])
         r = unet_ref.LearnableForwardUNet_MultiScoreMap(CLIP_ScoreMapModule=smm, use_image_context=True, **s).eval()
         r.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()})
         refs.append(r)
@@ -343,3 +344,101 @@ def oracle_nets_drop_gains(model):
         r.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items() if ".gamma_sa" not in k and ".gamma_ca" not in k and ".gamma_mlp" not in k})
         refs.append(r)
     return refs
+
+
+# ---- the reference's half-precision form of the decoder attentions (TransformerDecoderLayer_scaled(if_flash=True) -> Attention_flash,
+# models/_modified_BiomedCLIP.py:481-517,552-590): model option score_map_if_flash, a labelled reduced-precision VARIANT --------------------
+def test_flash_form_token_attention_vs_emulation():
+    """idiff_attn_tokens_f16_fwd against oracle/unet_ref.attention_core_flash (clamp +-255, fp16 operands / probabilities / result,
+    fp32 statistics); operands beyond +-255 included so the clamp matters"""
+    g = torch.Generator().manual_seed(610)
+    B, K, C, heads = 3, 5, 256, 4
+    qkv = torch.randn(B, K, 3 * C, generator=g) * 1.5
+    qkv[0, 1, 7] = 300.0
+    qkv[1, 2, C + 9] = -400.0
+    qkv[2, 0, 2 * C + 11] = 290.0
+    scale = (C // heads) ** -0.5
+    q, k, v = qkv.split(C, dim=2)
+    ref = unet_ref.attention_core_flash(q, k, v, heads, scale)
+    out = ops.attn_tokens_packed_f16(qkv.to(DEV).contiguous(), heads, scale).cpu()
+    plain = unet_ref.attention_core(q, k, v, heads, scale)
+    err = float((out - ref).abs().max() / ref.abs().max())
+    print(f"flash-form token attention: rel err vs the emulation {err:.2e}; the fp32 attention differs by {float((plain - ref).abs().max() / ref.abs().max()):.2e}")
+    assert err < 2e-3  # one fp16 ulp of the result (the kernel's sum order differs from the emulation's)
+    assert float(out.abs().max()) <= 255.0
+
+
+@pytest.mark.parametrize("N", [1024, 4096 + 36])
+def test_flash_form_cross_attention_vs_emulation(N):
+    """idiff_smm_xattn_kv_f16_fwd (unfolded k / v, wave = head, key splits + merge) against the same emulation; a key count that is not a
+    multiple of the 32-key block in the second case"""
+    g = torch.Generator().manual_seed(611 + N)
+    B, K, C, heads = 2, 5, 256, 4
+    q = torch.randn(B, K, C, generator=g) * 2.0
+    k = torch.randn(B, N, C, generator=g) * 1.2
+    v = torch.randn(B, N, C, generator=g) * 3.0
+    k[0, 3, 5], v[1, 7, 200], q[1, 2, 100] = 700.0, -900.0, 400.0
+    scale = (C // heads) ** -0.5
+    ref = unet_ref.attention_core_flash(q, k, v, heads, scale)
+    out = ops.smm_xattn_kv_f16(q.to(DEV), k.permute(0, 2, 1).contiguous().to(DEV), v.permute(0, 2, 1).contiguous().to(DEV), heads, scale).cpu()
+    out2 = ops.smm_xattn_kv_f16(q.to(DEV), k.permute(0, 2, 1).contiguous().to(DEV), v.permute(0, 2, 1).contiguous().to(DEV), heads, scale).cpu()
+    assert torch.equal(out, out2)
+    plain = unet_ref.attention_core(q, k, v, heads, scale)
+    err = float((out - ref).abs().max() / ref.abs().max())
+    print(f"flash-form cross attention N={N}: rel err vs the emulation {err:.2e}; the fp32 attention differs by {float((plain - ref).abs().max() / ref.abs().max()):.2e}")
+    assert err < 2e-3
+    # batch invariance: a sample alone gives the same bits (the key split is a function of N alone)
+    one = ops.smm_xattn_kv_f16(q[1:].to(DEV), k[1:].permute(0, 2, 1).contiguous().to(DEV), v[1:].permute(0, 2, 1).contiguous().to(DEV), heads, scale).cpu()
+    assert torch.equal(one, out[1:])
+
+
+def test_flash_form_decoder_chain_vs_oracle_and_refused_in_training():
+    """model options score_map_decoder: ContextDecoder_Hierachical + score_map_if_flash: a 6-step 64x64 chain against the oracle built
+    with the same options (Attention_flash emulated on the CPU), against the fp32 form of the same weights (the variant must differ from
+    it, by little), and the training step's loud refusal"""
+    T, B, H = 6, 2, 64
+    model, sde = pipeline.build(phase="test", device=torch.device(DEV), T=T, seed=0, score_map_decoder="ContextDecoder_Hierachical",
+                                score_map_if_flash=True)
+    model.set_eval()
+    g = torch.Generator().manual_seed(199)
+    with torch.no_grad():
+        for net in (model.drift_net, model.noise_net):
+            for m in net.CLIP_ScoreMapModule:
+                assert m.context_decoder.if_flash
+                for l in m.context_decoder.decoder:
+                    for name in ("gamma_sa", "gamma_ca", "gamma_mlp"):
+                        getattr(l, name).copy_((0.3 + 0.3 * torch.randn((1, 1, 256), generator=g)).to(DEV))
+    make_scoremap_branch_visible(model)
+    batch = make_batch(B, H, seed=6)
+    x_T = batch['input'] + 0.4 * torch.randn(batch['input'].shape, generator=g)
+    noises = torch.randn((T,) + tuple(batch['input'].shape), generator=g)
+
+    def run():
+        model.feed_data(batch)
+        model.test(x_T=x_T.to(DEV), noises=noises.to(DEV))
+        return torch.from_numpy(model.get_visuals())
+    out = run()
+    for net in (model.drift_net, model.noise_net):
+        for m in net.CLIP_ScoreMapModule:
+            m.context_decoder.if_flash = False
+    out32 = run()
+    for net in (model.drift_net, model.noise_net):
+        for m in net.CLIP_ScoreMapModule:
+            m.context_decoder.if_flash = True
+    refs = oracle_nets(model, decoder_type="ContextDecoder_Hierachical", if_flash=True)
+    assert all(l.cross_attn.flash and l.self_attn.flash for r in refs for m in r.CLIP_ScoreMapModule for l in m.context_decoder.decoder)
+    with torch.no_grad():
+        ref = sde_ref.DriftSDERef(T, refs[0], refs[1], max_sigma=0.4).reverse_ddpm(batch['input'], batch['names'], unet_ref.StubTextEncoder(), x_T, noises,
+                                                                                     image_context=batch['A_emb'])
+    err = float((out - ref).abs().max())
+    worst = max(abs(sde_ref.psnr(out[b], batch['target'][b]) - sde_ref.psnr(ref[b], batch['target'][b])) for b in range(B))
+    d32 = float((out - out32).abs().max())
+    print(f"flash-form decoder chain: max|hip-oracle(flash)| {err:.3e}, worst |dPSNR| {worst:.2e} dB; against the fp32 form of the same weights {d32:.3e}")
+    assert d32 > 0.0, "the half-precision kernels did not run"
+    assert worst < 1e-3 and err < 5e-4 and d32 < 5e-3
+    # training: refused loudly
+    tm, _ = pipeline.build(phase="train", device=torch.device(DEV), T=T, seed=0, score_map_decoder="ContextDecoder_Hierachical", score_map_if_flash=True)
+    tm.set_train()
+    tm.feed_data(make_batch(2, 32, seed=3))
+    with pytest.raises(RuntimeError, match="inference-only"):
+        tm.optimize_parameters()
