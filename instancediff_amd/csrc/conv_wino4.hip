@@ -281,16 +281,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a, const Geo4& g
     // preserve it around asm.  None of these loads is in hipcc's vmcnt bookkeeping.  Every statement opens with `s_nop 4`: an "s"
     // operand may be fresh from a VALU write (readfirstlane, the v_readlane of an SGPR spill reload) and a buffer instruction that
     // reads it as descriptor or soffset needs five wait states hipcc's hazard recognizer does not insert for inline asm.
-    // The 2304 float4 of weight chunk p -> U[buf] in 1-KB pieces per wave: U_ALL pieces by all eight waves, the remaining 2304 - 512 U_ALL
-    // float4 in U_LIGHT pieces by the light waves alone (piece j: float4 512 U_ALL + 256 j + (tid - 256)): 4 + 5 pieces for heavy + light
-    // waves, 3 + 6 with the prologue (whose heavy waves also activate what they stage).  r05, linked at the same position in one call:
-    // 23.05 -> 22.78 ms/step for the 3 + 6 form of the prologue instantiation.  READ THIS BEFORE EDITING THE KERNEL: its time depends on
-    // where its code lands, by 2..3 % of the step and 4..8 % on the two-source layers -- four or eight bytes of s_nop in front of either
-    // wave class's body, or the chunk loop's head anchored with .p2align 6 at any of the sixteen 4-byte phases, all measured 23.0..23.3
-    // ms/step against 22.7..22.8 for this listing (profiles/r05/x_wino4_code_placement.txt) -- so an edit's A/B is only meaningful
-    // against padded builds of both sides, and part of the step above may be placement rather than the split.
-    constexpr int U_ALL = SPEC == 2 ? 3 : 4, U_LIGHT = 9 - 2 * U_ALL;
-    constexpr int U_LOFF = U_ALL * NT * 16 - 4096;  // byte offset of the light waves' first own piece, less their thread offset
+    // The 2304 float4 of weight chunk p -> U[buf]: four 1-KB pieces per wave, the last 256 float4 by the light waves.
     const unsigned u_voff = tid * 16;
     auto dma_u = [&](int p, int buf) {
         const bool inA = p < nchunks;
@@ -300,37 +291,24 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a, const Geo4& g
         asm volatile(
             "s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds\n\t"
             "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %4 offen lds\n\t"
-            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %5 offen lds"
-            ::"v"(u_voff), "s"(rsu), "s"(lds0), "s"(so), "s"(so + NT * 16), "s"(so + 2 * NT * 16)
+            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %5 offen lds\n\t"
+            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %6 offen lds"
+            ::"v"(u_voff), "s"(rsu), "s"(lds0), "s"(so), "s"(so + NT * 16), "s"(so + 2 * NT * 16), "s"(so + 3 * NT * 16)
             : "memory", "scc");
-        if (U_ALL == 4) {
-            const unsigned lds3 = __builtin_amdgcn_readfirstlane(lds0 + 3 * NT * 16);
-            asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(u_voff), "s"(rsu), "s"(lds3),
-                         "s"(so + 3 * NT * 16)
+        if (!HEAVY) {  // waves 4-7: float4 2048 + (tid - 256) of the chunk
+            const unsigned lds4 = __builtin_amdgcn_readfirstlane(lds0 + 4 * NT * 16 - 256 * 16);
+            asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(u_voff), "s"(rsu), "s"(lds4),
+                         "s"(so + 4 * NT * 16 - 256 * 16)
                          : "memory");
-        }
-        if (!HEAVY) {  // waves 4-7
-            const unsigned lds4 = __builtin_amdgcn_readfirstlane(lds0 + U_LOFF);
-            asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(u_voff), "s"(rsu), "s"(lds4), "s"(so + U_LOFF)
-                         : "memory");
-            if (U_LIGHT == 3) {
-                asm volatile(
-                    "s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds\n\t"
-                    "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %4 offen lds"
-                    ::"v"(u_voff), "s"(rsu), "s"(lds4 + 4096u), "s"(so + U_LOFF + 4096), "s"(so + U_LOFF + 8192)
-                    : "memory", "scc");
-            }
         }
     };
-    // one 1-KB piece of the same copy: i = 0 .. U_ALL - 1 by every wave, i = U_ALL .. U_ALL + U_LIGHT - 1 the light waves' own.  Between two
-    // barriers a chunk's pieces are dealt out one per quad: eight waves issuing 36 of them at once right behind the barrier held the last
-    // wave in line ~1 k cycles
+    // one 1-KB piece of the same copy: i = 0..3, and 4 = the light waves' fifth.  Between two barriers a chunk's pieces are dealt
+    // out one per quad: eight waves issuing 36 of them at once right behind the barrier held the last wave in line ~1 k cycles
     auto dma_u_piece = [&](int p, int buf, int i) {
         const bool inA = p < nchunks;
-        const int off = i < U_ALL ? i * NT * 16 : U_LOFF + (i - U_ALL) * 4096;
-        const int so = (inA ? p : p - nchunks) * ustride_b + off;
+        const int so = (inA ? p : p - nchunks) * ustride_b + (i < 4 ? i * NT * 16 : 4 * NT * 16 - 256 * 16);
         const __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(inA ? puA : puB), 0, inA ? 0x7fffffff : nrB, RSRC_FLAGS);
-        const unsigned lds0 = __builtin_amdgcn_readfirstlane(U_LDS0 + (unsigned)buf * U_BYTES + (unsigned)wave * 1024u + (unsigned)off);
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane(U_LDS0 + (unsigned)buf * U_BYTES + (unsigned)wave * 1024u + (unsigned)(i < 4 ? i * NT * 16 : 4 * NT * 16 - 256 * 16));
         asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(u_voff), "s"(rsu), "s"(lds0), "s"(so) : "memory");
     };
     // The gathered patch of position p -> R slot at byte offset rslot: six dwords per thread, element tid + i*512
@@ -399,7 +377,7 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a, const Geo4& g
             R[i * NT] = ((om >> i) & 1u) ? 0.f : x;
         }
     };
-    constexpr int N_U = HEAVY ? U_ALL : U_ALL + U_LIGHT;  // 1-KB weight copies per wave and chunk
+    constexpr int N_U = HEAVY ? 4 : 5;  // 1-KB weight copies per wave and chunk
 
     // ---- input transform B^T d B of an R slot -> V[buf].  Thread = (ci = k4, tile (tyl, tx) of half-patch thalf) x row set:
     //   heavy waves 0-3: Winograd rows (1,2) (trole 0) or (3,4) (trole 1):  X = d4 + al*d2, Y = d3 + al*d1, rows X +- be*Y
@@ -596,8 +574,8 @@ __device__ __forceinline__ void conv_wino4_body(const ConvArgs& a, const Geo4& g
                     acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, ZERO ? z4 : acc[4 * q + 2], 0, 0, 0);
                     acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, ZERO ? z4 : acc[4 * q + 3], 0, 0, 0);
                     if (!ZERO) {  // (chunk 0: U(1) was copied whole before the epilogue / by the fill)
-                        if (q < U_ALL - 1) dma_u_piece(cc + 1, PAR ^ 1, q + 1);
-                        if (!HEAVY && q >= U_ALL - 1 && q < U_ALL - 1 + U_LIGHT) dma_u_piece(cc + 1, PAR ^ 1, q + 1);
+                        if (q < 3) dma_u_piece(cc + 1, PAR ^ 1, q + 1);
+                        if (q == 3 && !HEAVY) dma_u_piece(cc + 1, PAR ^ 1, 4);
                     }
                     if (SPEC == 2 && q == 5) {
                         // position c+2 (requested over the previous chunk) has arrived: younger than it are the N_U copies of

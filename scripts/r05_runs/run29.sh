@@ -1,5 +1,5 @@
 #!/bin/bash
-# code-placement probe of conv_wino4_kernel: the tree's kernel with 4 / 8 bytes of s_nop in front of the heavy / light wave class's body
+# (run with variants that LACKED -fno-slp-vectorize: see profiles/r05/x_wino4_variants.txt) code-placement probe of conv_wino4_kernel: the tree's kernel with 4 / 8 bytes of s_nop in front of the heavy / light wave class's body
 set -u
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r05/run29; mkdir -p $O
