@@ -522,3 +522,23 @@ def test_pointer_rebuilt_from_a_signed_low_half_breaks_when_bit_31_is_set():
             if re.search(r"<<\s*32\)?\s*\|\s*__builtin_amdgcn_readfirstlane", line) or re.search(r"\(unsigned long long\)\s*__builtin_amdgcn_readfirstlane", line):
                 bad.append(f"{os.path.basename(path)}:{n}")
     assert not bad, bad
+
+
+def test_variant_builders_carry_the_makefiles_per_object_flags():
+    """scripts/build_variant.sh / build_variant2.sh rebuild ONE translation unit for A/B runs.  In r05 they lacked conv_wino4.o's
+    -fno-slp-vectorize: every variant of that kernel was an SLP-packed build, 0.3-0.5 ms/step slower than the tree whatever it changed
+    (profiles/r05/x_wino4_variants.txt).  Every `obj.o [obj.o ...]: FLAGS += ...` line of the Makefile must be mirrored in both scripts."""
+    import re
+    mk = open(os.path.join(ROOT, "instancediff_amd", "csrc", "Makefile")).read()
+    per_obj = {}
+    for objs, flags in re.findall(r"^([\w. ]+\.o)\s*:\s*FLAGS\s*\+=\s*(.+)$", mk, re.M):
+        for o in objs.split():
+            per_obj.setdefault(o, []).extend(flags.split())
+    assert per_obj.get("conv_wino4.o") == ["-fno-slp-vectorize"] and "sde.o" in per_obj, per_obj
+    for script in ("build_variant.sh", "build_variant2.sh"):
+        txt = open(os.path.join(ROOT, "scripts", script)).read()
+        cases = {}
+        for objs, flag in re.findall(r"([\w.|]+\.o)\)\s*EXTRA=\"([^\"]+)\"", txt):
+            for o in objs.split("|"):
+                cases.setdefault(o, []).extend(flag.split())
+        assert cases == per_obj, (script, cases, per_obj)
