@@ -11,7 +11,7 @@ mkdir -p /root/repo/instancediff_amd/variants /tmp/variants/$NAME
 cp "$SRC" $CS/_variant_$NAME.hip
 trap 'rm -f $CS/_variant_$NAME.hip' EXIT
 EXTRA=""  # the Makefile's per-object flags (missing until r05: variants of conv_wino4.hip were built with SLP packing on)
-case "$OBJ" in conv_wino4.o|conv_wino4h.o|conv_select.o) EXTRA="-fno-slp-vectorize";; sde.o) EXTRA="-ffp-contract=off";; esac
+case "$OBJ" in conv_wino4.o|conv_wino4h.o|conv_wino4_wgrad.o|conv_select.o) EXTRA="-fno-slp-vectorize";; sde.o) EXTRA="-ffp-contract=off";; esac
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wno-unused-function $EXTRA "$@" -c $CS/_variant_$NAME.hip -o /tmp/variants/$NAME/$OBJ
 rm -f $CS/_variant_$NAME.hip
 OBJS=$(ls $CS/*.o | grep -v "/$OBJ")

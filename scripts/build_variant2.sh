@@ -19,7 +19,7 @@ if [ -n "$SRC" ]; then
   # the Makefile's per-object flags (r05: the first version of this script and build_variant.sh compiled conv_wino4.hip WITHOUT its
   # -fno-slp-vectorize: every variant of that kernel came out 0.3-0.5 ms/step slower than the tree for that reason alone)
   EXTRA=""
-  case "$REPL" in conv_wino4.o|conv_wino4h.o|conv_select.o) EXTRA="-fno-slp-vectorize";; sde.o) EXTRA="-ffp-contract=off";; esac
+  case "$REPL" in conv_wino4.o|conv_wino4h.o|conv_wino4_wgrad.o|conv_select.o) EXTRA="-fno-slp-vectorize";; sde.o) EXTRA="-ffp-contract=off";; esac
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wall -Wno-unused-function $EXTRA "${FLAGS[@]}" -c $CS/_variant_$NAME.hip -o /tmp/variants/$NAME/$REPL
   rm -f $CS/_variant_$NAME.hip
 fi
